@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference.
+
+Run in the build container only (needs /root/reference, which does not exist on
+the GPU box):   python tests/golden/make_golden.py
+
+Every fixture is data: the numpy inputs that were fed to the reference and the
+outputs the reference's own PyTorch (CPU, fp32) code produced for them
+(loss/flow.py, utils/iwe.py, dataloader/encodings.py imported unmodified from
+/root/reference).  No reference source text is stored.
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from taming_event_flow_amd import synth  # noqa: E402
+
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+from loss.flow import Iterative, Linear  # noqa: E402  (reference)
+from utils import iwe as ref_iwe  # noqa: E402  (reference)
+from dataloader import encodings as ref_enc  # noqa: E402  (reference)
+
+torch.set_num_threads(4)
+torch.manual_seed(0)
+
+
+def make_config(H, W, B, P, S, mode="two", spat=None, temp=None, round_ts=False):
+    return {
+        "loader": {"resolution": [H, W], "batch_size": B},
+        "loss": {
+            "flow_spat_smooth_weight": spat,
+            "flow_temp_smooth_weight": temp,
+            "round_ts": round_ts,
+            "iterative_mode": mode,
+        },
+        "data": {"passes_loss": P, "scales_loss": S},
+    }
+
+
+def run_loss(kind, cfg, win):
+    """Feed a synthetic window through the reference loss; return loss + d loss / d flow."""
+    P = len(win["flows"])
+    F = len(win["flows"][0])
+    L = (Iterative if kind == "Iterative" else Linear)(cfg, torch.device("cpu"))
+    flows = [[torch.tensor(win["flows"][t][i], requires_grad=True) for i in range(F)] for t in range(P)]
+    for t in range(P):
+        L.update(
+            flows[t],
+            torch.tensor(win["ev"][t]).clone(),
+            torch.tensor(win["pm"][t]).clone(),
+            torch.tensor(win["dev"][t]).clone(),
+            torch.tensor(win["dpm"][t]).clone(),
+        )
+    assert L.num_passes == P
+    loss = L()
+    loss.backward()
+    g = np.stack([np.stack([flows[t][i].grad.numpy() for i in range(F)]) for t in range(P)])
+    return float(loss.item()), np.float32(loss.item()), g.astype(np.float32)
+
+
+def save_loss_case(name, kind, H, W, B, P, F, S, mode, n_grad, n_det, seed, sigma=1.5, flow_kind="smooth",
+                   ragged=True, spat=None, temp=None, round_ts=False, integer_coords=True):
+    rng = np.random.default_rng(seed)
+    win = synth.make_window(rng, B, H, W, P, F, n_grad, n_det, sigma, flow_kind, ragged, integer_coords)
+    cfg = make_config(H, W, B, P, S, mode, spat, temp, round_ts)
+    loss64, loss32, g = run_loss(kind, cfg, win)
+    meta = dict(kind=kind, H=H, W=W, B=B, P=P, F=F, S=S, mode=mode, spat=spat, temp=temp, round_ts=round_ts,
+                seed=seed, loss=loss64)
+    arrays = {"meta": np.array(json.dumps(meta)), "loss": loss32, "dflows": g,
+              "flows": np.stack([np.stack(win["flows"][t]) for t in range(P)])}
+    for t in range(P):
+        arrays[f"ev{t}"] = win["ev"][t]
+        arrays[f"pm{t}"] = win["pm"][t]
+        arrays[f"dev{t}"] = win["dev"][t]
+        arrays[f"dpm{t}"] = win["dpm"][t]
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: loss={loss64:.7f} |g|max={np.abs(g).max():.4e} size={os.path.getsize(path)/1e3:.0f} kB")
+
+
+def save_primitives(seed=11):
+    """utils/iwe.py primitives on one small batch (values and gradients)."""
+    rng = np.random.default_rng(seed)
+    B, H, W, N = 2, 12, 17, 96
+    fx = torch.tensor(rng.standard_normal((B, H, W)).astype(np.float32), requires_grad=True)
+    fy = torch.tensor(rng.standard_normal((B, H, W)).astype(np.float32), requires_grad=True)
+    # locations (y, x): interior, exact integers, exact far border, and out-of-bounds ones
+    loc = np.stack([rng.random((B, N)) * (H + 3) - 1.5, rng.random((B, N)) * (W + 3) - 1.5], -1).astype(np.float32)
+    loc[:, :8] = np.round(loc[:, :8])
+    loc[:, 8] = [H - 1, W - 1]
+    loc[:, 9] = [0, 0]
+    loc[:, 10] = [H - 1, 3.25]
+    loc_t = torch.tensor(loc, requires_grad=True)
+    ef = ref_iwe.get_event_flow(fx, fy, loc_t)
+    wgt = torch.tensor(rng.standard_normal(ef.shape).astype(np.float32))
+    (ef * wgt).sum().backward()
+    out = {
+        "H": H, "W": W,
+        "gef_fx": fx.detach().numpy(), "gef_fy": fy.detach().numpy(), "gef_loc": loc,
+        "gef_out": ef.detach().numpy(), "gef_w": wgt.numpy(),
+        "gef_dfx": fx.grad.numpy(), "gef_dfy": fy.grad.numpy(), "gef_dloc": loc_t.grad.numpy(),
+    }
+    # event_propagation + purge_unfeasible
+    ts = torch.tensor(rng.random((B, N, 1)).astype(np.float32))
+    prop = ref_iwe.event_propagation(ts, torch.tensor(loc), ef.detach(), 1.0)
+    pm = torch.tensor((rng.random((B, N, 2)) < 0.5).astype(np.float32))
+    ploc, ppm = ref_iwe.purge_unfeasible(prop, pm, (H, W))
+    out.update(prop_ts=ts.numpy(), prop_out=prop.numpy(), purge_pm=pm.numpy(), purge_loc=ploc.numpy(),
+               purge_mask=ppm.numpy())
+    # get_interpolation (+ gradient of sum(w * r) w.r.t. positions) and interpolate
+    pos = torch.tensor(loc, requires_grad=True)
+    idx, w = ref_iwe.get_interpolation(pos, (H, W))
+    r = torch.tensor(rng.standard_normal(w.shape).astype(np.float32))
+    (w * r).sum().backward()
+    img = ref_iwe.interpolate(idx.detach(), w.detach(), (H, W), polarity_mask=torch.cat([pm[:, :, 0:1]] * 4, 1))
+    out.update(gi_idx=idx.detach().numpy(), gi_w=w.detach().numpy(), gi_r=r.numpy(), gi_dpos=pos.grad.numpy(),
+               interp_img=img.numpy())
+    # rounding branch (metrics only)
+    idx_r, w_r = ref_iwe.get_interpolation(torch.tensor(loc), (H, W), round_idx=True)
+    out.update(gi_round_idx=idx_r.numpy(), gi_round_w=w_r.numpy())
+    # iwe_formatting + focus_loss through the loss module
+    cfg = make_config(H, W, B, 4, 1)
+    L = Iterative(cfg, torch.device("cpu"))
+    inb = torch.tensor(loc)
+    tsl = torch.tensor((rng.random((B, N, 1)) * 4).astype(np.float32))
+    pm4 = torch.cat([pm] * 4, 1)
+    iwe, iwe_ts = L.iwe_formatting(inb, pm4, torch.cat([tsl] * 4, 1), 2.0, 2.0)
+    a = iwe_ts / (iwe + 1e-9)
+    fl = L.focus_loss(iwe, a)
+    out.update(fmt_ts=tsl.numpy(), fmt_iwe=iwe.numpy(), fmt_iwe_ts=iwe_ts.numpy(), focus=np.float32(fl.item()))
+    np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)
+    print("primitives: focus=%.6f" % fl.item())
+
+
+def save_encodings(seed=12):
+    """dataloader/encodings.py count / voxel representations."""
+    rng = np.random.default_rng(seed)
+    H, W, N = 15, 22, 700
+    xs = rng.integers(0, W, N).astype(np.float32)
+    ys = rng.integers(0, H, N).astype(np.float32)
+    ts = np.sort(rng.random(N).astype(np.float32))
+    ts = (ts - ts[0]) / (ts[-1] - ts[0])
+    ps = np.where(rng.random(N) < 0.5, -1.0, 1.0).astype(np.float32)
+    cnt = ref_enc.events_to_channels(torch.tensor(xs), torch.tensor(ys), torch.tensor(ps), sensor_size=(H, W))
+    out = {"H": H, "W": W, "xs": xs, "ys": ys, "ts": ts, "ps": ps, "cnt": cnt.numpy()}
+    for bins in (2, 5, 9):
+        vox = ref_enc.events_to_voxel(torch.tensor(xs), torch.tensor(ys), torch.tensor(ts), torch.tensor(ps), bins,
+                                      sensor_size=(H, W))
+        out[f"voxel{bins}"] = vox.numpy()
+    img = ref_enc.events_to_image(torch.tensor(xs), torch.tensor(ys), torch.tensor(ps), sensor_size=(H, W))
+    out["image"] = img.numpy()
+    np.savez_compressed(os.path.join(HERE, "encodings.npz"), **out)
+    print("encodings: cnt sum", float(cnt.sum()))
+
+
+def main():
+    save_primitives()
+    save_encodings()
+    # Iterative (loss/flow.py:415) — the north-star path
+    save_loss_case("it_two_s1_p6", "Iterative", 16, 20, 2, 6, 2, 1, "two", [180, 200, 150, 220, 190, 210],
+                   [0, 60, 0, 80, 40, 0], seed=1)
+    save_loss_case("it_one_s1_p4", "Iterative", 16, 20, 2, 4, 2, 1, "one", [150, 170, 160, 140], [50, 0, 30, 0], seed=2)
+    save_loss_case("it_two_s2_p8", "Iterative", 16, 20, 2, 8, 2, 2, "two", 150, [40, 0, 0, 30, 0, 60, 0, 20], seed=3)
+    save_loss_case("it_two_s3_p8", "Iterative", 12, 14, 2, 8, 1, 3, "two", 100, 0, seed=4)
+    save_loss_case("it_two_s1_p10_f4", "Iterative", 32, 32, 2, 10, 4, 1, "two", 300, 150, seed=5)
+    save_loss_case("it_two_iid", "Iterative", 16, 20, 2, 6, 2, 1, "two", 200, 50, seed=6, sigma=2.0, flow_kind="iid")
+    save_loss_case("it_two_zero_flow", "Iterative", 16, 20, 2, 4, 2, 1, "two", 120, 40, seed=7, flow_kind="zero")
+    save_loss_case("it_two_smooth_terms", "Iterative", 16, 20, 2, 5, 2, 1, "two", 150, 30, seed=8, spat=0.001,
+                   temp=0.1)
+    save_loss_case("it_two_round_ts", "Iterative", 16, 20, 2, 4, 2, 1, "two", 150, 30, seed=9, round_ts=True)
+    save_loss_case("it_two_float_xy", "Iterative", 16, 20, 2, 5, 2, 1, "two", 160, 30, seed=10, integer_coords=False)
+    save_loss_case("it_two_p5_odd", "Iterative", 16, 20, 1, 5, 2, 2, "two", 160, 0, seed=13)
+    # Linear (loss/flow.py:216)
+    save_loss_case("lin_s1_p6", "Linear", 16, 20, 2, 6, 2, 1, "two", [180, 200, 150, 220, 190, 210],
+                   [0, 60, 0, 80, 40, 0], seed=21)
+    save_loss_case("lin_s2_p8", "Linear", 16, 20, 2, 8, 2, 2, "two", 150, 40, seed=22)
+    save_loss_case("lin_smooth_terms", "Linear", 16, 20, 2, 4, 2, 1, "two", 150, 30, seed=23, spat=0.001, temp=0.1)
+    save_loss_case("lin_zero_flow", "Linear", 16, 20, 2, 4, 2, 1, "two", 120, 40, seed=24, flow_kind="zero")
+
+
+if __name__ == "__main__":
+    main()
