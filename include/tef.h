@@ -1,0 +1,103 @@
+/*
+ * tef.h — C ABI of libtef_hip.so, the MI355X (gfx950) implementation of the
+ * tudelft/taming_event_flow training hot path.
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; each entry point below
+ * names the reference code it replaces (path:line under the reference tree).  The Python
+ * host modules in taming_event_flow_amd/ (loss/flow.py, dataloader/encodings.py,
+ * models/...) bind these with ctypes and keep the reference's module API.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name ends in _host;
+ *   - the caller owns every buffer, including workspaces (size queries are provided);
+ *     the library never allocates or frees device memory and keeps no mutable global state;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no implicit sync;
+ *   - return value: 0 = ok, TEF_ERR_* < 0 otherwise (never throws across the ABI);
+ *     tef_last_error() returns a static description of the last failure of the calling thread.
+ */
+#ifndef TEF_H
+#define TEF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEF_VERSION 1
+#define TEF_MAX_PASSES 64     /* passes_loss upper bound */
+#define TEF_MAX_SCALES 6      /* scales_loss upper bound */
+
+#define TEF_ERR_INVALID   (-1)   /* bad argument / unsupported configuration */
+#define TEF_ERR_WORKSPACE (-2)   /* workspace too small */
+#define TEF_ERR_LAUNCH    (-3)   /* HIP launch failure (see tef_last_error) */
+
+#define TEF_KIND_ITERATIVE 0     /* loss/flow.py:415 Iterative */
+#define TEF_KIND_LINEAR    1     /* loss/flow.py:216 Linear    */
+
+int tef_version(void);
+const char *tef_last_error(void);
+
+/* Event list of one loss window in structure-of-arrays form, [B][cap] per array.
+ * Slots of pass t occupy [off[t], off[t+1]) of every sample's row (see tef_loss_cfg).
+ * ts already carries the "+ pass index" shift of loss/flow.py:457-458 (tef_pack_events adds it).
+ * mp/mn = polarity mask columns (pos, neg) of dataloader/base.py:265-278.
+ * bin[cap] = pass index of each slot (shared by all samples). */
+typedef struct tef_events {
+    const float *ts, *y, *x, *mp, *mn;
+    const uint8_t *bin;
+    int cap;
+} tef_events;
+
+/* One loss window.  Mirrors what BaseEventWarping/Iterative/Linear.__init__ read from the
+ * config (loss/flow.py:25-28, 42-44, 434-441) plus the per-pass event counts. */
+typedef struct tef_loss_cfg {
+    int kind;                 /* TEF_KIND_* */
+    int B, H, W;              /* loader.batch_size, loader.resolution */
+    int P;                    /* data.passes_loss (= number of update() calls in the window) */
+    int F;                    /* number of flow heads per pass (len(flow_list)) */
+    int S;                    /* data.scales_loss */
+    int mode_div;             /* Iterative: 1 = iterative_mode "one", 2 = "two" */
+    int M, Md;                /* total grad / detached slots per sample */
+    int off[TEF_MAX_PASSES + 1];    /* grad slot offsets per pass */
+    int doff[TEF_MAX_PASSES + 1];   /* detached slot offsets per pass */
+} tef_loss_cfg;
+
+/* AoS -> SoA packing of one pass, replaces the bookkeeping of Iterative.update / Linear.update
+ * (loss/flow.py:443-476, 233-288): adds `ts_shift` to ev[:, :, 0] IN PLACE (reference side effect,
+ * :457-458) and appends the pass at slot `slot0` of the SoA arrays.  If ts_override >= 0 the stored
+ * timestamp is that constant instead (round_ts, :461-463).  ev [B,N,4] (ts,y,x,p), pm [B,N,2]. */
+int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
+                    int slot0, int cap, float *ts, float *y, float *x, float *mp, float *mn, uint8_t *bin,
+                    void *stream);
+
+/* Workspace (bytes) needed by tef_loss_forward + tef_loss_backward for this window. */
+size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg);
+
+/* Contrast-maximisation loss forward: Iterative.forward (loss/flow.py:588-736) or Linear.forward (:306-402),
+ * without the optional smoothing terms (see tef_smoothing_*).
+ *   flows  [P][F][B][2][H][W]  (channel 0 = x, 1 = y; already multiplied by flow_scaling by the caller)
+ *   grad / det: event lists with / without gradient (det may have Md = 0)
+ *   loss_out: one float.  The workspace keeps what tef_loss_backward needs. */
+int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows, const tef_events *grad, const tef_events *det,
+                     void *workspace, size_t workspace_bytes, float *loss_out, void *stream);
+
+/* d loss / d flows, same layout as flows; grad_out = upstream scalar gradient (device pointer).
+ * Must follow tef_loss_forward on the same workspace.  dflows is fully overwritten. */
+int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows, const tef_events *grad, const tef_events *det,
+                      void *workspace, size_t workspace_bytes, const float *grad_out, float *dflows, void *stream);
+
+/* Optional Charbonnier priors of loss/flow.py:170-209 (spatial) and :131-168 (temporal) on the flow maps of
+ * the window.  weight < 0 disables a term.  loss_out += term (accumulates onto the CM loss);
+ * backward ADDS into dflows.  scratch: tef_smoothing_scratch_bytes(). */
+size_t tef_smoothing_scratch_bytes(const tef_loss_cfg *cfg);
+int tef_smoothing_forward(const tef_loss_cfg *cfg, const float *flows, float spat_weight, float temp_weight,
+                          void *scratch, float *loss_out, void *stream);
+int tef_smoothing_backward(const tef_loss_cfg *cfg, const float *flows, float spat_weight, float temp_weight,
+                           void *scratch, const float *grad_out, float *dflows, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEF_H */

@@ -1,0 +1,93 @@
+"""ctypes binding of libtef_hip.so (C ABI declared in include/tef.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a RuntimeError is
+raised.  (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+
+import ctypes
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "libtef_hip.so")
+
+TEF_MAX_PASSES = 64
+TEF_MAX_SCALES = 6
+KIND_ITERATIVE = 0
+KIND_LINEAR = 1
+
+_fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class Events(ctypes.Structure):
+    """struct tef_events (include/tef.h)"""
+
+    _fields_ = [("ts", _fp), ("y", _fp), ("x", _fp), ("mp", _fp), ("mn", _fp), ("bin", _fp), ("cap", ctypes.c_int)]
+
+
+class LossCfg(ctypes.Structure):
+    """struct tef_loss_cfg (include/tef.h)"""
+
+    _fields_ = [
+        ("kind", ctypes.c_int), ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+        ("P", ctypes.c_int), ("F", ctypes.c_int), ("S", ctypes.c_int), ("mode_div", ctypes.c_int),
+        ("M", ctypes.c_int), ("Md", ctypes.c_int),
+        ("off", ctypes.c_int * (TEF_MAX_PASSES + 1)), ("doff", ctypes.c_int * (TEF_MAX_PASSES + 1)),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/tef.h declares
+SIGNATURES = {
+    "tef_version": (ctypes.c_int, []),
+    "tef_last_error": (ctypes.c_char_p, []),
+    "tef_pack_events": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),
+    "tef_loss_forward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.POINTER(Events), ctypes.POINTER(Events),
+                                        _fp, ctypes.c_size_t, _fp, _fp]),
+    "tef_loss_backward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.POINTER(Events), ctypes.POINTER(Events),
+                                         _fp, ctypes.c_size_t, _fp, _fp, _fp]),
+    "tef_smoothing_scratch_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),
+    "tef_smoothing_forward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.c_float, ctypes.c_float, _fp, _fp,
+                                             _fp]),
+    "tef_smoothing_backward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.c_float, ctypes.c_float, _fp, _fp,
+                                              _fp, _fp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libtef_hip.so once; fail loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `python taming_event_flow_amd/build.py`). There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().tef_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def require_device_tensor(t, name):
+    """The HIP path only runs on device tensors; anything else is an error, not a fallback."""
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); the MI355X path has no CPU fallback")
+    return t
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,290 @@
+"""Contrast-maximisation loss modules — drop-in for the reference's ``loss/flow.py``.
+
+Same public surface as the reference (`BaseEventWarping` loss/flow.py:14, `Linear` :216, `Iterative` :415):
+``L = Iterative(config, device)``, ``L.update(flow_list, event_list, pol_mask, d_event_list, d_pol_mask)``,
+``L.num_passes``, ``loss = L()``, ``L.reset()``; the same config keys are read
+(``loader.resolution|batch_size``, ``loss.flow_spat_smooth_weight|flow_temp_smooth_weight|round_ts|iterative_mode``,
+``data.passes_loss|scales_loss``) and ``update`` keeps the reference's in-place time shift of the caller's event
+lists (loss/flow.py:457-458).
+
+All arithmetic runs in the hand-written HIP kernels of libtef_hip.so (include/tef.h); this file only owns
+buffers, bookkeeping and the autograd boundary.  There is no PyTorch/CPU fallback.
+"""
+
+import ctypes
+
+import torch
+
+from .. import _lib
+
+__all__ = ["BaseEventWarping", "Linear", "Iterative"]
+
+
+class _SoA:
+    """Growable structure-of-arrays event store for one list (grad or detached) of one window."""
+
+    def __init__(self, B, device):
+        self.B, self.device = B, device
+        self.cap = 0
+        self.n = 0
+        self.off = [0]
+        self.ts = self.y = self.x = self.mp = self.mn = self.bin = None
+
+    def _grow(self, need):
+        cap = max(need, 2 * self.cap, 1024)
+        new = [torch.empty((self.B, cap), dtype=torch.float32, device=self.device) for _ in range(5)]
+        nbin = torch.empty((cap,), dtype=torch.uint8, device=self.device)
+        if self.n:
+            for dst, src in zip(new, (self.ts, self.y, self.x, self.mp, self.mn)):
+                dst[:, : self.n].copy_(src[:, : self.n])
+            nbin[: self.n].copy_(self.bin[: self.n])
+        self.ts, self.y, self.x, self.mp, self.mn = new
+        self.bin = nbin
+        self.cap = cap
+
+    def append(self, ev, pm, pass_idx, ts_override):
+        """Pack one pass ([B,N,4], [B,N,2]); shifts ev[:, :, 0] in place by pass_idx."""
+        B, N = ev.shape[0], ev.shape[1]
+        if B != self.B:
+            raise RuntimeError(f"event list batch {B} != config loader.batch_size {self.B}")
+        if self.n + N > self.cap:
+            self._grow(self.n + N)
+        if N:
+            in_place = ev.is_contiguous() and ev.dtype == torch.float32 and ev.data_ptr() % 16 == 0
+            if in_place:
+                src, shift = ev, float(pass_idx)
+            else:  # exotic views: keep the side effect with a strided add, pack a contiguous copy
+                ev[:, :, 0:1] += pass_idx
+                src, shift = ev.to(torch.float32).contiguous(), 0.0
+            pmc = pm.to(torch.float32).contiguous()
+            rc = _lib.lib().tef_pack_events(
+                src.data_ptr(), pmc.data_ptr(), B, N, shift, ts_override, pass_idx, self.n, self.cap,
+                self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(), self.mn.data_ptr(),
+                self.bin.data_ptr(), _lib.stream_ptr(),
+            )
+            _lib.check(rc, "tef_pack_events")
+        self.n += N
+        self.off.append(self.n)
+
+    def struct(self):
+        if self.cap == 0:
+            self._grow(1)
+        return _lib.Events(self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(),
+                           self.mn.data_ptr(), self.bin.data_ptr(), self.cap)
+
+
+class _Window:
+    """Device state of one loss window (everything the kernels read)."""
+
+    def __init__(self, B, device):
+        self.flows = None          # [P][F][B][2][H][W]
+        self.flow_refs = []        # autograd handles, flow_refs[t][i]
+        self.grad = _SoA(B, device)
+        self.det = _SoA(B, device)
+        self.workspace = None
+        self.scratch = None
+        self.cfg = None
+
+
+class _CMLossFn(torch.autograd.Function):
+    """Autograd boundary: inputs are the F*P flow tensors of the window, output the scalar loss."""
+
+    @staticmethod
+    def forward(ctx, module, win, *flows):
+        lib = _lib.lib()
+        cfg = win.cfg
+        loss = torch.zeros((), dtype=torch.float32, device=win.flows.device)
+        g, d = win.grad.struct(), win.det.struct()
+        rc = lib.tef_loss_forward(ctypes.byref(cfg), win.flows.data_ptr(), ctypes.byref(g), ctypes.byref(d),
+                                  win.workspace.data_ptr(), win.workspace.numel(), loss.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "tef_loss_forward")
+        ws, wt = module._smooth_weights(cfg.P)
+        if ws >= 0 or wt >= 0:
+            rc = lib.tef_smoothing_forward(ctypes.byref(cfg), win.flows.data_ptr(), ws, wt, win.scratch.data_ptr(),
+                                           loss.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "tef_smoothing_forward")
+        ctx.win = win
+        ctx.smooth = (ws, wt)
+        ctx.shape = tuple(flows[0].shape)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.lib()
+        win, cfg = ctx.win, ctx.win.cfg
+        go = grad_out.to(torch.float32).contiguous()
+        dflows = torch.empty_like(win.flows)
+        g, d = win.grad.struct(), win.det.struct()
+        rc = lib.tef_loss_backward(ctypes.byref(cfg), win.flows.data_ptr(), ctypes.byref(g), ctypes.byref(d),
+                                   win.workspace.data_ptr(), win.workspace.numel(), go.data_ptr(), dflows.data_ptr(),
+                                   _lib.stream_ptr())
+        _lib.check(rc, "tef_loss_backward")
+        ws, wt = ctx.smooth
+        if ws >= 0 or wt >= 0:
+            rc = lib.tef_smoothing_backward(ctypes.byref(cfg), win.flows.data_ptr(), ws, wt, win.scratch.data_ptr(),
+                                            go.data_ptr(), dflows.data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "tef_smoothing_backward")
+        P, F = cfg.P, cfg.F
+        grads = tuple(dflows[t, i] for t in range(P) for i in range(F))
+        return (None, None) + grads
+
+
+class BaseEventWarping(torch.nn.Module):
+    """Base class for the contrast maximization loss (reference loss/flow.py:14-213)."""
+
+    _kind = None
+
+    def __init__(self, config, device, loss_scaling=True, border_compensation=True):
+        super().__init__()
+        if not loss_scaling or not border_compensation:
+            raise NotImplementedError("the HIP path implements loss_scaling=True, border_compensation=True "
+                                      "(the only values the reference's training loop uses)")
+        self.device = torch.device(device)
+        self.config = config
+        self.loss_scaling = loss_scaling
+        self.border_compensation = border_compensation
+        self.res = config["loader"]["resolution"]
+        self.batch_size = config["loader"]["batch_size"]
+        self.flow_spat_smooth_weight = config["loss"]["flow_spat_smooth_weight"]
+        self.flow_temp_smooth_weight = config["loss"]["flow_temp_smooth_weight"]
+
+        self._passes = 0
+        self._num_flows = None
+        self._win = None
+
+        # timescales for loss computation (loss/flow.py:42-44)
+        self.passes_loss = []
+        for s in range(config["data"]["scales_loss"]):
+            self.passes_loss.append(config["data"]["passes_loss"] // (2**s))
+
+    # ---- reference API -------------------------------------------------------------------------
+    @property
+    def num_passes(self):
+        return self._passes
+
+    def update_base(self, flow_list):
+        """Append the flow maps of one pass (reference loss/flow.py:46-66)."""
+        if self._num_flows is None:
+            self._num_flows = len(flow_list)
+        if len(flow_list) != self._num_flows:
+            raise RuntimeError("number of flow maps changed inside a loss window")
+        P = max(self.passes_loss)
+        if self._passes >= P:
+            raise RuntimeError(f"update() called more than data.passes_loss={P} times without reset()")
+        H, W = self.res
+        B, F = self.batch_size, self._num_flows
+        win = self._win
+        if win is None:
+            win = self._win = _Window(B, self.device)
+        if win.flows is None:
+            _lib.require_device_tensor(flow_list[0], "flow map")
+            win.flows = torch.empty((P, F, B, 2, H, W), dtype=torch.float32, device=flow_list[0].device)
+        refs = []
+        for i, flow in enumerate(flow_list):
+            if tuple(flow.shape) != (B, 2, H, W):
+                raise RuntimeError(f"flow map {i} has shape {tuple(flow.shape)}, expected {(B, 2, H, W)}")
+            win.flows[self._passes, i].copy_(flow.detach())
+            refs.append(flow)
+        win.flow_refs.append(refs)
+
+    def reset_base(self):
+        self._passes = 0
+        self._win = None
+
+    def _update_events(self, event_list, pol_mask, d_event_list, d_pol_mask):
+        """Shared tail of Linear.update / Iterative.update (loss/flow.py:246-263, :456-476)."""
+        win = self._win
+        for name, t in (("event_list", event_list), ("pol_mask", pol_mask), ("d_event_list", d_event_list),
+                        ("d_pol_mask", d_pol_mask)):
+            _lib.require_device_tensor(t, name)
+        ovr = d_ovr = -1.0
+        if self.config["loss"]["round_ts"]:
+            # event_ts[...] = event_ts.min() + 0.5 over the shifted list (loss/flow.py:461-463)
+            ovr = float(event_list[:, :, 0].min().item()) + self._passes + 0.5
+            if d_event_list.shape[1] > 0:
+                d_ovr = float(d_event_list[:, :, 0].min().item()) + self._passes + 0.5
+        win.grad.append(event_list, pol_mask, self._passes, ovr)
+        win.det.append(d_event_list, d_pol_mask, self._passes, d_ovr)
+        self._passes += 1
+
+    def _smooth_weights(self, P):
+        ws = -1.0 if self.flow_spat_smooth_weight is None else float(self.flow_spat_smooth_weight)
+        wt = -1.0 if (self.flow_temp_smooth_weight is None or P < 2) else float(self.flow_temp_smooth_weight)
+        return ws, wt
+
+    def _make_cfg(self):
+        win = self._win
+        P = max(self.passes_loss)
+        cfg = _lib.LossCfg()
+        cfg.kind = self._kind
+        cfg.B, cfg.H, cfg.W = self.batch_size, self.res[0], self.res[1]
+        cfg.P, cfg.F, cfg.S = P, self._num_flows, len(self.passes_loss)
+        cfg.mode_div = getattr(self, "_mode_div", 1)
+        cfg.M, cfg.Md = win.grad.n, win.det.n
+        for t in range(P + 1):
+            cfg.off[t] = win.grad.off[t]
+            cfg.doff[t] = win.det.off[t]
+        return cfg
+
+    def forward(self):
+        win = self._win
+        P = max(self.passes_loss)
+        if win is None or self._passes != P:
+            raise RuntimeError(f"loss called after {self._passes} update() calls; data.passes_loss={P} are required")
+        lib = _lib.lib()
+        win.cfg = cfg = self._make_cfg()
+        nbytes = lib.tef_loss_workspace_bytes(ctypes.byref(cfg))
+        if nbytes == 0:
+            _lib.check(-1, "tef_loss_workspace_bytes")
+        win.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=win.flows.device)
+        ws, wt = self._smooth_weights(P)
+        if ws >= 0 or wt >= 0:
+            win.scratch = torch.empty((lib.tef_smoothing_scratch_bytes(ctypes.byref(cfg)),), dtype=torch.uint8,
+                                      device=win.flows.device)
+        flat = [f for refs in win.flow_refs for f in refs]
+        return _CMLossFn.apply(self, win, *flat)
+
+
+class Linear(BaseEventWarping):
+    """Contrast maximization loss from Hagenaars and Paredes-Valles et al. (NeurIPS 2021) — reference loss/flow.py:216."""
+
+    _kind = _lib.KIND_LINEAR
+
+    def __init__(self, config, device, loss_scaling=True):
+        super().__init__(config, device, loss_scaling=loss_scaling)
+
+    def update(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
+        """reference loss/flow.py:233-288.  The per-event flow lookup of :268-283 happens inside the HIP forward
+        (the map of the event's own pass is the "latest" map at update time)."""
+        self.update_base(flow_list)
+        self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
+
+    def reset(self):
+        self.reset_base()
+
+
+class Iterative(BaseEventWarping):
+    """CM loss with iterative event warping, loss at all intermediate times and multiple temporal scales (ICCV 2023)
+    — reference loss/flow.py:415."""
+
+    _kind = _lib.KIND_ITERATIVE
+
+    def __init__(self, config, device, loss_scaling=True):
+        mode = config["loss"]["iterative_mode"]
+        if mode == "four":
+            # the reference doubles passes_loss here (loss/flow.py:422-423) and then fails with a TypeError in
+            # forward (:674-692, shared mask list holds None); there is no behaviour to reproduce
+            raise NotImplementedError("iterative_mode 'four' raises TypeError in the reference implementation itself")
+        if mode not in ("one", "two"):
+            raise ValueError(f"Unknown iterative_mode: {mode}")
+        super().__init__(config, device, loss_scaling=loss_scaling)
+        self._mode_div = {"one": 1, "two": 2}[mode]
+        self.delta_passes = [p // self._mode_div for p in self.passes_loss]   # loss/flow.py:434-441
+
+    def update(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
+        """reference loss/flow.py:443-476"""
+        self.update_base(flow_list)
+        self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
+
+    def reset(self):
+        self.reset_base()

@@ -1,0 +1,140 @@
+"""GPU parity tests of the HIP loss path (through the C ABI) against the golden vectors recorded from the
+reference and against the CPU oracle.  North-star tolerance: 1e-4 relative, fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import ITERATIVE_CASES, LINEAR_CASES, load_case, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def make_cfg(meta):
+    return {
+        "loader": {"resolution": [meta["H"], meta["W"]], "batch_size": meta["B"]},
+        "loss": {"flow_spat_smooth_weight": meta["spat"], "flow_temp_smooth_weight": meta["temp"],
+                 "round_ts": meta["round_ts"], "iterative_mode": meta["mode"]},
+        "data": {"passes_loss": meta["P"], "scales_loss": meta["S"]},
+    }
+
+
+def run_hip(kind, cfg, win, dev, grad_scale=None):
+    from taming_event_flow_amd.loss.flow import Iterative, Linear
+
+    P, F = len(win["flows"]), len(win["flows"][0])
+    L = (Iterative if kind == "Iterative" else Linear)(cfg, dev)
+    flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
+    evs = []
+    for t in range(P):
+        ev = torch.tensor(win["ev"][t], device=dev)
+        dev_ = torch.tensor(win["dev"][t], device=dev)
+        evs.append((ev, dev_))
+        L.update(flows[t], ev, torch.tensor(win["pm"][t], device=dev), dev_, torch.tensor(win["dpm"][t], device=dev))
+    assert L.num_passes == P
+    loss = L()
+    (loss if grad_scale is None else loss * grad_scale).backward()
+    g = np.stack([np.stack([flows[t][i].grad.cpu().numpy() for i in range(F)]) for t in range(P)])
+    L.reset()
+    assert L.num_passes == 0
+    return float(loss.item()), g, evs
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import __graft_entry__ as g
+
+    g.build()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES)
+def test_golden_cases(name, dev):
+    meta, win, loss, dflows = load_case(name)
+    l, g, evs = run_hip(meta["kind"], make_cfg(meta), win, dev)
+    assert abs(l - loss) <= TOL * abs(loss), (l, float(loss))
+    assert rel_err(g, dflows) <= TOL
+    for t in range(meta["P"]):
+        # in-place time shift of the caller's lists (reference loss/flow.py:457-458)
+        np.testing.assert_allclose(evs[t][0][:, :, 0].cpu().numpy(), win["ev"][t][:, :, 0] + t, rtol=0, atol=0)
+        np.testing.assert_allclose(evs[t][1][:, :, 0].cpu().numpy(), win["dev"][t][:, :, 0] + t, rtol=0, atol=0)
+        for i in range(meta["F"]):
+            if np.abs(dflows[t, i]).max() > 0:
+                assert rel_err(g[t, i], dflows[t, i]) <= 2e-3, (t, i)
+
+
+def test_upstream_gradient_scaling(dev):
+    meta, win, loss, dflows = load_case("it_two_s1_p6")
+    l, g, _ = run_hip("Iterative", make_cfg(meta), win, dev, grad_scale=3.0)
+    assert rel_err(g, 3.0 * dflows) <= TOL
+
+
+@pytest.mark.parametrize("kind,H,W,B,P,F,S,N,Nd", [
+    ("Iterative", 128, 128, 2, 10, 4, 1, 3000, 0),       # BASELINE resolution / window, reduced batch + events
+    ("Iterative", 128, 128, 1, 8, 2, 2, 2000, 500),
+    ("Iterative", 180, 240, 1, 4, 2, 1, 3000, 0),        # needs two LDS row bands (240*8*180 > 128 KiB)
+    ("Linear", 128, 128, 2, 10, 4, 1, 3000, 1000),
+    ("Linear", 64, 96, 2, 8, 2, 2, 1500, 0),
+])
+def test_against_oracle_mid_size(kind, H, W, B, P, F, S, N, Nd, dev):
+    from oracle import oracle
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(100 + H + P)
+    win = synth.make_window(rng, B, H, W, P, F, N, Nd, sigma=2.0, ragged=True)
+    meta = dict(H=H, W=W, B=B, P=P, S=S, mode="two", spat=None, temp=None, round_ts=False)
+    l, g, _ = run_hip(kind, make_cfg(meta), win, dev)
+    ow = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=S, mode="two")
+    ol, od = ow.loss(kind)
+    assert abs(l - ol) <= TOL * abs(ol), (l, float(ol))
+    assert rel_err(g, od) <= TOL
+
+
+def test_empty_and_padding_only_lists(dev):
+    """N = 0 detached lists, a pass with zero grad events, and all-padding samples."""
+    from oracle import oracle
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(5)
+    B, H, W, P, F = 2, 16, 20, 4, 2
+    win = synth.make_window(rng, B, H, W, P, F, [50, 0, 70, 40], 0, sigma=1.0)
+    win["ev"][2][1] = 0
+    win["pm"][2][1] = 0   # sample 1 of pass 2 is pure collate padding
+    meta = dict(H=H, W=W, B=B, P=P, S=1, mode="two", spat=None, temp=None, round_ts=False)
+    l, g, _ = run_hip("Iterative", make_cfg(meta), win, dev)
+    ol, od = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"]).iterative()
+    assert abs(l - ol) <= TOL * abs(ol)
+    assert rel_err(g, od) <= TOL
+
+
+def test_full_size_properties(dev):
+    """BASELINE config (128x128, B=8, P=10, F=4, N=10k): size-independent properties instead of the slow oracle."""
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(7)
+    B, H, W, P, F, N = 8, 128, 128, 10, 4, 10000
+    win = synth.make_window(rng, B, H, W, P, F, N, 0, sigma=2.0)
+    meta = dict(H=H, W=W, B=B, P=P, S=1, mode="two", spat=None, temp=None, round_ts=False)
+    l1, g1, _ = run_hip("Iterative", make_cfg(meta), win, dev)
+    assert np.isfinite(l1) and np.isfinite(g1).all()
+    # (1) the loss is a SUM over batch samples (reference loss/flow.py:129): per-sample windows add up
+    tot = 0.0
+    for b in (0, 5):
+        sub = {k: [[m[b:b + 1] for m in row] for row in win["flows"]] if k == "flows" else [a[b:b + 1] for a in win[k]]
+               for k in win}
+        m1 = dict(meta, B=1)
+        lb, gb, _ = run_hip("Iterative", make_cfg(m1), sub, dev)
+        assert rel_err(gb[:, :, 0], g1[:, :, b]) <= TOL
+        tot += lb
+    # (2) event order inside a pass is irrelevant (scatter-add is a sum): permute events, same result
+    perm = rng.permutation(N)
+    win2 = dict(win)
+    win2["ev"] = [a[:, perm] for a in win["ev"]]
+    win2["pm"] = [a[:, perm] for a in win["pm"]]
+    l2, g2, _ = run_hip("Iterative", make_cfg(meta), win2, dev)
+    assert abs(l1 - l2) <= TOL * abs(l1)
+    assert rel_err(g2, g1) <= TOL
+    # (3) mean timestamps are in [0, 1] so every image term is in [0, 2]; loss <= 2 * B
+    assert 0.0 < l1 <= 2.0 * B
