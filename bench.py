@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py — events/s through the IWE + contrast-maximisation loss (BASELINE.json metric).
+
+A step = one pass of the hot path over one loss window: `loss = L(); loss.backward()` of the
+`Iterative` loss (mode "two", scales_loss 1) on B=8 samples x P=10 passes x N=10 000 events at
+128x128 with F=4 flow heads — BASELINE.json configs[1].  Inputs (flow maps, event lists) are
+resident in HBM and already handed to `update()` when the timed region starts (SURVEY.md §8d:
+`update()` is excluded from t and reported separately as `ms_update_per_window`).
+
+Multi-GPU: one process per GPU, the batch dimension shards with no data-path collective (the loss
+is a sum over samples, reference loss/flow.py:129); weak scaling, per-GPU B fixed.
+
+Prints ONE JSON line (rank 0).
+"""
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--passes", type=int, default=10)
+    ap.add_argument("--events", type=int, default=10000, help="grad events per pass per sample")
+    ap.add_argument("--detached", type=int, default=0, help="detached events per pass per sample")
+    ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--res", type=int, nargs=2, default=[128, 128])
+    ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
+    ap.add_argument("--warping", default="Iterative", choices=["Iterative", "Linear"])
+    ap.add_argument("--windows", type=int, default=2, help="distinct pre-staged windows cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def make_cfg(a):
+    return {
+        "loader": {"resolution": list(a.res), "batch_size": a.batch},
+        "loss": {"flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "round_ts": False,
+                 "iterative_mode": "two", "warping": a.warping},
+        "data": {"passes_loss": a.passes, "scales_loss": 1},
+    }
+
+
+def algorithmic_bytes(a, delta):
+    """Per-launch algorithmic bytes of each kernel for the Iterative window."""
+    B, P, F, N, Nd = a.batch, a.passes, a.heads, a.events, a.detached
+    H, W = a.res
+    HW, FB, Mt, M = H * W, F * B, P * (N + Nd), P * N
+    pairs = 0           # (tref, bin) pairs of one window = image/bin incidences
+    for tref in range(P + 1):
+        pairs += max(0, min(P, tref + delta) - max(0, tref - delta))
+    nimg = P + 1
+    splats = pairs * (N + Nd) * FB
+    maps = P * FB * 2 * HW * 4
+    return {
+        # 16 B per event-splat (position 8 + timestamp 4 + mask word 4)  [SURVEY.md §8d]; write-out excluded
+        "iwe_splat": splats * 16,
+        # per (event, head): 12 B event + 8 B masks in, (P+1) positions + 1 meta word out; flow maps once
+        "warp": FB * Mt * (20 + (P + 1) * 8 + 4) + maps,
+        # per (grad event, head): trajectory in, one vector per map out; IWEs + flow maps once
+        "chain_bwd": FB * M * (20 + (P + 1) * 8 + P * 8) + nimg * FB * 2 * HW * 8 + maps,
+        # per (grad event, head, map): vector 8 + position 8; gradient maps written once
+        "dflow_splat": FB * M * P * 16 + maps,
+        "image_stats": nimg * FB * 2 * HW * 8,
+    }, splats
+
+
+def main():
+    a = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if dist:
+        dist.barrier()
+    from taming_event_flow_amd import _lib, synth
+    from taming_event_flow_amd.loss.flow import Iterative, Linear
+
+    lib = _lib.lib()
+    H, W = a.res
+    B, P, F = a.batch, a.passes, a.heads
+    cfg = make_cfg(a)
+    cls = Iterative if a.warping == "Iterative" else Linear
+
+    # ---- stage `windows` distinct loss windows (untimed): synthetic inputs -> HBM -> update() -----------------
+    staged, host_windows = [], []
+    t_update = 0.0
+    for wi in range(a.windows):
+        rng = np.random.default_rng(1000 * rank + wi)
+        win = synth.make_window(rng, B, H, W, P, F, a.events, a.detached, sigma=2.0, kind=a.flow)
+        host_windows.append(win)
+        flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
+        evs = [(torch.tensor(win["ev"][t], device=dev), torch.tensor(win["pm"][t], device=dev),
+                torch.tensor(win["dev"][t], device=dev), torch.tensor(win["dpm"][t], device=dev)) for t in range(P)]
+        L = cls(cfg, dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(P):
+            L.update(flows[t], *evs[t])
+        torch.cuda.synchronize()
+        t_update += time.perf_counter() - t0
+        staged.append((L, flows))
+
+    def step(k):
+        L, flows = staged[k % len(staged)]
+        loss = L()
+        loss.backward()
+        return loss
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(a.warmup):
+        step(k)
+    barrier()
+    lib.tef_profile_enable(1)       # HIP events around every kernel, on the launch stream
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        last = step(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.tef_profile_collect()
+    kern = {}
+    for s in range(lib.tef_profile_slots()):
+        n = lib.tef_profile_calls(s)
+        if n:
+            kern[lib.tef_profile_name(s).decode()] = (lib.tef_profile_ms(s) / n, n)
+    lib.tef_profile_enable(0)
+    loss_val = float(last.item())
+
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    events_per_step = B * P * (a.events + a.detached)
+    total_events = events_per_step * a.steps * world
+    value = total_events / elapsed
+
+    if rank == 0:
+        delta = a.passes // 2
+        alg, splats = algorithmic_bytes(a, delta)
+        kernels = {}
+        for name, (ms, n) in kern.items():
+            e = {"ms": round(ms, 5), "calls_per_step": round(n / a.steps, 3)}
+            if name in alg and a.warping == "Iterative":
+                e["algorithmic_bytes"] = alg[name]
+                e["GBps"] = round(alg[name] / (ms * 1e-3) / 1e9, 1)
+            kernels[name] = e
+        dominant = max(kern, key=lambda k_: kern[k_][0] * kern[k_][1]) if kern else None
+        roofline = None
+        if dominant and dominant in alg and a.warping == "Iterative":
+            ach = alg[dominant] / (kern[dominant][0] * 1e-3) / 1e9
+            roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        out = {
+            "metric": "events/sec through IWE+contrast-max loss, 128x128 bs=8",
+            "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.warping}/two loss fwd+bwd, {H}x{W}, B={B}/GPU, P={P}, F={F}, "
+                                   f"N={a.events}+{a.detached} events/pass/sample, {a.flow} flows sigma=2px "
+                                   "(BASELINE.json configs[1])",
+                       "global_batch": B * world, "events_per_window_per_gpu": events_per_step,
+                       "parallelism": f"dp{world} (batch-sharded, no data-path collective)"},
+            "loss": round(loss_val, 6),
+            "ms_update_per_window": round(1e3 * t_update / a.windows, 3),
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        if "iwe_splat" in kernels and "GBps" in kernels["iwe_splat"]:
+            out["roofline_scatter"] = {
+                "kernel": "iwe_splat", "bound": "hbm", "achieved": kernels["iwe_splat"]["GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "splats_per_launch": splats}
+        if not a.no_cpu_baseline and a.warping == "Iterative":
+            out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, win):
+    """The CPU restatement (oracle/, "port") on the host cores: one window of the same workload,
+    all (head, sample) pairs in parallel over the available cores; bounded to ~10-30 s."""
+    from oracle import oracle
+
+    ncores = len(os.sched_getaffinity(0))
+    nthr = oracle.threads(ncores)
+    bs = a.cpu_batch or a.batch
+    sub = {k: ([[m[:bs] for m in row] for row in win["flows"]] if k == "flows" else [x[:bs] for x in win[k]])
+           for k in win}
+    w = oracle.Window(sub["flows"], sub["ev"], sub["pm"], sub["dev"], sub["dpm"], S=1, mode="two")
+    t0 = time.perf_counter()
+    loss, _ = w.iterative(backward=True)
+    dt = time.perf_counter() - t0
+    ev = bs * a.passes * (a.events + a.detached)
+    return {"value": round(ev / dt, 1), "unit": "events/s", "cores": nthr, "kind": "port",
+            "sample": f"1 window, B={bs}, same P/F/N/resolution as the GPU workload, fwd+bwd, {dt:.2f} s",
+            "loss": round(float(loss), 6)}
+
+
+if __name__ == "__main__":
+    main()

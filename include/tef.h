@@ -10,7 +10,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer to contiguous fp32 unless the name ends in _host;
  *   - the caller owns every buffer, including workspaces (size queries are provided);
- *     the library never allocates or frees device memory and keeps no mutable global state;
+ *     the library never allocates or frees device memory and keeps no mutable global state
+ *     (except the opt-in profiling accumulators below);
  *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no implicit sync;
  *   - return value: 0 = ok, TEF_ERR_* < 0 otherwise (never throws across the ABI);
  *     tef_last_error() returns a static description of the last failure of the calling thread.
@@ -38,6 +39,17 @@ extern "C" {
 
 int tef_version(void);
 const char *tef_last_error(void);
+
+/* Opt-in per-kernel timing for bench.py's roofline line: while enabled, HIP events are recorded on the
+ * launch stream around every kernel (the only mutable process state the library keeps).
+ * tef_profile_enable(1) resets the accumulators; tef_profile_collect() synchronises the recorded events and
+ * accumulates per-slot totals; slots are named (tef_profile_name) after the kernels in DESIGN.md. */
+int tef_profile_enable(int on);
+int tef_profile_collect(void);
+int tef_profile_slots(void);
+const char *tef_profile_name(int slot);
+double tef_profile_ms(int slot);
+long tef_profile_calls(int slot);
 
 /* Event list of one loss window in structure-of-arrays form, [B][cap] per array.
  * Slots of pass t occupy [off[t], off[t+1]) of every sample's row (see tef_loss_cfg).

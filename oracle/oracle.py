@@ -33,7 +33,7 @@ def build(force=False):
     """Compile the C restatement (gcc only; building the checker is not using it)."""
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
         subprocess.check_call(
-            ["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC, "-lm"]
+            ["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC, "-lm"]
         )
     return _LIB
 
@@ -56,6 +56,11 @@ def lib():
             fn.argtypes = [ctypes.POINTER(_Window), ctypes.c_float, _f, ctypes.c_float]
         _lib.tef_oracle_focus_loss.restype = ctypes.c_float
     return _lib
+
+
+def threads(n=0):
+    """Set (n > 0) / query the number of OpenMP threads the oracle uses for the (head, sample) loop."""
+    return int(lib().tef_oracle_threads(int(n)))
 
 
 def _p(a):

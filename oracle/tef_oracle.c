@@ -19,6 +19,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define TEF_EPS 1e-9f
 
@@ -338,26 +341,20 @@ static int tef_bin_of(const int *off, int P, int sl)
  * loss/flow.py:415-746 (Iterative.__init__/update/event_warping/forward).
  * dflows may be NULL (forward only).  Returns the loss (without smoothing terms).
  * ---------------------------------------------------------------------------------------- */
-float tef_oracle_iterative(const tef_window *wd, float *dflows, float grad_out)
+static double tef_iterative_pair(const tef_window *wd, const int *bin, int i, int b, float *dflows, float grad_out)
 {
-    const int B = wd->B, H = wd->H, W = wd->W, P = wd->P, F = wd->F, S = wd->S;
+    const int H = wd->H, W = wd->W, P = wd->P, F = wd->F, S = wd->S;
     const int HW = H * W, M = wd->M, Md = wd->Md, Mt = M + Md;
-    if (dflows) memset(dflows, 0, sizeof(float) * (size_t)P * F * B * 2 * HW);
-
-    float *ty = (float *)malloc(sizeof(float) * (size_t)(P + 1) * Mt);   /* trajectory, plane k = tref */
-    float *tx = (float *)malloc(sizeof(float) * (size_t)(P + 1) * Mt);
-    int *kb = (int *)malloc(sizeof(int) * Mt), *kf = (int *)malloc(sizeof(int) * Mt), *bin = (int *)malloc(sizeof(int) * Mt);
+    float *ty = (float *)malloc(sizeof(float) * (size_t)(P + 1) * (Mt + 1));   /* trajectory, plane k = tref */
+    float *tx = (float *)malloc(sizeof(float) * (size_t)(P + 1) * (Mt + 1));
+    int *kb = (int *)malloc(sizeof(int) * (Mt + 1)), *kf = (int *)malloc(sizeof(int) * (Mt + 1));
     float *gy = (float *)malloc(sizeof(float) * (size_t)(P + 1) * (M + 1));
     float *gx = (float *)malloc(sizeof(float) * (size_t)(P + 1) * (M + 1));
     unsigned char *valid = (unsigned char *)malloc(Mt + 1);
     tef_imgbuf ib = tef_imgbuf_new(HW);
-    for (int sl = 0; sl < M; ++sl) bin[sl] = tef_bin_of(wd->off, P, sl);
-    for (int sl = 0; sl < Md; ++sl) bin[M + sl] = tef_bin_of(wd->doff, P, sl);
-
-    double loss = 0.0;
-    for (int i = 0; i < F; ++i) {
-        double loss_i = 0.0;
-        for (int b = 0; b < B; ++b) {
+    double loss_i = 0.0;
+    {
+        {
             /* (A) iterative warping of every event to every tref (loss/flow.py:599-654, :521-586) */
             for (int sl = 0; sl < Mt; ++sl) {
                 size_t o = (size_t)b * Mt + sl;
@@ -425,7 +422,7 @@ float tef_oracle_iterative(const tef_window *wd, float *dflows, float grad_out)
                     }
                 }
             }
-            if (!dflows) continue;
+            if (!dflows) goto done;
             /* (C) reverse sweep along each grad event's trajectory */
             for (int sl = 0; sl < M; ++sl) {
                 size_t o = (size_t)b * Mt + sl;
@@ -480,10 +477,26 @@ float tef_oracle_iterative(const tef_window *wd, float *dflows, float grad_out)
                 tef_tap_scatter(tef_dmap(wd, dflows, t, i, b, 0), &tp, c0x);
             }
         }
-        loss += loss_i;
     }
-    free(ty); free(tx); free(kb); free(kf); free(bin); free(gy); free(gx); free(valid);
+done:
+    free(ty); free(tx); free(kb); free(kf); free(gy); free(gx); free(valid);
     tef_imgbuf_free(&ib);
+    return loss_i;
+}
+
+float tef_oracle_iterative(const tef_window *wd, float *dflows, float grad_out)
+{
+    const int B = wd->B, P = wd->P, F = wd->F, M = wd->M, Md = wd->Md, Mt = M + Md;
+    if (dflows) memset(dflows, 0, sizeof(float) * (size_t)P * F * B * 2 * wd->H * wd->W);
+    int *bin = (int *)malloc(sizeof(int) * (Mt + 1));
+    for (int sl = 0; sl < M; ++sl) bin[sl] = tef_bin_of(wd->off, P, sl);
+    for (int sl = 0; sl < Md; ++sl) bin[M + sl] = tef_bin_of(wd->doff, P, sl);
+    double loss = 0.0;
+    /* (head, sample) pairs are independent until the final sum (loss/flow.py:129, :735-736) */
+#pragma omp parallel for schedule(dynamic) reduction(+ : loss)
+    for (int q = 0; q < F * B; ++q)
+        loss += tef_iterative_pair(wd, bin, q / B, q % B, dflows, grad_out);
+    free(bin);
     return (float)loss;
 }
 
@@ -703,3 +716,15 @@ void tef_oracle_events_to_image(const float *xs, const float *ys, const float *p
 }
 
 int tef_oracle_version(void) { return 1; }
+
+/* number of threads the OpenMP build uses (1 when built without OpenMP); n > 0 sets it first */
+int tef_oracle_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}

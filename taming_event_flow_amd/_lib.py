@@ -39,6 +39,12 @@ class LossCfg(ctypes.Structure):
 SIGNATURES = {
     "tef_version": (ctypes.c_int, []),
     "tef_last_error": (ctypes.c_char_p, []),
+    "tef_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "tef_profile_collect": (ctypes.c_int, []),
+    "tef_profile_slots": (ctypes.c_int, []),
+    "tef_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "tef_profile_ms": (ctypes.c_double, [ctypes.c_int]),
+    "tef_profile_calls": (ctypes.c_long, [ctypes.c_int]),
     "tef_pack_events": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),

@@ -14,6 +14,21 @@ bool fail_hip(const char *what, hipError_t e);
 // hipGetLastError() after a launch: 0 or TEF_ERR_LAUNCH (message recorded).
 int check_launch(const char *kernel);
 
+// Opt-in per-kernel timing (tef_profile_* in include/tef.h): HIP events recorded on the launch stream
+// around each kernel while enabled; zero cost when disabled.
+enum ProfSlot {
+    PROF_PACK = 0, PROF_WARP, PROF_SPLAT, PROF_STATS, PROF_REDUCE, PROF_CHAIN_BWD, PROF_DFLOW,
+    PROF_SMOOTH_FWD, PROF_SMOOTH_BWD, PROF_ENCODE, PROF_NSLOTS
+};
+void prof_begin(int slot, hipStream_t st);
+void prof_end(int slot, hipStream_t st);
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(int s, hipStream_t stream) : slot(s), st(stream) { prof_begin(slot, st); }
+    ~ProfScope() { prof_end(slot, st); }
+};
+
 }  // namespace tef
 
 #endif

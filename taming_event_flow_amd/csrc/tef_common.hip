@@ -4,8 +4,34 @@
 
 #include "tef_common.h"
 
+#include <vector>
+
 namespace {
 thread_local char g_err[512] = "";
+
+const char *kSlotNames[tef::PROF_NSLOTS] = {
+    "pack_events", "warp", "iwe_splat", "image_stats", "loss_reduce", "chain_bwd", "dflow_splat",
+    "smoothing_fwd", "smoothing_bwd", "encode",
+};
+struct Pending { int slot; hipEvent_t a, b; };
+bool g_prof_on = false;
+double g_ms[tef::PROF_NSLOTS];
+long g_calls[tef::PROF_NSLOTS];
+std::vector<Pending> g_pending;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t g_open[tef::PROF_NSLOTS];
+
+hipEvent_t get_event()
+{
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
 }
 
 namespace tef {
@@ -30,9 +56,52 @@ int check_launch(const char *kernel)
     return TEF_ERR_LAUNCH;
 }
 
+void prof_begin(int slot, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEvent_t e = get_event();
+    (void)hipEventRecord(e, st);
+    g_open[slot] = e;
+}
+
+void prof_end(int slot, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEvent_t e = get_event();
+    (void)hipEventRecord(e, st);
+    g_pending.push_back(Pending{slot, g_open[slot], e});
+}
+
 }  // namespace tef
 
 extern "C" {
+
+int tef_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    for (int i = 0; i < tef::PROF_NSLOTS; ++i) { g_ms[i] = 0.0; g_calls[i] = 0; }
+    for (auto &p : g_pending) { g_pool.push_back(p.a); g_pool.push_back(p.b); }
+    g_pending.clear();
+    return 0;
+}
+
+int tef_profile_collect(void)
+{
+    for (auto &p : g_pending) {
+        if (hipEventSynchronize(p.b) != hipSuccess) return tef::fail("tef_profile_collect: event sync failed"), TEF_ERR_LAUNCH;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { g_ms[p.slot] += ms; g_calls[p.slot] += 1; }
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
+    }
+    g_pending.clear();
+    return 0;
+}
+
+int tef_profile_slots(void) { return tef::PROF_NSLOTS; }
+const char *tef_profile_name(int slot) { return (slot >= 0 && slot < tef::PROF_NSLOTS) ? kSlotNames[slot] : ""; }
+double tef_profile_ms(int slot) { return (slot >= 0 && slot < tef::PROF_NSLOTS) ? g_ms[slot] : 0.0; }
+long tef_profile_calls(int slot) { return (slot >= 0 && slot < tef::PROF_NSLOTS) ? g_calls[slot] : 0; }
 
 int tef_version(void) { return TEF_VERSION; }
 

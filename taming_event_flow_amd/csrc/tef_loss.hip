@@ -829,8 +829,8 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, fl
         return tef::fail("tef_pack_events: bad sizes"), TEF_ERR_INVALID;
     if (N == 0) return 0;
     dim3 grid((N + 255) / 256, B);
-    hipLaunchKernelGGL(pack_events_kernel, grid, dim3(256), 0, (hipStream_t)stream, ev, pm, B, N, ts_shift, ts_override,
-                       pass_idx, slot0, cap, ts, y, x, mp, mn, bin);
+    { tef::ProfScope ps(tef::PROF_PACK, (hipStream_t)stream); hipLaunchKernelGGL(pack_events_kernel, grid, dim3(256), 0, (hipStream_t)stream, ev, pm, B, N, ts_shift, ts_override,
+                       pass_idx, slot0, cap, ts, y, x, mp, mn, bin); }
     return tef::check_launch("pack_events_kernel");
 }
 
@@ -857,20 +857,20 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows, const tef_even
     if (w.Mt > 0) {
         dim3 grid((w.Mt + 255) / 256, FB);
         if (w.kind == TEF_KIND_ITERATIVE)
-            hipLaunchKernelGGL(iter_warp_kernel, grid, dim3(256), 0, st, w, flows, g, d, traj, meta);
+            { tef::ProfScope ps(tef::PROF_WARP, st); hipLaunchKernelGGL(iter_warp_kernel, grid, dim3(256), 0, st, w, flows, g, d, traj, meta); }
         else
-            hipLaunchKernelGGL(linear_warp_kernel, grid, dim3(256), 0, st, w, flows, g, d, traj, meta);
+            { tef::ProfScope ps(tef::PROF_WARP, st); hipLaunchKernelGGL(linear_warp_kernel, grid, dim3(256), 0, st, w, flows, g, d, traj, meta); }
         if (int rc = tef::check_launch("warp_kernel")) return rc;
     }
     int rows, nbands;
     size_t lds;
     band_geometry(w, &rows, &nbands, &lds);
-    hipLaunchKernelGGL(splat_kernel, dim3((unsigned)(w.nimg * FB * 2 * nbands)), dim3(kSplatThreads), lds, st, w, g, d,
-                       traj, meta, iwe, rows, nbands);
+    { tef::ProfScope ps(tef::PROF_SPLAT, st); hipLaunchKernelGGL(splat_kernel, dim3((unsigned)(w.nimg * FB * 2 * nbands)), dim3(kSplatThreads), lds, st, w, g, d,
+                       traj, meta, iwe, rows, nbands); }
     if (int rc = tef::check_launch("splat_kernel")) return rc;
-    hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, w, iwe, stats);
+    { tef::ProfScope ps(tef::PROF_STATS, st); hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, w, iwe, stats); }
     if (int rc = tef::check_launch("image_stats_kernel")) return rc;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, stats, loss_out);
+    { tef::ProfScope ps(tef::PROF_REDUCE, st); hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, stats, loss_out); }
     return tef::check_launch("loss_reduce_kernel");
 }
 
@@ -896,18 +896,18 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows, const tef_eve
     if (w.M > 0) {
         dim3 grid((w.M + 255) / 256, FB);
         if (w.kind == TEF_KIND_ITERATIVE)
-            hipLaunchKernelGGL(iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, flows, g, traj, meta, iwe, stats,
-                               grad_out, contrib);
+            { tef::ProfScope ps(tef::PROF_CHAIN_BWD, st); hipLaunchKernelGGL(iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, flows, g, traj, meta, iwe, stats,
+                               grad_out, contrib); }
         else
-            hipLaunchKernelGGL(linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, iwe, stats, grad_out,
-                               contrib);
+            { tef::ProfScope ps(tef::PROF_CHAIN_BWD, st); hipLaunchKernelGGL(linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, iwe, stats, grad_out,
+                               contrib); }
         if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
     }
     int rows, nbands;
     size_t lds;
     band_geometry(w, &rows, &nbands, &lds);
-    hipLaunchKernelGGL(dflow_splat_kernel, dim3((unsigned)(w.P * FB * nbands)), dim3(kSplatThreads), lds, st, w, g, traj,
-                       contrib, dflows, rows, nbands);
+    { tef::ProfScope ps(tef::PROF_DFLOW, st); hipLaunchKernelGGL(dflow_splat_kernel, dim3((unsigned)(w.P * FB * nbands)), dim3(kSplatThreads), lds, st, w, g, traj,
+                       contrib, dflows, rows, nbands); }
     return tef::check_launch("dflow_splat_kernel");
 }
 

@@ -272,16 +272,16 @@ int tef_smoothing_forward(const tef_loss_cfg *cfg, const float *flows, float spa
     double *terms = (double *)((char *)scratch + pl.off_terms);
     bool do_s = spat_weight >= 0.0f, do_t = temp_weight >= 0.0f && pl.nt > 0;
     if (do_s) {
-        hipLaunchKernelGGL(spatial_fwd_kernel, dim3(pl.sblocks, pl.nmaps), dim3(256), 0, st, pl.d, flows, spart);
+        { tef::ProfScope ps(tef::PROF_SMOOTH_FWD, st); hipLaunchKernelGGL(spatial_fwd_kernel, dim3(pl.sblocks, pl.nmaps), dim3(256), 0, st, pl.d, flows, spart); }
         if (int rc = tef::check_launch("spatial_fwd_kernel")) return rc;
     }
     if (do_t) {
-        hipLaunchKernelGGL(temporal_fwd_kernel, dim3(pl.nt), dim3(256), 0, st, pl.d, flows, terms);
+        { tef::ProfScope ps(tef::PROF_SMOOTH_FWD, st); hipLaunchKernelGGL(temporal_fwd_kernel, dim3(pl.nt), dim3(256), 0, st, pl.d, flows, terms); }
         if (int rc = tef::check_launch("temporal_fwd_kernel")) return rc;
     }
     if (do_s || do_t) {
-        hipLaunchKernelGGL(smoothing_reduce_kernel, dim3(1), dim3(256), 0, st, pl.d, spart, do_s ? pl.ns : 0,
-                           spat_weight, terms, do_t ? pl.nt : 0, temp_weight, loss_out);
+        { tef::ProfScope ps(tef::PROF_SMOOTH_FWD, st); hipLaunchKernelGGL(smoothing_reduce_kernel, dim3(1), dim3(256), 0, st, pl.d, spart, do_s ? pl.ns : 0,
+                           spat_weight, terms, do_t ? pl.nt : 0, temp_weight, loss_out); }
         if (int rc = tef::check_launch("smoothing_reduce_kernel")) return rc;
     }
     return 0;
@@ -297,13 +297,13 @@ int tef_smoothing_backward(const tef_loss_cfg *cfg, const float *flows, float sp
     hipStream_t st = (hipStream_t)stream;
     double *terms = (double *)((char *)scratch + pl.off_terms);
     if (spat_weight >= 0.0f) {
-        hipLaunchKernelGGL(spatial_bwd_kernel, dim3(pl.sblocks, pl.nmaps), dim3(256), 0, st, pl.d, flows, spat_weight,
-                           grad_out, dflows);
+        { tef::ProfScope ps(tef::PROF_SMOOTH_BWD, st); hipLaunchKernelGGL(spatial_bwd_kernel, dim3(pl.sblocks, pl.nmaps), dim3(256), 0, st, pl.d, flows, spat_weight,
+                           grad_out, dflows); }
         if (int rc = tef::check_launch("spatial_bwd_kernel")) return rc;
     }
     if (temp_weight >= 0.0f && pl.nt > 0) {
-        hipLaunchKernelGGL(temporal_bwd_kernel, dim3(pl.sblocks, pl.nt), dim3(256), 0, st, pl.d, flows, temp_weight,
-                           terms, grad_out, dflows);
+        { tef::ProfScope ps(tef::PROF_SMOOTH_BWD, st); hipLaunchKernelGGL(temporal_bwd_kernel, dim3(pl.sblocks, pl.nt), dim3(256), 0, st, pl.d, flows, temp_weight,
+                           terms, grad_out, dflows); }
         if (int rc = tef::check_launch("temporal_bwd_kernel")) return rc;
     }
     return 0;

@@ -103,25 +103,25 @@ class _CMLossFn(torch.autograd.Function):
             rc = lib.tef_smoothing_forward(ctypes.byref(cfg), win.flows.data_ptr(), ws, wt, win.scratch.data_ptr(),
                                            loss.data_ptr(), _lib.stream_ptr())
             _lib.check(rc, "tef_smoothing_forward")
-        ctx.win = win
+        # the context owns everything backward reads, so a later forward on the same window cannot clobber it
+        ctx.win, ctx.cfg, ctx.workspace, ctx.scratch = win, cfg, win.workspace, win.scratch
         ctx.smooth = (ws, wt)
-        ctx.shape = tuple(flows[0].shape)
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.lib()
-        win, cfg = ctx.win, ctx.win.cfg
+        win, cfg, workspace, scratch = ctx.win, ctx.cfg, ctx.workspace, ctx.scratch
         go = grad_out.to(torch.float32).contiguous()
         dflows = torch.empty_like(win.flows)
         g, d = win.grad.struct(), win.det.struct()
         rc = lib.tef_loss_backward(ctypes.byref(cfg), win.flows.data_ptr(), ctypes.byref(g), ctypes.byref(d),
-                                   win.workspace.data_ptr(), win.workspace.numel(), go.data_ptr(), dflows.data_ptr(),
+                                   workspace.data_ptr(), workspace.numel(), go.data_ptr(), dflows.data_ptr(),
                                    _lib.stream_ptr())
         _lib.check(rc, "tef_loss_backward")
         ws, wt = ctx.smooth
         if ws >= 0 or wt >= 0:
-            rc = lib.tef_smoothing_backward(ctypes.byref(cfg), win.flows.data_ptr(), ws, wt, win.scratch.data_ptr(),
+            rc = lib.tef_smoothing_backward(ctypes.byref(cfg), win.flows.data_ptr(), ws, wt, scratch.data_ptr(),
                                             go.data_ptr(), dflows.data_ptr(), _lib.stream_ptr())
             _lib.check(rc, "tef_smoothing_backward")
         P, F = cfg.P, cfg.F
