@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
     ap.add_argument("--warping", default="Iterative", choices=["Iterative", "Linear"])
     ap.add_argument("--windows", type=int, default=2, help="distinct pre-staged windows cycled through")
+    ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
+                    help="experiment: pre-sort the synthetic events of each pass on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -119,6 +121,17 @@ def main():
     for wi in range(a.windows):
         rng = np.random.default_rng(1000 * rank + wi)
         win = synth.make_window(rng, B, H, W, P, F, a.events, a.detached, sigma=2.0, kind=a.flow)
+        if a.presort != "none":
+            for t in range(P):
+                for key_e, key_m in (("ev", "pm"), ("dev", "dpm")):
+                    ev_, pm_ = win[key_e][t], win[key_m][t]
+                    for b in range(B):
+                        yy, xx, pol = ev_[b, :, 1], ev_[b, :, 2], 1e6 * (ev_[b, :, 3] < 0)
+                        k = {"y": yy, "pol_y": yy + pol, "pol_tile8": (yy // 8) * 64 + xx // 8 + pol,
+                             "pol_tile16": (yy // 16) * 64 + xx // 16 + pol, "pol_yx": yy * 1024 + xx + pol,
+                             "pol_y4": yy // 4 + pol}[a.presort]
+                        o = np.argsort(k, kind="stable")
+                        ev_[b], pm_[b] = ev_[b][o], pm_[b][o]
         host_windows.append(win)
         flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
         evs = [(torch.tensor(win["ev"][t], device=dev), torch.tensor(win["pm"][t], device=dev),
@@ -134,6 +147,9 @@ def main():
 
     def step(k):
         L, flows = staged[k % len(staged)]
+        for row in flows:           # like optimizer.zero_grad(set_to_none=True): no gradient-accumulate kernels
+            for f in row:
+                f.grad = None
         loss = L()
         loss.backward()
         return loss

@@ -79,29 +79,40 @@ typedef struct tef_loss_cfg {
 /* AoS -> SoA packing of one pass, replaces the bookkeeping of Iterative.update / Linear.update
  * (loss/flow.py:443-476, 233-288): adds `ts_shift` to ev[:, :, 0] IN PLACE (reference side effect,
  * :457-458) and appends the pass at slot `slot0` of the SoA arrays.  If ts_override >= 0 the stored
- * timestamp is that constant instead (round_ts, :461-463).  ev [B,N,4] (ts,y,x,p), pm [B,N,2]. */
+ * timestamp is that constant instead (round_ts, :461-463).  ev [B,N,4] (ts,y,x,p), pm [B,N,2].
+ * The events of the pass are stored sorted by (polarity, 8x8 pixel tile of the H x W frame): the loss is a sum over
+ * events, so the order inside a pass is free, and coherent wavefronts halve the cost of the lookups. */
 int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
-                    int slot0, int cap, float *ts, float *y, float *x, float *mp, float *mn, uint8_t *bin,
-                    void *stream);
+                    int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
+                    uint8_t *bin, void *stream);
+
+/* Flow map of one head of one pass, replaces BaseEventWarping.update_base (loss/flow.py:46-66): copies the
+ * model's [B,2,H,W] tensor (channel 0 = x, 1 = y; element strides stride_b / stride_c, rows dense) into
+ *   planar [B][2][H*W]            -> slot [t][i] of the planar window buffer  [P][F][B][2][H][W]  (smoothing terms)
+ *   yx     [B][H*W] (flow_y, flow_x) pairs -> slot [t][i] of the interleaved buffer [P][F][B][H][W][2]  (lookups) */
+int tef_pack_flow(const float *flow, long stride_b, long stride_c, int B, int H, int W, float *planar, float *yx,
+                  void *stream);
 
 /* Workspace (bytes) needed by tef_loss_forward + tef_loss_backward for this window. */
 size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg);
 
 /* Contrast-maximisation loss forward: Iterative.forward (loss/flow.py:588-736) or Linear.forward (:306-402),
  * without the optional smoothing terms (see tef_smoothing_*).
- *   flows  [P][F][B][2][H][W]  (channel 0 = x, 1 = y; already multiplied by flow_scaling by the caller)
+ *   flows_yx  [P][F][B][H][W][2]  interleaved (flow_y, flow_x), see tef_pack_flow (already multiplied by
+ *             flow_scaling by the caller, train_flow.py:107-108)
  *   grad / det: event lists with / without gradient (det may have Md = 0)
  *   loss_out: one float.  The workspace keeps what tef_loss_backward needs. */
-int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows, const tef_events *grad, const tef_events *det,
+int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,
                      void *workspace, size_t workspace_bytes, float *loss_out, void *stream);
 
-/* d loss / d flows, same layout as flows; grad_out = upstream scalar gradient (device pointer).
+/* d loss / d flows as PLANAR [P][F][B][2][H][W] (channel 0 = x, 1 = y: the layout of the model's tensors);
+ * grad_out = upstream scalar gradient (device pointer).
  * Must follow tef_loss_forward on the same workspace.  dflows is fully overwritten. */
-int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows, const tef_events *grad, const tef_events *det,
+int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,
                       void *workspace, size_t workspace_bytes, const float *grad_out, float *dflows, void *stream);
 
 /* Optional Charbonnier priors of loss/flow.py:170-209 (spatial) and :131-168 (temporal) on the flow maps of
- * the window.  weight < 0 disables a term.  loss_out += term (accumulates onto the CM loss);
+ * the window (flows = the PLANAR buffer [P][F][B][2][H][W]).  weight < 0 disables a term.  loss_out += term (accumulates onto the CM loss);
  * backward ADDS into dflows.  scratch: tef_smoothing_scratch_bytes(). */
 size_t tef_smoothing_scratch_bytes(const tef_loss_cfg *cfg);
 int tef_smoothing_forward(const tef_loss_cfg *cfg, const float *flows, float spat_weight, float temp_weight,

@@ -46,7 +46,10 @@ SIGNATURES = {
     "tef_profile_ms": (ctypes.c_double, [ctypes.c_int]),
     "tef_profile_calls": (ctypes.c_long, [ctypes.c_int]),
     "tef_pack_events": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
-                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
+                                       _fp, _fp, _fp, _fp]),
+    "tef_pack_flow": (ctypes.c_int, [_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                     _fp, _fp]),
     "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),
     "tef_loss_forward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.POINTER(Events), ctypes.POINTER(Events),
                                         _fp, ctypes.c_size_t, _fp, _fp]),

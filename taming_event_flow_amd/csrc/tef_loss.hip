@@ -6,18 +6,24 @@
 //   forward   K1 warp      one thread per (head, sample, event): walks the event through the flow maps,
 //                          stores its position at every reference time (trajectory planes) and the
 //                          border-compensation flags (loss/flow.py:671-681)
-//             K2 splat     one workgroup per (image, head, sample, polarity[, row band]): the IWE pair
-//                          (count, sum of weighted timestamps) lives in LDS (128 KiB for 128x128),
-//                          events stream in coalesced, bilinear corners go in with LDS float atomics
-//             K3 stats     per image: sum of squared mean timestamps, number of active pixels
+//             K2 splat     one workgroup per (image, head, sample, polarity, quantity[, row band]): one
+//                          quantity (event count C or weighted timestamp sum T) of one polarity of one
+//                          image lives in LDS as fp64 (128 KiB for 128x128); events stream in coalesced,
+//                          bilinear corners go in with ds_add_f64
+//             K3 stats     per image: A = T/(C+eps), R = 1/(C+eps) for the backward, sum of squared mean
+//                          timestamps, number of active pixels
 //             K4 reduce    deterministic sum of the per-image terms -> scalar loss
 //   backward  K6 chain     one thread per (head, sample, grad event): gathers d loss / d position at
-//                          every reference time from the stored IWEs, reverse sweep along the
+//                          every reference time from the (A, R) images, reverse sweep along the
 //                          trajectory (grid_sample backward w.r.t. grid), emits one flow-gradient
 //                          vector per (event, flow map)
-//             K7 dflow     one workgroup per (flow map, head, sample[, row band]): bilinear splat of
-//                          those vectors into an LDS-resident gradient map, plain coalesced write-out
-//                          (no global atomics, no zero-fill pass)
+//             K7 dflow     one workgroup per (flow map, head, sample, component[, row band]): bilinear
+//                          splat of those vectors into an LDS-resident fp64 gradient map, plain coalesced
+//                          write-out (no global atomics, no zero-fill pass)
+//
+// Why fp64 in LDS: on gfx950 ds_add_f32 sustains only ~0.2 T atomics/s chip-wide, ds_add_f64 ~1.3 T/s
+// (tools/lds_atomic_bench.hip); fp64 sums also make the result independent of the arrival order to
+// far below fp32 resolution.
 //
 // Arithmetic is fp32 and follows the reference / ATen op order where it matters for parity
 // (coordinate normalisation + un-normalisation of grid_sample, floor(y + 1) corners, true division
@@ -27,6 +33,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "tef.h"
 #include "tef_common.h"
 
@@ -34,7 +42,14 @@ namespace {
 
 constexpr float kEps = 1e-9f;
 constexpr int kSplatThreads = 1024;
-constexpr size_t kLdsBudget = 128 * 1024;   // per-workgroup image budget (160 KiB LDS per CU on gfx950)
+constexpr size_t kLdsBudget = 128 * 1024;   // per-workgroup accumulator budget (160 KiB LDS per CU on gfx950)
+constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
+constexpr int kUnroll = 4;
+
+// meta word written by K1 per (head, sample, slot)
+constexpr uint32_t kMetaPos = 1u << 24;      // mask_pos != 0
+constexpr uint32_t kMetaNeg = 1u << 25;      // mask_neg != 0
+constexpr uint32_t kMetaNonUnit = 1u << 26;  // a mask value is neither 0 nor 1: fetch the float
 
 // ---------------------------------------------------------------------------------------------
 // Window descriptor handed to kernels by value (kernarg segment).
@@ -44,6 +59,7 @@ struct Win {
     int img_base[TEF_MAX_SCALES + 1];
     int off[TEF_MAX_PASSES + 1];
     int doff[TEF_MAX_PASSES + 1];
+    uint16_t order[kMaxImages];      // images sorted by decreasing number of bins (longest workgroups first)
 };
 
 struct Events {
@@ -57,14 +73,14 @@ struct Img {
     float tref, delta, coef;
 };
 
-__host__ __device__ inline int images_of_scale(const Win &w, int s)
+__host__ __device__ inline int images_of_scale(int kind, int P, int s)
 {
-    int scale = w.P >> s;
-    return (w.kind == TEF_KIND_ITERATIVE) ? (1 << s) * (scale + 1) : (1 << s) * 2;
+    int scale = P >> s;
+    return (kind == TEF_KIND_ITERATIVE) ? (1 << s) * (scale + 1) : (1 << s) * 2;
 }
 
 // image index -> (scale, window, reference time, bin range, normalisation)   loss/flow.py:657-731 / :309-397
-__device__ inline Img decode_image(const Win &w, int j)
+__host__ __device__ inline Img decode_image(const Win &w, int j)
 {
     Img im;
     int s = 0;
@@ -78,8 +94,8 @@ __device__ inline Img decode_image(const Win &w, int j)
         im.lo = wi * scale;
         im.hi = im.lo + scale;
         int tref = im.lo + q;
-        im.le = max(im.lo, tref - delta);
-        im.he = min(im.hi, tref + delta);
+        im.le = (im.lo > tref - delta) ? im.lo : tref - delta;
+        im.he = (im.hi < tref + delta) ? im.hi : tref + delta;
         im.plane = tref;
         im.tref = (float)tref;
         im.delta = (float)delta;
@@ -98,8 +114,21 @@ __device__ inline Img decode_image(const Win &w, int j)
     return im;
 }
 
+// XCD-aware work distribution: workgroups are dealt round-robin over the 8 XCDs (bid % 8), each with a
+// private 4 MiB L2.  `item` indexes things that should share an L2 (all chunks of one (head, sample) pair,
+// all variants of one image) so that their common inputs are fetched from HBM once per XCD.
+// bid -> (item, sub) with item % 8 == XCD; grid = 8 * ceil(nitems / 8) * nsub, guard item < nitems.  [speed only]
+__device__ __forceinline__ void xcd_split(int bid, int nsub, int &item, int &sub)
+{
+    int g = bid & 7, r = bid >> 3;
+    item = g + 8 * (r / nsub);
+    sub = r % nsub;
+}
+inline unsigned xcd_grid(int nitems, int nsub) { return 8u * (unsigned)((nitems + 7) / 8) * (unsigned)nsub; }
+
 // ---------------------------------------------------------------------------------------------
 // Bilinear flow lookup: utils/iwe.py:17-40 + ATen grid_sampler_2d (bilinear, align_corners=True, zeros).
+// Flow maps are interleaved float2 (.x = flow_y, .y = flow_x) per pixel: one 8-byte tap per corner.
 // ---------------------------------------------------------------------------------------------
 struct Taps {
     int i00, i01, i10, i11;   // -1 when outside
@@ -131,28 +160,35 @@ __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
     return t;
 }
 
-struct Quad { float v00, v01, v10, v11; };
+struct Quad2 { float2 v00, v01, v10, v11; };
 
-__device__ __forceinline__ Quad load_quad(const float *map, const Taps &t)
+__device__ __forceinline__ Quad2 load_quad(const float2 *__restrict__ map, const Taps &t)
 {
-    Quad q;
-    q.v00 = t.i00 >= 0 ? map[t.i00] : 0.0f;
-    q.v01 = t.i01 >= 0 ? map[t.i01] : 0.0f;
-    q.v10 = t.i10 >= 0 ? map[t.i10] : 0.0f;
-    q.v11 = t.i11 >= 0 ? map[t.i11] : 0.0f;
+    const float2 z = make_float2(0.0f, 0.0f);
+    Quad2 q;
+    q.v00 = t.i00 >= 0 ? map[t.i00] : z;
+    q.v01 = t.i01 >= 0 ? map[t.i01] : z;
+    q.v10 = t.i10 >= 0 ? map[t.i10] : z;
+    q.v11 = t.i11 >= 0 ? map[t.i11] : z;
     return q;
 }
 
-__device__ __forceinline__ float quad_value(const Quad &q, const Taps &t)
+// (flow_y, flow_x) at the tap position
+__device__ __forceinline__ float2 quad_value(const Quad2 &q, const Taps &t)
 {
-    return q.v00 * (t.s * t.e) + q.v01 * (t.s * t.w) + q.v10 * (t.n * t.e) + q.v11 * (t.n * t.w);
+    float w00 = t.s * t.e, w01 = t.s * t.w, w10 = t.n * t.e, w11 = t.n * t.w;
+    return make_float2(q.v00.x * w00 + q.v01.x * w01 + q.v10.x * w10 + q.v11.x * w11,
+                       q.v00.y * w00 + q.v01.y * w01 + q.v10.y * w10 + q.v11.y * w11);
 }
 
-// d value / d(y, x)
-__device__ __forceinline__ void quad_jacobian(const Quad &q, const Taps &t, float &dy, float &dx)
+// Jacobian of the lookup: jyy = d f_y/d y, jyx = d f_y/d x, jxy = d f_x/d y, jxx = d f_x/d x
+__device__ __forceinline__ void quad_jacobian(const Quad2 &q, const Taps &t, float &jyy, float &jyx, float &jxy,
+                                              float &jxx)
 {
-    dx = (q.v01 - q.v00) * t.s + (q.v11 - q.v10) * t.n;
-    dy = (q.v10 - q.v00) * t.e + (q.v11 - q.v01) * t.w;
+    jyx = (q.v01.x - q.v00.x) * t.s + (q.v11.x - q.v10.x) * t.n;
+    jyy = (q.v10.x - q.v00.x) * t.e + (q.v11.x - q.v01.x) * t.w;
+    jxx = (q.v01.y - q.v00.y) * t.s + (q.v11.y - q.v10.y) * t.n;
+    jxy = (q.v10.y - q.v00.y) * t.e + (q.v11.y - q.v01.y) * t.w;
 }
 
 __device__ __forceinline__ bool inbounds(float y, float x, int H, int W)   // utils/iwe.py:52-57 (closed interval)
@@ -160,9 +196,10 @@ __device__ __forceinline__ bool inbounds(float y, float x, int H, int W)   // ut
     return (y >= 0.0f) & (y <= (float)H - 1.0f) & (x >= 0.0f) & (x <= (float)W - 1.0f);
 }
 
-__device__ __forceinline__ const float *flow_map(const Win &w, const float *flows, int t, int i, int b, int c)
+// flows_yx [P][F][B][H*W] float2
+__device__ __forceinline__ const float2 *flow_map(const Win &w, const float2 *flows, int t, int i, int b)
 {
-    return flows + ((((size_t)t * w.F + i) * w.B + b) * 2 + c) * (size_t)(w.H * w.W);
+    return flows + (((size_t)t * w.F + i) * w.B + b) * (size_t)(w.H * w.W);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -197,30 +234,39 @@ __device__ __forceinline__ Splat make_splat(float y, float x)
     return s;
 }
 
-__device__ __forceinline__ uint32_t pack_meta(uint32_t bits, int kb, int kf)
+__device__ __forceinline__ uint32_t pack_meta(uint32_t bits, int kb, int kf, float mp, float mn)
 {
-    return bits | ((uint32_t)(kb + 1) << 8) | ((uint32_t)kf << 16);
+    uint32_t m = bits | ((uint32_t)(kb + 1) << 8) | ((uint32_t)kf << 16);
+    if (mp != 0.0f) m |= kMetaPos;
+    if (mn != 0.0f) m |= kMetaNeg;
+    if ((mp != 0.0f && mp != 1.0f) || (mn != 0.0f && mn != 1.0f)) m |= kMetaNonUnit;
+    return m;
 }
 
 // =============================================================================================
 // K1 (Iterative): iterative warping of every event to every reference time.
 // loss/flow.py:521-586 event_warping, :492-519 update_warping_indices, :599-654.
 // traj plane k (k = 0..P) holds the event position at tref = k; meta packs the per-scale
-// border-compensation bits (:671-681), kb (last out-of-bounds tref going backward, -1 if none)
-// and kf (first out-of-bounds tref going forward, P+1 if none).
+// border-compensation bits (:671-681), kb (last out-of-bounds tref going backward, -1 if none),
+// kf (first out-of-bounds tref going forward, P+1 if none) and the polarity flags.
 // =============================================================================================
-__global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float *__restrict__ flows, Events g, Events d,
-                                                        float2 *__restrict__ traj, uint32_t *__restrict__ meta)
+__global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
+                                                        float2 *__restrict__ traj, uint32_t *__restrict__ meta,
+                                                        int chunks)
 {
-    int u = blockIdx.x * blockDim.x + threadIdx.x;
+    int ib, chunk;
+    xcd_split(blockIdx.x, chunks, ib, chunk);
+    if (ib >= w.F * w.B) return;
+    int u = chunk * blockDim.x + threadIdx.x;
     if (u >= w.Mt) return;
-    int ib = blockIdx.y, i = ib / w.B, b = ib - i * w.B;
+    int i = ib / w.B, b = ib - i * w.B;
     bool isd = u >= w.M;
     int sl = isd ? u - w.M : u;
     const Events &E = isd ? d : g;
     size_t o = (size_t)b * E.cap + sl;
     uint32_t *mo = meta + (size_t)ib * w.Mt + u;
-    if (E.mp[o] == 0.0f && E.mn[o] == 0.0f) {   // collate padding (dataloader/base.py:414-421): contributes nothing
+    float mp = E.mp[o], mn = E.mn[o];
+    if (mp == 0.0f && mn == 0.0f) {   // collate padding (dataloader/base.py:414-421): contributes nothing
         *mo = 0u;
         return;
     }
@@ -231,38 +277,37 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float *__re
 
     // flow at the original location, shared by the first forward and the first backward step
     Taps tp = make_taps(y0, x0, H, W);
-    float fy0 = quad_value(load_quad(flow_map(w, flows, t, i, b, 1), tp), tp);
-    float fx0 = quad_value(load_quad(flow_map(w, flows, t, i, b, 0), tp), tp);
+    float2 f0 = quad_value(load_quad(flow_map(w, flows, t, i, b), tp), tp);
 
     int kf = P + 1, kb = -1;
     {   // forward: maps t .. P-1, positions at tref = t+1 .. P
-        float y = y0, x = x0, fy = fy0, fx = fx0;
+        float y = y0, x = x0;
+        float2 f = f0;
         float dt = (float)(t + 1) - ts;             // utils/iwe.py:14 (tref - ts)
         for (int k = t; k < P; ++k) {
             if (k > t) {
                 Taps q = make_taps(y, x, H, W);
-                fy = quad_value(load_quad(flow_map(w, flows, k, i, b, 1), q), q);
-                fx = quad_value(load_quad(flow_map(w, flows, k, i, b, 0), q), q);
+                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q), q);
                 dt = 1.0f;
             }
-            y = y + dt * fy;
-            x = x + dt * fx;
+            y = y + dt * f.x;
+            x = x + dt * f.y;
             tr[(size_t)(k + 1) * w.Mt] = make_float2(y, x);
             if (!inbounds(y, x, H, W)) { kf = k + 1; break; }       // cumulative purge, loss/flow.py:575
         }
     }
     {   // backward: maps t .. 0, positions at tref = t .. 0
-        float y = y0, x = x0, fy = fy0, fx = fx0;
+        float y = y0, x = x0;
+        float2 f = f0;
         float dt = (float)t - ts;
         for (int k = t; k >= 0; --k) {
             if (k < t) {
                 Taps q = make_taps(y, x, H, W);
-                fy = quad_value(load_quad(flow_map(w, flows, k, i, b, 1), q), q);
-                fx = quad_value(load_quad(flow_map(w, flows, k, i, b, 0), q), q);
+                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q), q);
                 dt = -1.0f;
             }
-            y = y + dt * fy;
-            x = x + dt * fx;
+            y = y + dt * f.x;
+            x = x + dt * f.y;
             tr[(size_t)k * w.Mt] = make_float2(y, x);
             if (!inbounds(y, x, H, W)) { kb = k; break; }
         }
@@ -274,7 +319,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float *__re
         int lo = wi * scale, hi = lo + scale;
         if (kb < lo && kf > hi) bits |= 1u << s;
     }
-    *mo = pack_meta(bits, kb, kf);
+    *mo = pack_meta(bits, kb, kf, mp, mn);
 }
 
 // =============================================================================================
@@ -282,18 +327,23 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float *__re
 // loss/flow.py:268-283 (sample), :337-343 (warp + shared purge).  Plane 2s = forward (tref = hi),
 // plane 2s+1 = backward (tref = lo).
 // =============================================================================================
-__global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float *__restrict__ flows, Events g, Events d,
-                                                          float2 *__restrict__ traj, uint32_t *__restrict__ meta)
+__global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
+                                                          float2 *__restrict__ traj, uint32_t *__restrict__ meta,
+                                                          int chunks)
 {
-    int u = blockIdx.x * blockDim.x + threadIdx.x;
+    int ib, chunk;
+    xcd_split(blockIdx.x, chunks, ib, chunk);
+    if (ib >= w.F * w.B) return;
+    int u = chunk * blockDim.x + threadIdx.x;
     if (u >= w.Mt) return;
-    int ib = blockIdx.y, i = ib / w.B, b = ib - i * w.B;
+    int i = ib / w.B, b = ib - i * w.B;
     bool isd = u >= w.M;
     int sl = isd ? u - w.M : u;
     const Events &E = isd ? d : g;
     size_t o = (size_t)b * E.cap + sl;
     uint32_t *mo = meta + (size_t)ib * w.Mt + u;
-    if (E.mp[o] == 0.0f && E.mn[o] == 0.0f) {
+    float mp = E.mp[o], mn = E.mn[o];
+    if (mp == 0.0f && mn == 0.0f) {
         *mo = 0u;
         return;
     }
@@ -301,8 +351,7 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float *__
     float ts = E.ts[o], y0 = E.y[o], x0 = E.x[o];
     int t = E.bin[sl];
     Taps tp = make_taps(y0, x0, H, W);
-    float fy = quad_value(load_quad(flow_map(w, flows, t, i, b, 1), tp), tp);
-    float fx = quad_value(load_quad(flow_map(w, flows, t, i, b, 0), tp), tp);
+    float2 f = quad_value(load_quad(flow_map(w, flows, t, i, b), tp), tp);
     float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
     uint32_t bits = 0;
     for (int s = 0; s < w.S; ++s) {
@@ -310,95 +359,138 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float *__
         if (wi >= (1 << s)) continue;
         int lo = wi * scale, hi = lo + scale;
         float dtf = (float)hi - ts, dtb = (float)lo - ts;
-        float yf = y0 + dtf * fy, xf = x0 + dtf * fx;
-        float yb = y0 + dtb * fy, xb = x0 + dtb * fx;
+        float yf = y0 + dtf * f.x, xf = x0 + dtf * f.y;
+        float yb = y0 + dtb * f.x, xb = x0 + dtb * f.y;
         tr[(size_t)(2 * s) * w.Mt] = make_float2(yf, xf);
         tr[(size_t)(2 * s + 1) * w.Mt] = make_float2(yb, xb);
         if (inbounds(yf, xf, H, W) && inbounds(yb, xb, H, W)) bits |= 1u << s;
     }
-    *mo = pack_meta(bits, -1, 0);
+    *mo = pack_meta(bits, -1, 0, mp, mn);
 }
 
 // =============================================================================================
 // K2: image of warped events.  loss/flow.py:81-110 iwe_formatting = utils/iwe.py:63-136
-// get_interpolation + 4x interpolate (scatter_add_).  One workgroup owns the (count, timestamp)
-// pair of ONE polarity of one image (or a row band of it) in LDS.
-//   iwe [(j * F*B + ib) * 2 + c][H*W] float2 = (C, T) summed over grad AND detached events (:725-726).
+// get_interpolation + 4x interpolate (scatter_add_).  One workgroup owns ONE quantity
+// (QT = false: event count C, QT = true: weighted timestamp sum T) of ONE polarity of one image
+// (or a row band of it) in LDS, accumulated in fp64 with ds_add_f64.
+//   out [(j * F*B + ib) * 2 + c][H*W] float, summed over grad AND detached events (:725-726).
+// The four (polarity, quantity) variants of an image read the same trajectory plane; xcd_split keeps
+// them on one XCD so the plane is fetched from HBM once.
 // =============================================================================================
-__global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, Events d,
-                                                              const float2 *__restrict__ traj,
-                                                              const uint32_t *__restrict__ meta,
-                                                              float2 *__restrict__ iwe, int rows_per_band, int nbands)
+template <bool QT>
+__device__ __forceinline__ void splat_one(const Win &w, const Img &im, uint32_t mv, float2 p, float ts, float m,
+                                          double *img, int r0, int r1)
 {
-    extern __shared__ float2 img[];
-    int bid = blockIdx.x;
-    int band = bid % nbands;
-    bid /= nbands;
-    int c = bid & 1;
-    bid >>= 1;
-    const int FB = w.F * w.B;
-    int ib = bid % FB, j = bid / FB;
+    Splat sp = make_splat(p.x, p.y);                 // traj stores (y, x) in (.x, .y)
+    float tau = 0.0f;
+    if (QT) tau = 1.0f - fabsf(im.tref - ts) / im.delta;     // :94-95
+    (void)mv;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int iy = sp.iy[k >> 1], ix = sp.ix[k & 1];
+        float wgt = sp.wy[k >> 1] * sp.wx[k & 1];
+        if (wgt == 0.0f || iy < r0 || iy >= r1 || ix < 0 || ix >= w.W) continue;
+        float v = QT ? (wgt * tau) * m : wgt * m;
+        atomicAdd(img + (iy - r0) * w.W + ix, (double)v);
+    }
+}
+
+template <bool QT>
+__device__ __forceinline__ void splat_range(const Win &w, const Img &im, const Events &E, int b, int c, int base,
+                                            int s0, int s1, const float2 *__restrict__ pl,
+                                            const uint32_t *__restrict__ mt, double *img, int r0, int r1)
+{
+    const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap;
+    const float *tsp = E.ts + (size_t)b * E.cap;
+    const uint32_t polbit = c ? kMetaNeg : kMetaPos;
+    const int stride = blockDim.x;
+    for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
+        uint32_t mv[kUnroll];
+        float2 p[kUnroll];
+        float ts[kUnroll];
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) {      // issue every load of the batch before any use
+            int sl = sl0 + q * stride;
+            bool ok = sl < s1;
+            int u = base + (ok ? sl : s0);
+            mv[q] = ok ? mt[u] : 0u;
+            p[q] = pl[u];
+            ts[q] = QT ? tsp[ok ? sl : s0] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) {
+            if (!((mv[q] >> im.s) & 1u) || !(mv[q] & polbit)) continue;   // shared border mask (:671-681), polarity
+            float m = 1.0f;
+            if (mv[q] & kMetaNonUnit) m = mask[sl0 + q * stride];
+            splat_one<QT>(w, im, mv[q], p[q], ts[q], m, img, r0, r1);
+        }
+    }
+}
+
+template <bool QT>
+__device__ __forceinline__ void splat_body(const Win &w, const Events &g, const Events &d,
+                                           const float2 *__restrict__ traj, const uint32_t *__restrict__ meta,
+                                           float *__restrict__ out, int j, int ib, int c, int band, int rows_per_band,
+                                           double *img)
+{
+    const int FB = w.F * w.B, H = w.H, W = w.W;
     int b = ib % w.B;
-    const int H = w.H, W = w.W;
     int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
     int npx = (r1 - r0) * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = make_float2(0.0f, 0.0f);
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = 0.0;
     __syncthreads();
-
     Img im = decode_image(w, j);
     const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
     const uint32_t *mt = meta + (size_t)ib * w.Mt;
-#pragma unroll 1
-    for (int list = 0; list < 2; ++list) {
-        const Events &E = list ? d : g;
-        int base = list ? w.M : 0;
-        int s0 = list ? w.doff[im.le] : w.off[im.le];
-        int s1 = list ? w.doff[im.he] : w.off[im.he];
-        const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap;
-        const float *tsp = E.ts + (size_t)b * E.cap;
-        for (int sl = s0 + threadIdx.x; sl < s1; sl += blockDim.x) {
-            int u = base + sl;
-            if (!((mt[u] >> im.s) & 1u)) continue;          // shared border mask (:671-681)
-            float m = mask[sl];
-            if (m == 0.0f) continue;
-            float2 p = pl[u];
-            float tau = 1.0f - fabsf(im.tref - tsp[sl]) / im.delta;     // :94-95
-            Splat sp = make_splat(p.x, p.y);                 // traj stores (y, x) in (.x, .y)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int iy = sp.iy[k >> 1], ix = sp.ix[k & 1];
-                float wgt = sp.wy[k >> 1] * sp.wx[k & 1];
-                if (wgt == 0.0f || iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
-                float2 *px = img + (iy - r0) * W + ix;
-                atomicAdd(&px->x, wgt * m);
-                atomicAdd(&px->y, (wgt * tau) * m);
-            }
-        }
-    }
+    splat_range<QT>(w, im, g, b, c, 0, w.off[im.le], w.off[im.he], pl, mt, img, r0, r1);
+    if (w.Md > 0) splat_range<QT>(w, im, d, b, c, w.M, w.doff[im.le], w.doff[im.he], pl, mt, img, r0, r1);
     __syncthreads();
-    float2 *out = iwe + (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) out[p] = img[p];
+    float *o = out + (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) o[p] = (float)img[p];
+}
+
+__global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, Events d,
+                                                              const float2 *__restrict__ traj,
+                                                              const uint32_t *__restrict__ meta,
+                                                              float *__restrict__ iwe_c, float *__restrict__ iwe_t,
+                                                              int rows_per_band, int nbands)
+{
+    extern __shared__ double lds_img[];
+    const int FB = w.F * w.B;
+    int item, sub;
+    xcd_split(blockIdx.x, 4 * nbands, item, sub);     // item = (sorted image, head, sample); sub = (band, pol, quantity)
+    if (item >= w.nimg * FB) return;
+    int j = w.order[item / FB], ib = item % FB;
+    int qt = sub & 1, c = (sub >> 1) & 1, band = sub >> 2;
+    if (qt)
+        splat_body<true>(w, g, d, traj, meta, iwe_t, j, ib, c, band, rows_per_band, lds_img);
+    else
+        splat_body<false>(w, g, d, traj, meta, iwe_c, j, ib, c, band, rows_per_band, lds_img);
 }
 
 // =============================================================================================
 // K3: per-image focus loss terms.  loss/flow.py:112-129 focus_loss on A = T / (C + 1e-9) (:727).
+//   ar   [(j*FB + ib)*2 + c][H*W] float2 = (A, R = 1/(C + 1e-9))  for the backward
 //   stats[(j*FB + ib)*2 + 0] = sum_px (A_pos^2 + A_neg^2) / n,   [+1] = n = #{C_pos + C_neg != 0} + 1e-9
 // =============================================================================================
-__global__ __launch_bounds__(256) void image_stats_kernel(Win w, const float2 *__restrict__ iwe,
+__global__ __launch_bounds__(256) void image_stats_kernel(Win w, const float *__restrict__ iwe_c,
+                                                          const float *__restrict__ iwe_t, float2 *__restrict__ ar,
                                                           float *__restrict__ stats)
 {
     __shared__ double ssum[256];
     __shared__ int scnt[256];
     const int HW = w.H * w.W;
-    const float2 *pos = iwe + (size_t)blockIdx.x * 2 * HW;
-    const float2 *neg = pos + HW;
+    const size_t base = (size_t)blockIdx.x * 2 * HW;
     float acc = 0.0f;
     int nnz = 0;
     for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-        float2 a = pos[p], bq = neg[p];
-        float a0 = a.y / (a.x + kEps), a1 = bq.y / (bq.x + kEps);
+        float c0 = iwe_c[base + p], c1 = iwe_c[base + HW + p];
+        float t0 = iwe_t[base + p], t1 = iwe_t[base + HW + p];
+        float a0 = t0 / (c0 + kEps), a1 = t1 / (c1 + kEps);
+        ar[base + p] = make_float2(a0, 1.0f / (c0 + kEps));
+        ar[base + HW + p] = make_float2(a1, 1.0f / (c1 + kEps));
         acc += a0 * a0 + a1 * a1;
-        nnz += ((a.x + bq.x) != 0.0f);
+        nnz += ((c0 + c1) != 0.0f);
     }
     ssum[threadIdx.x] = (double)acc;
     scnt[threadIdx.x] = nnz;
@@ -439,10 +531,10 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const float *__
 
 // ---------------------------------------------------------------------------------------------
 // d(coef * image loss)/d position of one event at one image:
-//   dl/dw_k = sum_c m_c * K * 2 A_c (tau - A_c) / (C_c + eps),  K = grad_out * coef / n
+//   dl/dw_k = sum_c m_c * K * 2 A_c (tau - A_c) R_c,  K = grad_out * coef / n
 // followed by the derivative of the bilinear hat weights.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ iwe,
+__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
                                              const float *__restrict__ stats, int ib, int j, float kscale, float tref,
                                              float delta, float2 p, float ts, float mp, float mn)
 {
@@ -450,7 +542,7 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     const int FB = w.F * w.B;
     size_t q = (size_t)j * FB + ib;
     float kimg = kscale / stats[q * 2 + 1];
-    const float2 *pos = iwe + q * 2 * HW;
+    const float2 *pos = ar + q * 2 * HW;
     const float2 *neg = pos + HW;
     float tau = 1.0f - fabsf(tref - ts) / delta;
     Splat sp = make_splat(p.x, p.y);
@@ -462,14 +554,12 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
         int px = iy * w.W + ix;
         float dw = 0.0f;
         if (mp != 0.0f) {
-            float2 ct = pos[px];
-            float A = ct.y / (ct.x + kEps), R = 1.0f / (ct.x + kEps);
-            dw += mp * (2.0f * A * (tau - A) * R);
+            float2 a = pos[px];
+            dw += mp * (2.0f * a.x * (tau - a.x) * a.y);
         }
         if (mn != 0.0f) {
-            float2 ct = neg[px];
-            float A = ct.y / (ct.x + kEps), R = 1.0f / (ct.x + kEps);
-            dw += mn * (2.0f * A * (tau - A) * R);
+            float2 a = neg[px];
+            dw += mn * (2.0f * a.x * (tau - a.x) * a.y);
         }
         dw *= kimg;
         gy += dw * (sp.sy[k >> 1] * sp.wx[k & 1]);
@@ -479,7 +569,7 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
 }
 
 // gradient w.r.t. the event position at tref = k, summed over the temporal scales that use it (Iterative)
-__device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 *__restrict__ iwe,
+__device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 *__restrict__ ar,
                                                      const float *__restrict__ stats, int ib, uint32_t bits, int t,
                                                      int k, float gout, float2 p, float ts, float mp, float mn)
 {
@@ -494,7 +584,7 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
         if (t < le || t >= he) continue;
         int j = w.img_base[s] + wi * (scale + 1) + (k - lo);
         float coef = 1.0f / ((float)(1 << s) * (float)(2 * delta + 1) * (float)w.S * (float)w.F);
-        float2 a = image_grad(w, iwe, stats, ib, j, gout * coef, (float)k, (float)delta, p, ts, mp, mn);
+        float2 a = image_grad(w, ar, stats, ib, j, gout * coef, (float)k, (float)delta, p, ts, mp, mn);
         g.x += a.x;
         g.y += a.y;
     }
@@ -505,25 +595,28 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
 // K6 (Iterative): reverse sweep along each grad event's trajectory.
 // Autograd counterpart of loss/flow.py:555-584: p' = p + dt * f(p) with f = bilinear lookup, so the
 // adjoint picks up (I + dt * J^T) per step, and every step leaves dt * adjoint as the gradient of the
-// sampled flow vector.  contrib[(ib*P + k)*M + sl] = (d/d f_y, d/d f_x) of this event's sample of map k.
+// sampled flow vector.  cy/cx[(ib*P + k)*M + sl] = d/d f_y, d/d f_x of this event's sample of map k.
 // =============================================================================================
-__global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float *__restrict__ flows, Events g,
+__global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
                                                              const uint32_t *__restrict__ meta,
-                                                             const float2 *__restrict__ iwe,
+                                                             const float2 *__restrict__ ar,
                                                              const float *__restrict__ stats,
                                                              const float *__restrict__ grad_out,
-                                                             float2 *__restrict__ contrib)
+                                                             float *__restrict__ cy, float *__restrict__ cx, int chunks)
 {
-    int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    int ib, chunk;
+    xcd_split(blockIdx.x, chunks, ib, chunk);
+    if (ib >= w.F * w.B) return;
+    int sl = chunk * blockDim.x + threadIdx.x;
     if (sl >= w.M) return;
-    int ib = blockIdx.y, i = ib / w.B, b = ib - i * w.B;
+    int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, P = w.P, M = w.M;
-    float2 *co = contrib + (size_t)ib * P * M + sl;
+    float *coy = cy + (size_t)ib * P * M + sl, *cox = cx + (size_t)ib * P * M + sl;
     uint32_t mv = meta[(size_t)ib * w.Mt + sl];
     uint32_t bits = mv & 0xffu;
     if (bits == 0u) {
-        for (int k = 0; k < P; ++k) co[(size_t)k * M] = make_float2(0.0f, 0.0f);
+        for (int k = 0; k < P; ++k) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
         return;
     }
     int kb = (int)((mv >> 8) & 0xffu) - 1, kf = (int)((mv >> 16) & 0xffu);
@@ -537,11 +630,11 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float 
     float ay = 0.0f, ax = 0.0f;
     for (int k = P; k > t; --k) {        // forward chain, newest first
         if (k >= kf) {
-            if (k - 1 > t) co[(size_t)(k - 1) * M] = make_float2(0.0f, 0.0f);
+            if (k - 1 > t) { coy[(size_t)(k - 1) * M] = 0.0f; cox[(size_t)(k - 1) * M] = 0.0f; }
             continue;
         }
         float2 pk = tr[(size_t)k * w.Mt];
-        float2 gk = iter_position_grad(w, iwe, stats, ib, bits, t, k, gout, pk, ts, mp, mn);
+        float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, pk, ts, mp, mn);
         ay += gk.x;
         ax += gk.y;
         if (k - 1 == t) {
@@ -549,12 +642,12 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float 
             c0y += c * ay;
             c0x += c * ax;
         } else {
-            co[(size_t)(k - 1) * M] = make_float2(ay, ax);
+            coy[(size_t)(k - 1) * M] = ay;
+            cox[(size_t)(k - 1) * M] = ax;
             float2 q = tr[(size_t)(k - 1) * w.Mt];
             Taps tp = make_taps(q.x, q.y, H, W);
             float jyy, jyx, jxy, jxx;
-            quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b, 1), tp), tp, jyy, jyx);
-            quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b, 0), tp), tp, jxy, jxx);
+            quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp), tp, jyy, jyx, jxy, jxx);
             float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
             ay = ny;
             ax = nx;
@@ -564,11 +657,11 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float 
     ax = 0.0f;
     for (int k = 0; k <= t; ++k) {       // backward chain, oldest first
         if (k <= kb) {
-            if (k < t) co[(size_t)k * M] = make_float2(0.0f, 0.0f);
+            if (k < t) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
             continue;
         }
         float2 pk = tr[(size_t)k * w.Mt];
-        float2 gk = iter_position_grad(w, iwe, stats, ib, bits, t, k, gout, pk, ts, mp, mn);
+        float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, pk, ts, mp, mn);
         ay += gk.x;
         ax += gk.y;
         if (k == t) {
@@ -576,33 +669,37 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float 
             c0y += c * ay;
             c0x += c * ax;
         } else {
-            co[(size_t)k * M] = make_float2(-ay, -ax);
+            coy[(size_t)k * M] = -ay;
+            cox[(size_t)k * M] = -ax;
             float2 q = tr[(size_t)(k + 1) * w.Mt];
             Taps tp = make_taps(q.x, q.y, H, W);
             float jyy, jyx, jxy, jxx;
-            quad_jacobian(load_quad(flow_map(w, flows, k, i, b, 1), tp), tp, jyy, jyx);
-            quad_jacobian(load_quad(flow_map(w, flows, k, i, b, 0), tp), tp, jxy, jxx);
+            quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp), tp, jyy, jyx, jxy, jxx);
             float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
             ay = ny;
             ax = nx;
         }
     }
-    co[(size_t)t * M] = make_float2(c0y, c0x);
+    coy[(size_t)t * M] = c0y;
+    cox[(size_t)t * M] = c0x;
 }
 
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
 __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const float2 *__restrict__ traj,
                                                          const uint32_t *__restrict__ meta,
-                                                         const float2 *__restrict__ iwe,
+                                                         const float2 *__restrict__ ar,
                                                          const float *__restrict__ stats,
-                                                         const float *__restrict__ grad_out,
-                                                         float2 *__restrict__ contrib)
+                                                         const float *__restrict__ grad_out, float *__restrict__ cy,
+                                                         float *__restrict__ cx, int chunks)
 {
-    int sl = blockIdx.x * blockDim.x + threadIdx.x;
+    int ib, chunk;
+    xcd_split(blockIdx.x, chunks, ib, chunk);
+    if (ib >= w.F * w.B) return;
+    int sl = chunk * blockDim.x + threadIdx.x;
     if (sl >= w.M) return;
-    int ib = blockIdx.y, b = ib % w.B;
+    int b = ib % w.B;
     uint32_t bits = meta[(size_t)ib * w.Mt + sl] & 0xffu;
-    float cy = 0.0f, cx = 0.0f;
+    float gy = 0.0f, gx = 0.0f;
     if (bits) {
         size_t o = (size_t)b * g.cap + sl;
         float ts = g.ts[o], mp = g.mp[o], mn = g.mn[o];
@@ -618,110 +715,175 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
                 float tref = (float)(e ? lo : hi);
                 int j = w.img_base[s] + wi * 2 + e;
                 float2 p = tr[(size_t)(2 * s + e) * w.Mt];
-                float2 gp = image_grad(w, iwe, stats, ib, j, gout * coef, tref, (float)scale, p, ts, mp, mn);
-                cy += (tref - ts) * gp.x;
-                cx += (tref - ts) * gp.y;
+                float2 gp = image_grad(w, ar, stats, ib, j, gout * coef, tref, (float)scale, p, ts, mp, mn);
+                gy += (tref - ts) * gp.x;
+                gx += (tref - ts) * gp.y;
             }
         }
     }
-    contrib[(size_t)ib * w.M + sl] = make_float2(cy, cx);
+    cy[(size_t)ib * w.M + sl] = gy;
+    cx[(size_t)ib * w.M + sl] = gx;
 }
 
 // =============================================================================================
 // K7: flow-map gradient = bilinear splat (grid_sample backward w.r.t. input) of the per-event vectors.
-// One workgroup per (pass k, head, sample[, band]); LDS holds the (x, y) gradient planes.
+// One workgroup per (pass k, head, sample, component[, band]); LDS holds one fp64 gradient plane.
 // Sample position of event (bin t) on map k: t < k -> trajectory plane k, t > k -> plane k+1,
 // t == k -> original location.  Linear: only the events of pass k sample map k.
-//   dflows [P][F][B][2][H][W] is fully overwritten.
+//   dflows [P][F][B][2][H][W] (channel 0 = x, 1 = y) is fully overwritten.
 // =============================================================================================
 __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
-                                                                    const float2 *__restrict__ contrib,
+                                                                    const float *__restrict__ cy,
+                                                                    const float *__restrict__ cx,
                                                                     float *__restrict__ dflows, int rows_per_band,
                                                                     int nbands)
 {
-    extern __shared__ float2 img[];      // (.x = d/d flow_x, .y = d/d flow_y)
-    int bid = blockIdx.x;
-    int band = bid % nbands;
-    bid /= nbands;
+    extern __shared__ double lds_img[];
     const int FB = w.F * w.B;
-    int ib = bid % FB, k = bid / FB;
+    int item, sub;
+    xcd_split(blockIdx.x, 2 * nbands, item, sub);      // item = (pass k, head, sample); sub = (band, component)
+    if (item >= w.P * FB) return;
+    int ib = item % FB, k = item / FB;
+    int comp = sub & 1, band = sub >> 1;               // comp 0 = d/d flow_x (channel 0), 1 = d/d flow_y
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, M = w.M;
     int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
     int npx = (r1 - r0) * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = make_float2(0.0f, 0.0f);
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) lds_img[p] = 0.0;
     __syncthreads();
 
     const bool iter = (w.kind == TEF_KIND_ITERATIVE);
-    const float2 *co = iter ? contrib + ((size_t)ib * w.P + k) * M : contrib + (size_t)ib * M;
+    const float *co = (comp ? cy : cx) + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
     const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
+    const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
     int s0 = iter ? 0 : w.off[k], s1 = iter ? M : w.off[k + 1];
-    for (int sl = s0 + threadIdx.x; sl < s1; sl += blockDim.x) {
-        float2 cv = co[sl];
-        if (cv.x == 0.0f && cv.y == 0.0f) continue;
-        int t = g.bin[sl];
-        float y, x;
-        if (t == k) {
-            size_t o = (size_t)b * g.cap + sl;
-            y = g.y[o];
-            x = g.x[o];
-        } else {
-            float2 p = tr[(size_t)(t < k ? k : k + 1) * w.Mt + sl];
-            y = p.x;
-            x = p.y;
-        }
-        Taps tp = make_taps(y, x, H, W);
-        const int idx[4] = {tp.i00, tp.i01, tp.i10, tp.i11};
-        const float wt[4] = {tp.s * tp.e, tp.s * tp.w, tp.n * tp.e, tp.n * tp.w};
+    const int stride = blockDim.x;
+    for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
+        float cv[kUnroll];
+        float2 p[kUnroll];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (idx[q] < 0) continue;
-            int iy = idx[q] / W;
-            if (iy < r0 || iy >= r1) continue;
-            float2 *px = img + (idx[q] - r0 * W);
-            atomicAdd(&px->x, cv.y * wt[q]);     // cv = (d/d f_y, d/d f_x)
-            atomicAdd(&px->y, cv.x * wt[q]);
+        for (int q = 0; q < kUnroll; ++q) {
+            int sl = sl0 + q * stride;
+            bool ok = sl < s1;
+            sl = ok ? sl : s0;
+            cv[q] = ok ? co[sl] : 0.0f;
+            int t = g.bin[sl];
+            // position this event had when it sampled map k
+            p[q] = (t == k) ? make_float2(ey[sl], ex[sl]) : tr[(size_t)(t < k ? k : k + 1) * w.Mt + sl];
+        }
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) {
+            if (cv[q] == 0.0f) continue;
+            Taps tp = make_taps(p[q].x, p[q].y, H, W);
+            const int idx[4] = {tp.i00, tp.i01, tp.i10, tp.i11};
+            const float wt[4] = {tp.s * tp.e, tp.s * tp.w, tp.n * tp.e, tp.n * tp.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (idx[c] < 0) continue;
+                int iy = idx[c] / W;
+                if (iy < r0 || iy >= r1) continue;
+                atomicAdd(lds_img + (idx[c] - r0 * W), (double)(cv[q] * wt[c]));
+            }
         }
     }
     __syncthreads();
-    float *ox = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2) * (size_t)(H * W) + (size_t)r0 * W;
-    float *oy = ox + (size_t)H * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) {
-        float2 v = img[p];
-        ox[p] = v.x;
-        oy[p] = v.y;
+    float *o = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2 + (comp ? 1 : 0)) * (size_t)(H * W) + (size_t)r0 * W;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) o[p] = (float)lds_img[p];
+}
+
+// K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473),
+// with a counting sort of the pass's events by (polarity class, 8x8 pixel tile).  The loss is a sum over
+// events, so the order inside a pass is free; sorting makes the 64 events of a wavefront spatially
+// coherent (their bilinear flow / IWE lookups share cache lines: 2x on the gather-bound kernels) and
+// polarity-uniform (a splat workgroup skips the other polarity a wavefront at a time).
+// One workgroup per sample.  Order inside a (class, tile) bucket follows LDS-atomic arrival.
+constexpr int kPackThreads = 1024;
+constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters
+
+__device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, int H, int W, int tile, int tw,
+                                        int ntiles)
+{
+    int cls = (mp == 0.0f && mn == 0.0f) ? 2 : (mn != 0.0f ? 1 : 0);     // positives, negatives, padding
+    int ty = min(max((int)y, 0), H - 1) / tile, tx = min(max((int)x, 0), W - 1) / tile;
+    return cls * ntiles + ty * tw + tx;
+}
+
+__global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__restrict__ ev,
+                                                                  const float *__restrict__ pm, int N, float ts_shift,
+                                                                  float ts_override, int pass_idx, int slot0, int cap,
+                                                                  int H, int W, int tile, float *__restrict__ ts,
+                                                                  float *__restrict__ y, float *__restrict__ x,
+                                                                  float *__restrict__ mp, float *__restrict__ mn,
+                                                                  uint8_t *__restrict__ bin)
+{
+    extern __shared__ int cnt[];          // [nbins] counters, then [kPackThreads] scan scratch
+    const int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile, ntiles = tw * th, nbins = 3 * ntiles;
+    int *part = cnt + nbins;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float4 *evb = reinterpret_cast<const float4 *>(ev) + (size_t)b * N;
+    const float2 *pmb = reinterpret_cast<const float2 *>(pm) + (size_t)b * N;
+    for (int k = tid; k < nbins; k += kPackThreads) cnt[k] = 0;
+    __syncthreads();
+    for (int e = tid; e < N; e += kPackThreads) {
+        float4 v = evb[e];
+        float2 m = pmb[e];
+        atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, tile, tw, ntiles)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the counters: per-thread run of consecutive bins + scan of the run totals
+    const int per = (nbins + kPackThreads - 1) / kPackThreads;
+    int lo = min(tid * per, nbins), hi = min(lo + per, nbins), run = 0;
+    for (int k = lo; k < hi; ++k) run += cnt[k];
+    part[tid] = run;
+    __syncthreads();
+    for (int s = 1; s < kPackThreads; s <<= 1) {
+        int v = (tid >= s) ? part[tid - s] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int base = part[tid] - run;
+    for (int k = lo; k < hi; ++k) {
+        int c = cnt[k];
+        cnt[k] = base;
+        base += c;
+    }
+    __syncthreads();
+    for (int e = tid; e < N; e += kPackThreads) {
+        float4 v = evb[e];
+        float2 m = pmb[e];
+        float t = v.x + ts_shift;
+        ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
+        int pos = atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, tile, tw, ntiles)], 1);
+        size_t o = (size_t)b * cap + slot0 + pos;
+        ts[o] = (ts_override >= 0.0f) ? ts_override : t;
+        y[o] = v.y;
+        x[o] = v.z;
+        mp[o] = m.x;
+        mn[o] = m.y;
+        if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
     }
 }
 
-// K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473).
-__global__ __launch_bounds__(256) void pack_events_kernel(float *__restrict__ ev, const float *__restrict__ pm, int B,
-                                                          int N, float ts_shift, float ts_override, int pass_idx,
-                                                          int slot0, int cap, float *__restrict__ ts,
-                                                          float *__restrict__ y, float *__restrict__ x,
-                                                          float *__restrict__ mp, float *__restrict__ mn,
-                                                          uint8_t *__restrict__ bin)
+// flow map of one head of one pass: [B,2,H,W] (ch0 = x, ch1 = y; any batch/channel strides, dense rows)
+//   -> planar copy [B][2][H*W] (smoothing kernels) and interleaved [B][H*W] float2 (flow_y, flow_x) (lookups)
+__global__ __launch_bounds__(256) void pack_flow_kernel(const float *__restrict__ src, long sb, long sc, int B, int HW,
+                                                        float *__restrict__ planar, float2 *__restrict__ yx)
 {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N) return;
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
     int b = blockIdx.y;
-    float4 v = reinterpret_cast<const float4 *>(ev)[(size_t)b * N + e];
-    float2 m = reinterpret_cast<const float2 *>(pm)[(size_t)b * N + e];
-    float t = v.x + ts_shift;
-    ev[((size_t)b * N + e) * 4] = t;                       // in-place shift of the caller's list (:457-458)
-    size_t o = (size_t)b * cap + slot0 + e;
-    ts[o] = (ts_override >= 0.0f) ? ts_override : t;
-    y[o] = v.y;
-    x[o] = v.z;
-    mp[o] = m.x;
-    mn[o] = m.y;
-    if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
+    float fx = src[(size_t)b * sb + p], fy = src[(size_t)b * sb + sc + p];
+    planar[((size_t)b * 2) * HW + p] = fx;
+    planar[((size_t)b * 2 + 1) * HW + p] = fy;
+    yx[(size_t)b * HW + p] = make_float2(fy, fx);
 }
 
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, iwe, stats, contrib, total;
+    size_t traj, meta, iwe_c, iwe_t, ar, stats, cy, cx, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -733,7 +895,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     if (c->B < 1 || c->H < 2 || c->W < 2 || c->F < 1) return tef::fail("bad B/H/W/F");
     if (c->P < 1 || c->P > TEF_MAX_PASSES) return tef::fail("passes_loss out of range [1, 64]");
     if (c->S < 1 || c->S > TEF_MAX_SCALES) return tef::fail("scales_loss out of range [1, 6]");
-    if ((size_t)c->W * sizeof(float2) > kLdsBudget) return tef::fail("image row does not fit the LDS band");
+    if ((size_t)c->W * sizeof(double) > kLdsBudget) return tef::fail("image row does not fit the LDS band");
     if (c->kind == TEF_KIND_ITERATIVE) {
         // iterative_mode "four" raises TypeError in the reference itself (loss/flow.py:666-692); only one/two exist here
         if (c->mode_div != 1 && c->mode_div != 2) return tef::fail("iterative_mode must be 'one' or 'two'");
@@ -757,10 +919,21 @@ bool make_win(const tef_loss_cfg *c, Win *w)
         if (c->kind == TEF_KIND_ITERATIVE && scale / c->mode_div < 1)
             return tef::fail("delta_passes is zero for a temporal scale (the reference divides by it)");
         w->img_base[s] = n;
-        n += images_of_scale(*w, s);
+        n += images_of_scale(c->kind, c->P, s);
     }
     w->img_base[c->S] = n;
     w->nimg = n;
+    if (n > kMaxImages) return tef::fail("too many images");
+    // longest-processing-time-first order of the splat workgroups: images with the most events first
+    int idx[kMaxImages];
+    long work[kMaxImages];
+    for (int j = 0; j < n; ++j) {
+        Img im = decode_image(*w, j);
+        idx[j] = j;
+        work[j] = (long)(w->off[im.he] - w->off[im.le]) + (long)(w->doff[im.he] - w->doff[im.le]);
+    }
+    std::stable_sort(idx, idx + n, [&](int a, int b) { return work[a] > work[b]; });
+    for (int j = 0; j < n; ++j) w->order[j] = (uint16_t)idx[j];
     return true;
 }
 
@@ -768,12 +941,17 @@ Layout make_layout(const Win &w)
 {
     Layout L;
     const size_t FB = (size_t)w.F * w.B, HW = (size_t)w.H * w.W;
+    const size_t img = (size_t)w.nimg * FB * 2 * HW;
+    const size_t nc = FB * (size_t)(w.kind == TEF_KIND_ITERATIVE ? w.P : 1) * (size_t)w.M;
     size_t o = 0;
-    L.traj = o;    o += align_up(FB * w.nplanes * (size_t)w.Mt * sizeof(float2));
-    L.meta = o;    o += align_up(FB * (size_t)w.Mt * sizeof(uint32_t));
-    L.iwe = o;     o += align_up((size_t)w.nimg * FB * 2 * HW * sizeof(float2));
-    L.stats = o;   o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
-    L.contrib = o; o += align_up(FB * (size_t)(w.kind == TEF_KIND_ITERATIVE ? w.P : 1) * (size_t)w.M * sizeof(float2));
+    L.traj = o;   o += align_up(FB * w.nplanes * (size_t)w.Mt * sizeof(float2));
+    L.meta = o;   o += align_up(FB * (size_t)w.Mt * sizeof(uint32_t));
+    L.iwe_c = o;  o += align_up(img * sizeof(float));
+    L.iwe_t = o;  o += align_up(img * sizeof(float));
+    L.ar = o;     o += align_up(img * sizeof(float2));
+    L.stats = o;  o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
+    L.cy = o;     o += align_up(nc * sizeof(float));
+    L.cx = o;     o += align_up(nc * sizeof(float));
     L.total = o;
     return L;
 }
@@ -788,11 +966,11 @@ inline Events to_events(const tef_events *e)
 
 inline void band_geometry(const Win &w, int *rows_per_band, int *nbands, size_t *lds)
 {
-    int rows = (int)(kLdsBudget / ((size_t)w.W * sizeof(float2)));
+    int rows = (int)(kLdsBudget / ((size_t)w.W * sizeof(double)));
     if (rows > w.H) rows = w.H;
     *rows_per_band = rows;
     *nbands = (w.H + rows - 1) / rows;
-    *lds = (size_t)rows * w.W * sizeof(float2);
+    *lds = (size_t)rows * w.W * sizeof(double);
 }
 
 bool g_attr_done = false;
@@ -822,24 +1000,45 @@ size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg)
 }
 
 int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
-                    int slot0, int cap, float *ts, float *y, float *x, float *mp, float *mn, uint8_t *bin,
-                    void *stream)
+                    int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
+                    uint8_t *bin, void *stream)
 {
-    if (B < 1 || N < 0 || slot0 < 0 || slot0 + N > cap || pass_idx < 0 || pass_idx >= TEF_MAX_PASSES)
+    if (B < 1 || N < 0 || slot0 < 0 || slot0 + N > cap || pass_idx < 0 || pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
         return tef::fail("tef_pack_events: bad sizes"), TEF_ERR_INVALID;
     if (N == 0) return 0;
-    dim3 grid((N + 255) / 256, B);
-    { tef::ProfScope ps(tef::PROF_PACK, (hipStream_t)stream); hipLaunchKernelGGL(pack_events_kernel, grid, dim3(256), 0, (hipStream_t)stream, ev, pm, B, N, ts_shift, ts_override,
-                       pass_idx, slot0, cap, ts, y, x, mp, mn, bin); }
+    int tile = 8;
+    while (3 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;
+    int nbins = 3 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
+    size_t lds = (size_t)(nbins + kPackThreads) * sizeof(int);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        tef::ProfScope ps(tef::PROF_PACK, st);
+        hipLaunchKernelGGL(pack_events_kernel, dim3(B), dim3(kPackThreads), lds, st, ev, pm, N, ts_shift, ts_override,
+                           pass_idx, slot0, cap, H, W, tile, ts, y, x, mp, mn, bin);
+    }
     return tef::check_launch("pack_events_kernel");
 }
 
-int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows, const tef_events *grad, const tef_events *det,
+int tef_pack_flow(const float *flow, long stride_b, long stride_c, int B, int H, int W, float *planar, float *yx,
+                  void *stream)
+{
+    if (!flow || !planar || !yx || B < 1 || H < 1 || W < 1) return tef::fail("tef_pack_flow: bad arguments"), TEF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H * W + 255) / 256, B);
+    {
+        tef::ProfScope ps(tef::PROF_PACK, st);
+        hipLaunchKernelGGL(pack_flow_kernel, grid, dim3(256), 0, st, flow, stride_b, stride_c, B, H * W, planar,
+                           (float2 *)yx);
+    }
+    return tef::check_launch("pack_flow_kernel");
+}
+
+int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,
                      void *workspace, size_t workspace_bytes, float *loss_out, void *stream)
 {
     Win w;
     if (!make_win(cfg, &w)) return TEF_ERR_INVALID;
-    if (!flows || !grad || !workspace || !loss_out) return tef::fail("null pointer"), TEF_ERR_INVALID;
+    if (!flows_yx || !grad || !workspace || !loss_out) return tef::fail("null pointer"), TEF_ERR_INVALID;
     if (w.Md > 0 && !det) return tef::fail("detached events missing"), TEF_ERR_INVALID;
     if (grad->cap < w.M || (det && w.Md > 0 && det->cap < w.Md)) return tef::fail("event capacity < slots"), TEF_ERR_INVALID;
     Layout L = make_layout(w);
@@ -849,38 +1048,52 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows, const tef_even
     char *ws = (char *)workspace;
     float2 *traj = (float2 *)(ws + L.traj);
     uint32_t *meta = (uint32_t *)(ws + L.meta);
-    float2 *iwe = (float2 *)(ws + L.iwe);
+    float *iwe_c = (float *)(ws + L.iwe_c), *iwe_t = (float *)(ws + L.iwe_t);
+    float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
+    const float2 *fl = (const float2 *)flows_yx;
     Events g = to_events(grad), d = to_events(w.Md > 0 ? det : nullptr);
     const int FB = w.F * w.B;
 
     if (w.Mt > 0) {
-        dim3 grid((w.Mt + 255) / 256, FB);
+        int chunks = (w.Mt + 255) / 256;
+        dim3 grid(xcd_grid(FB, chunks));
+        tef::ProfScope ps(tef::PROF_WARP, st);
         if (w.kind == TEF_KIND_ITERATIVE)
-            { tef::ProfScope ps(tef::PROF_WARP, st); hipLaunchKernelGGL(iter_warp_kernel, grid, dim3(256), 0, st, w, flows, g, d, traj, meta); }
+            hipLaunchKernelGGL(iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, chunks);
         else
-            { tef::ProfScope ps(tef::PROF_WARP, st); hipLaunchKernelGGL(linear_warp_kernel, grid, dim3(256), 0, st, w, flows, g, d, traj, meta); }
-        if (int rc = tef::check_launch("warp_kernel")) return rc;
+            hipLaunchKernelGGL(linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, chunks);
     }
+    if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
     size_t lds;
     band_geometry(w, &rows, &nbands, &lds);
-    { tef::ProfScope ps(tef::PROF_SPLAT, st); hipLaunchKernelGGL(splat_kernel, dim3((unsigned)(w.nimg * FB * 2 * nbands)), dim3(kSplatThreads), lds, st, w, g, d,
-                       traj, meta, iwe, rows, nbands); }
+    {
+        tef::ProfScope ps(tef::PROF_SPLAT, st);
+        hipLaunchKernelGGL(splat_kernel, dim3(xcd_grid(w.nimg * FB, 4 * nbands)), dim3(kSplatThreads), lds, st, w, g, d,
+                           traj, meta, iwe_c, iwe_t, rows, nbands);
+    }
     if (int rc = tef::check_launch("splat_kernel")) return rc;
-    { tef::ProfScope ps(tef::PROF_STATS, st); hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, w, iwe, stats); }
+    {
+        tef::ProfScope ps(tef::PROF_STATS, st);
+        hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, w, iwe_c, iwe_t, ar,
+                           stats);
+    }
     if (int rc = tef::check_launch("image_stats_kernel")) return rc;
-    { tef::ProfScope ps(tef::PROF_REDUCE, st); hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, stats, loss_out); }
+    {
+        tef::ProfScope ps(tef::PROF_REDUCE, st);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, stats, loss_out);
+    }
     return tef::check_launch("loss_reduce_kernel");
 }
 
-int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows, const tef_events *grad, const tef_events *det,
+int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,
                       void *workspace, size_t workspace_bytes, const float *grad_out, float *dflows, void *stream)
 {
     (void)det;
     Win w;
     if (!make_win(cfg, &w)) return TEF_ERR_INVALID;
-    if (!flows || !grad || !workspace || !grad_out || !dflows) return tef::fail("null pointer"), TEF_ERR_INVALID;
+    if (!flows_yx || !grad || !workspace || !grad_out || !dflows) return tef::fail("null pointer"), TEF_ERR_INVALID;
     Layout L = make_layout(w);
     if (workspace_bytes < L.total) return tef::fail("workspace too small"), TEF_ERR_WORKSPACE;
     if (!ensure_attrs()) return TEF_ERR_LAUNCH;
@@ -888,26 +1101,32 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows, const tef_eve
     char *ws = (char *)workspace;
     float2 *traj = (float2 *)(ws + L.traj);
     uint32_t *meta = (uint32_t *)(ws + L.meta);
-    float2 *iwe = (float2 *)(ws + L.iwe);
+    float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
-    float2 *contrib = (float2 *)(ws + L.contrib);
+    float *cy = (float *)(ws + L.cy), *cx = (float *)(ws + L.cx);
+    const float2 *fl = (const float2 *)flows_yx;
     Events g = to_events(grad);
     const int FB = w.F * w.B;
     if (w.M > 0) {
-        dim3 grid((w.M + 255) / 256, FB);
+        int chunks = (w.M + 255) / 256;
+        dim3 grid(xcd_grid(FB, chunks));
+        tef::ProfScope ps(tef::PROF_CHAIN_BWD, st);
         if (w.kind == TEF_KIND_ITERATIVE)
-            { tef::ProfScope ps(tef::PROF_CHAIN_BWD, st); hipLaunchKernelGGL(iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, flows, g, traj, meta, iwe, stats,
-                               grad_out, contrib); }
+            hipLaunchKernelGGL(iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar, stats, grad_out,
+                               cy, cx, chunks);
         else
-            { tef::ProfScope ps(tef::PROF_CHAIN_BWD, st); hipLaunchKernelGGL(linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, iwe, stats, grad_out,
-                               contrib); }
-        if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
+            hipLaunchKernelGGL(linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats, grad_out, cy, cx,
+                               chunks);
     }
+    if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
     int rows, nbands;
     size_t lds;
     band_geometry(w, &rows, &nbands, &lds);
-    { tef::ProfScope ps(tef::PROF_DFLOW, st); hipLaunchKernelGGL(dflow_splat_kernel, dim3((unsigned)(w.P * FB * nbands)), dim3(kSplatThreads), lds, st, w, g, traj,
-                       contrib, dflows, rows, nbands); }
+    {
+        tef::ProfScope ps(tef::PROF_DFLOW, st);
+        hipLaunchKernelGGL(dflow_splat_kernel, dim3(xcd_grid(w.P * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w, g,
+                           traj, cy, cx, dflows, rows, nbands);
+    }
     return tef::check_launch("dflow_splat_kernel");
 }
 

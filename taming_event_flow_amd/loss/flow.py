@@ -23,8 +23,8 @@ __all__ = ["BaseEventWarping", "Linear", "Iterative"]
 class _SoA:
     """Growable structure-of-arrays event store for one list (grad or detached) of one window."""
 
-    def __init__(self, B, device):
-        self.B, self.device = B, device
+    def __init__(self, B, device, res):
+        self.B, self.device, self.res = B, device, res
         self.cap = 0
         self.n = 0
         self.off = [0]
@@ -59,6 +59,7 @@ class _SoA:
             pmc = pm.to(torch.float32).contiguous()
             rc = _lib.lib().tef_pack_events(
                 src.data_ptr(), pmc.data_ptr(), B, N, shift, ts_override, pass_idx, self.n, self.cap,
+                self.res[0], self.res[1],
                 self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(), self.mn.data_ptr(),
                 self.bin.data_ptr(), _lib.stream_ptr(),
             )
@@ -76,11 +77,12 @@ class _SoA:
 class _Window:
     """Device state of one loss window (everything the kernels read)."""
 
-    def __init__(self, B, device):
-        self.flows = None          # [P][F][B][2][H][W]
+    def __init__(self, B, device, res):
+        self.flows = None          # planar      [P][F][B][2][H][W]  (smoothing terms, gradient layout)
+        self.flows_yx = None       # interleaved [P][F][B][H][W][2]  (flow_y, flow_x) for the lookups
         self.flow_refs = []        # autograd handles, flow_refs[t][i]
-        self.grad = _SoA(B, device)
-        self.det = _SoA(B, device)
+        self.grad = _SoA(B, device, res)
+        self.det = _SoA(B, device, res)
         self.workspace = None
         self.scratch = None
         self.cfg = None
@@ -95,7 +97,7 @@ class _CMLossFn(torch.autograd.Function):
         cfg = win.cfg
         loss = torch.zeros((), dtype=torch.float32, device=win.flows.device)
         g, d = win.grad.struct(), win.det.struct()
-        rc = lib.tef_loss_forward(ctypes.byref(cfg), win.flows.data_ptr(), ctypes.byref(g), ctypes.byref(d),
+        rc = lib.tef_loss_forward(ctypes.byref(cfg), win.flows_yx.data_ptr(), ctypes.byref(g), ctypes.byref(d),
                                   win.workspace.data_ptr(), win.workspace.numel(), loss.data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "tef_loss_forward")
         ws, wt = module._smooth_weights(cfg.P)
@@ -115,7 +117,7 @@ class _CMLossFn(torch.autograd.Function):
         go = grad_out.to(torch.float32).contiguous()
         dflows = torch.empty_like(win.flows)
         g, d = win.grad.struct(), win.det.struct()
-        rc = lib.tef_loss_backward(ctypes.byref(cfg), win.flows.data_ptr(), ctypes.byref(g), ctypes.byref(d),
+        rc = lib.tef_loss_backward(ctypes.byref(cfg), win.flows_yx.data_ptr(), ctypes.byref(g), ctypes.byref(d),
                                    workspace.data_ptr(), workspace.numel(), go.data_ptr(), dflows.data_ptr(),
                                    _lib.stream_ptr())
         _lib.check(rc, "tef_loss_backward")
@@ -175,15 +177,23 @@ class BaseEventWarping(torch.nn.Module):
         B, F = self.batch_size, self._num_flows
         win = self._win
         if win is None:
-            win = self._win = _Window(B, self.device)
+            win = self._win = _Window(B, self.device, self.res)
         if win.flows is None:
             _lib.require_device_tensor(flow_list[0], "flow map")
             win.flows = torch.empty((P, F, B, 2, H, W), dtype=torch.float32, device=flow_list[0].device)
+            win.flows_yx = torch.empty((P, F, B, H, W, 2), dtype=torch.float32, device=flow_list[0].device)
         refs = []
+        lib = _lib.lib()
         for i, flow in enumerate(flow_list):
             if tuple(flow.shape) != (B, 2, H, W):
                 raise RuntimeError(f"flow map {i} has shape {tuple(flow.shape)}, expected {(B, 2, H, W)}")
-            win.flows[self._passes, i].copy_(flow.detach())
+            src = _lib.require_device_tensor(flow.detach(), "flow map")
+            if src.dtype != torch.float32 or src.stride(3) != 1 or src.stride(2) != W:
+                src = src.to(torch.float32).contiguous()
+            rc = lib.tef_pack_flow(src.data_ptr(), src.stride(0), src.stride(1), B, H, W,
+                                   win.flows[self._passes, i].data_ptr(), win.flows_yx[self._passes, i].data_ptr(),
+                                   _lib.stream_ptr())
+            _lib.check(rc, "tef_pack_flow")
             refs.append(flow)
         win.flow_refs.append(refs)
 
