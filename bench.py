@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--windows", type=int, default=2, help="distinct pre-staged windows cycled through")
     ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
                     help="experiment: pre-sort the synthetic events of each pass on the host")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -162,10 +163,11 @@ def main():
     for k in range(a.warmup):
         step(k)
     barrier()
-    lib.tef_profile_enable(1)       # HIP events around every kernel, on the launch stream
+    lib.tef_profile_enable(0 if a.no_kernel_events else 1)       # HIP events around every kernel, on the launch stream
     t0 = time.perf_counter()
     for k in range(a.steps):
         last = step(k)
+    t_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (diagnostic: host- vs device-bound)
     barrier()
     elapsed = time.perf_counter() - t0
     lib.tef_profile_collect()
@@ -214,6 +216,7 @@ def main():
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective)"},
             "loss": round(loss_val, 6),
             "ms_update_per_window": round(1e3 * t_update / a.windows, 3),
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -59,6 +59,8 @@ long tef_profile_calls(int slot);
 typedef struct tef_events {
     const float *ts, *y, *x, *mp, *mn;
     const uint8_t *bin;
+    const int *cls;   /* [B][TEF_MAX_PASSES][3]: per sample and pass, where the pos-only / neg-only / both-polarity
+                         runs of the pass end (slots relative to the pass start); written by tef_pack_events */
     int cap;
 } tef_events;
 
@@ -84,7 +86,7 @@ typedef struct tef_loss_cfg {
  * events, so the order inside a pass is free, and coherent wavefronts halve the cost of the lookups. */
 int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
                     int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
-                    uint8_t *bin, void *stream);
+                    uint8_t *bin, int *cls, void *stream);
 
 /* Flow map of one head of one pass, replaces BaseEventWarping.update_base (loss/flow.py:46-66): copies the
  * model's [B,2,H,W] tensor (channel 0 = x, 1 = y; element strides stride_b / stride_c, rows dense) into

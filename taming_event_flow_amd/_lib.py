@@ -8,7 +8,7 @@ import ctypes
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libtef_hip.so")
+LIB_PATH = os.environ.get("TEF_HIP_LIB", os.path.join(PKG, "libtef_hip.so"))   # override: A/B builds only
 
 TEF_MAX_PASSES = 64
 TEF_MAX_SCALES = 6
@@ -21,7 +21,8 @@ _fp = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 class Events(ctypes.Structure):
     """struct tef_events (include/tef.h)"""
 
-    _fields_ = [("ts", _fp), ("y", _fp), ("x", _fp), ("mp", _fp), ("mn", _fp), ("bin", _fp), ("cap", ctypes.c_int)]
+    _fields_ = [("ts", _fp), ("y", _fp), ("x", _fp), ("mp", _fp), ("mn", _fp), ("bin", _fp), ("cls", _fp),
+                ("cap", ctypes.c_int)]
 
 
 class LossCfg(ctypes.Structure):
@@ -47,7 +48,7 @@ SIGNATURES = {
     "tef_profile_calls": (ctypes.c_long, [ctypes.c_int]),
     "tef_pack_events": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
-                                       _fp, _fp, _fp, _fp]),
+                                       _fp, _fp, _fp, _fp, _fp]),
     "tef_pack_flow": (ctypes.c_int, [_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                      _fp, _fp]),
     "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),

@@ -42,7 +42,13 @@ namespace {
 
 constexpr float kEps = 1e-9f;
 constexpr int kSplatThreads = 1024;
-constexpr size_t kLdsBudget = 128 * 1024;   // per-workgroup accumulator budget (160 KiB LDS per CU on gfx950)
+constexpr size_t kLdsBudget = 144 * 1024;   // per-workgroup accumulator budget (160 KiB LDS per CU on gfx950)
+#ifndef TEF_ROWPAD
+#define TEF_ROWPAD 8
+#endif
+constexpr int kRowPad = TEF_ROWPAD;                  // fp64 LDS rows are W + 8 wide: rows 16 banks apart, so the 8x8-pixel
+                                            // neighbourhood a sorted wavefront hits spreads over all 64 banks
+constexpr int kMaxSegs = 4 * TEF_MAX_PASSES;
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
 constexpr int kUnroll = 4;
 
@@ -65,6 +71,7 @@ struct Win {
 struct Events {
     const float *ts, *y, *x, *mp, *mn;
     const uint8_t *bin;
+    const int *cls;      // [B][TEF_MAX_PASSES][3]: end of the pos-only / neg-only / both-polarity run of each pass
     int cap;
 };
 
@@ -162,14 +169,27 @@ __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
 
 struct Quad2 { float2 v00, v01, v10, v11; };
 
-__device__ __forceinline__ Quad2 load_quad(const float2 *__restrict__ map, const Taps &t)
+// two horizontally adjacent float2 pixels in one 16-byte load (global_load_dwordx4 only needs 4-byte alignment)
+struct __attribute__((aligned(8))) Pair2 { float2 a, b; };
+
+__device__ __forceinline__ void load_row(const float2 *__restrict__ map, int i0, int i1, float2 &v0, float2 &v1)
 {
     const float2 z = make_float2(0.0f, 0.0f);
+    if (i0 >= 0 && i1 >= 0) {
+        Pair2 p = *reinterpret_cast<const Pair2 *>(map + i0);
+        v0 = p.a;
+        v1 = p.b;
+    } else {
+        v0 = i0 >= 0 ? map[i0] : z;
+        v1 = i1 >= 0 ? map[i1] : z;
+    }
+}
+
+__device__ __forceinline__ Quad2 load_quad(const float2 *__restrict__ map, const Taps &t)
+{
     Quad2 q;
-    q.v00 = t.i00 >= 0 ? map[t.i00] : z;
-    q.v01 = t.i01 >= 0 ? map[t.i01] : z;
-    q.v10 = t.i10 >= 0 ? map[t.i10] : z;
-    q.v11 = t.i11 >= 0 ? map[t.i11] : z;
+    load_row(map, t.i00, t.i01, q.v00, q.v01);
+    load_row(map, t.i10, t.i11, q.v10, q.v11);
     return q;
 }
 
@@ -378,52 +398,70 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
 // them on one XCD so the plane is fetched from HBM once.
 // =============================================================================================
 template <bool QT>
-__device__ __forceinline__ void splat_one(const Win &w, const Img &im, uint32_t mv, float2 p, float ts, float m,
-                                          double *img, int r0, int r1)
+__device__ __forceinline__ void splat_one(const Win &w, const Img &im, float2 p, float ts, float m, double *img,
+                                          int r0, int r1)
 {
     Splat sp = make_splat(p.x, p.y);                 // traj stores (y, x) in (.x, .y)
     float tau = 0.0f;
     if (QT) tau = 1.0f - fabsf(im.tref - ts) / im.delta;     // :94-95
-    (void)mv;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int iy = sp.iy[k >> 1], ix = sp.ix[k & 1];
         float wgt = sp.wy[k >> 1] * sp.wx[k & 1];
         if (wgt == 0.0f || iy < r0 || iy >= r1 || ix < 0 || ix >= w.W) continue;
         float v = QT ? (wgt * tau) * m : wgt * m;
-        atomicAdd(img + (iy - r0) * w.W + ix, (double)v);
+        atomicAdd(img + (iy - r0) * (w.W + kRowPad) + ix, (double)v);
     }
 }
 
+// one contiguous run of slots [u0, u0 + len) of unified slot space (all of the workgroup's polarity)
 template <bool QT>
-__device__ __forceinline__ void splat_range(const Win &w, const Img &im, const Events &E, int b, int c, int base,
-                                            int s0, int s1, const float2 *__restrict__ pl,
-                                            const uint32_t *__restrict__ mt, double *img, int r0, int r1)
+__device__ __forceinline__ void splat_run(const Win &w, const Img &im, const Events &g, const Events &d, int b, int c,
+                                          int u0, int len, const float2 *__restrict__ pl,
+                                          const uint32_t *__restrict__ mt, double *img, int r0, int r1)
 {
-    const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap;
-    const float *tsp = E.ts + (size_t)b * E.cap;
-    const uint32_t polbit = c ? kMetaNeg : kMetaPos;
+    const bool isd = u0 >= w.M;
+    const Events &E = isd ? d : g;
+    const float *tsp = E.ts + (size_t)b * E.cap - (isd ? w.M : 0);      // indexed by unified slot
+    const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap - (isd ? w.M : 0);
     const int stride = blockDim.x;
-    for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
+    for (int v0 = threadIdx.x; v0 < len; v0 += kUnroll * stride) {
         uint32_t mv[kUnroll];
         float2 p[kUnroll];
         float ts[kUnroll];
 #pragma unroll
         for (int q = 0; q < kUnroll; ++q) {      // issue every load of the batch before any use
-            int sl = sl0 + q * stride;
-            bool ok = sl < s1;
-            int u = base + (ok ? sl : s0);
+            int v = v0 + q * stride;
+            bool ok = v < len;
+            int u = u0 + (ok ? v : v0);
             mv[q] = ok ? mt[u] : 0u;
             p[q] = pl[u];
-            ts[q] = QT ? tsp[ok ? sl : s0] : 0.0f;
+            ts[q] = QT ? tsp[u] : 0.0f;
         }
 #pragma unroll
         for (int q = 0; q < kUnroll; ++q) {
-            if (!((mv[q] >> im.s) & 1u) || !(mv[q] & polbit)) continue;   // shared border mask (:671-681), polarity
+            if (!((mv[q] >> im.s) & 1u)) continue;   // shared border mask (:671-681)
             float m = 1.0f;
-            if (mv[q] & kMetaNonUnit) m = mask[sl0 + q * stride];
-            splat_one<QT>(w, im, mv[q], p[q], ts[q], m, img, r0, r1);
+            if (mv[q] & kMetaNonUnit) m = mask[u0 + v0 + q * stride];
+            splat_one<QT>(w, im, p[q], ts[q], m, img, r0, r1);
         }
+    }
+}
+
+// events of polarity c of pass t: classes are stored [pos-only | neg-only | both | padding]
+template <bool QT>
+__device__ __forceinline__ void splat_pass(const Win &w, const Img &im, const Events &g, const Events &d,
+                                           const Events &E, int b, int c, int t, int base, int slot0,
+                                           const float2 *__restrict__ pl, const uint32_t *__restrict__ mt,
+                                           double *img, int r0, int r1)
+{
+    const int *cl = E.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3;
+    int n0 = cl[0], n01 = cl[1], n012 = cl[2];
+    if (c == 0) {
+        splat_run<QT>(w, im, g, d, b, c, base + slot0, n0, pl, mt, img, r0, r1);
+        splat_run<QT>(w, im, g, d, b, c, base + slot0 + n01, n012 - n01, pl, mt, img, r0, r1);
+    } else {
+        splat_run<QT>(w, im, g, d, b, c, base + slot0 + n0, n012 - n0, pl, mt, img, r0, r1);
     }
 }
 
@@ -433,20 +471,25 @@ __device__ __forceinline__ void splat_body(const Win &w, const Events &g, const 
                                            float *__restrict__ out, int j, int ib, int c, int band, int rows_per_band,
                                            double *img)
 {
-    const int FB = w.F * w.B, H = w.H, W = w.W;
+    const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad;
     int b = ib % w.B;
     int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
-    int npx = (r1 - r0) * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = 0.0;
+    int nlds = (r1 - r0) * WP;
+    for (int p = threadIdx.x; p < nlds; p += blockDim.x) img[p] = 0.0;
     __syncthreads();
     Img im = decode_image(w, j);
     const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
     const uint32_t *mt = meta + (size_t)ib * w.Mt;
-    splat_range<QT>(w, im, g, b, c, 0, w.off[im.le], w.off[im.he], pl, mt, img, r0, r1);
-    if (w.Md > 0) splat_range<QT>(w, im, d, b, c, w.M, w.doff[im.le], w.doff[im.he], pl, mt, img, r0, r1);
+    for (int t = im.le; t < im.he; ++t) splat_pass<QT>(w, im, g, d, g, b, c, t, 0, w.off[t], pl, mt, img, r0, r1);
+    if (w.Md > 0)
+        for (int t = im.le; t < im.he; ++t)
+            splat_pass<QT>(w, im, g, d, d, b, c, t, w.M, w.doff[t], pl, mt, img, r0, r1);
     __syncthreads();
     float *o = out + (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) o[p] = (float)img[p];
+    for (int p = threadIdx.x; p < (r1 - r0) * W; p += blockDim.x) {
+        int r = p / W;
+        o[p] = (float)img[r * WP + (p - r * W)];
+    }
 }
 
 __global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, Events d,
@@ -547,23 +590,33 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     float tau = 1.0f - fabsf(tref - ts) / delta;
     Splat sp = make_splat(p.x, p.y);
     float gy = 0.0f, gx = 0.0f;
+    bool vx0 = (sp.ix[0] >= 0) & (sp.ix[0] < w.W), vx1 = (sp.ix[1] >= 0) & (sp.ix[1] < w.W);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int iy = sp.iy[k >> 1], ix = sp.ix[k & 1];
-        if (iy < 0 || iy >= w.H || ix < 0 || ix >= w.W) continue;
-        int px = iy * w.W + ix;
-        float dw = 0.0f;
+    for (int r = 0; r < 2; ++r) {
+        int iy = sp.iy[r];
+        if (iy < 0 || iy >= w.H) continue;
+        int i0 = vx0 ? iy * w.W + sp.ix[0] : -1;
+        int i1 = (vx1 && sp.ix[1] == sp.ix[0] + 1) ? iy * w.W + sp.ix[1] : -1;   // adjacent unless y+1 rounded up
+        int i1s = (vx1 && i1 < 0) ? iy * w.W + sp.ix[1] : -1;
+        float2 ap[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, an[2] = {ap[0], ap[0]};
         if (mp != 0.0f) {
-            float2 a = pos[px];
-            dw += mp * (2.0f * a.x * (tau - a.x) * a.y);
+            load_row(pos, i0, i1, ap[0], ap[1]);
+            if (i1s >= 0) ap[1] = pos[i1s];
         }
         if (mn != 0.0f) {
-            float2 a = neg[px];
-            dw += mn * (2.0f * a.x * (tau - a.x) * a.y);
+            load_row(neg, i0, i1, an[0], an[1]);
+            if (i1s >= 0) an[1] = neg[i1s];
         }
-        dw *= kimg;
-        gy += dw * (sp.sy[k >> 1] * sp.wx[k & 1]);
-        gx += dw * (sp.wy[k >> 1] * sp.sx[k & 1]);
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+            if (!(cx ? vx1 : vx0)) continue;
+            float dw = 0.0f;
+            if (mp != 0.0f) dw += mp * (2.0f * ap[cx].x * (tau - ap[cx].x) * ap[cx].y);
+            if (mn != 0.0f) dw += mn * (2.0f * an[cx].x * (tau - an[cx].x) * an[cx].y);
+            dw *= kimg;
+            gy += dw * (sp.sy[r] * sp.wx[cx]);
+            gx += dw * (sp.wy[r] * sp.sx[cx]);
+        }
     }
     return make_float2(gy, gx);
 }
@@ -627,57 +680,76 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + sl;
     float c0y = 0.0f, c0x = 0.0f;
 
+    // Both sweeps keep the next trajectory position one iteration ahead (cur = p_k, nxt = the position the
+    // step into p_k was sampled at), so the IWE lookups at cur and the flow lookups at nxt of one iteration
+    // are all independent loads.
     float ay = 0.0f, ax = 0.0f;
-    for (int k = P; k > t; --k) {        // forward chain, newest first
-        if (k >= kf) {
+    {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = P .. t+1
+        int ks = min(P, kf - 1);
+        for (int k = P; k > ks; --k)
             if (k - 1 > t) { coy[(size_t)(k - 1) * M] = 0.0f; cox[(size_t)(k - 1) * M] = 0.0f; }
-            continue;
-        }
-        float2 pk = tr[(size_t)k * w.Mt];
-        float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, pk, ts, mp, mn);
-        ay += gk.x;
-        ax += gk.y;
-        if (k - 1 == t) {
-            float c = (float)(t + 1) - ts;
-            c0y += c * ay;
-            c0x += c * ax;
-        } else {
-            coy[(size_t)(k - 1) * M] = ay;
-            cox[(size_t)(k - 1) * M] = ax;
-            float2 q = tr[(size_t)(k - 1) * w.Mt];
-            Taps tp = make_taps(q.x, q.y, H, W);
-            float jyy, jyx, jxy, jxx;
-            quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp), tp, jyy, jyx, jxy, jxx);
-            float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
-            ay = ny;
-            ax = nx;
+        float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
+        if (ks > t) cur = tr[(size_t)ks * w.Mt];
+        if (ks - 1 > t) nxt = tr[(size_t)(ks - 1) * w.Mt];
+        for (int k = ks; k > t; --k) {
+            float2 nn = make_float2(0.0f, 0.0f);
+            if (k - 2 > t) nn = tr[(size_t)(k - 2) * w.Mt];
+            float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+            if (k - 1 > t) {
+                Taps tp = make_taps(nxt.x, nxt.y, H, W);
+                quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp), tp, jyy, jyx, jxy, jxx);
+            }
+            float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
+            ay += gk.x;
+            ax += gk.y;
+            if (k - 1 == t) {
+                float c = (float)(t + 1) - ts;
+                c0y += c * ay;
+                c0x += c * ax;
+            } else {
+                coy[(size_t)(k - 1) * M] = ay;
+                cox[(size_t)(k - 1) * M] = ax;
+                float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
+                ay = ny;
+                ax = nx;
+            }
+            cur = nxt;
+            nxt = nn;
         }
     }
     ay = 0.0f;
     ax = 0.0f;
-    for (int k = 0; k <= t; ++k) {       // backward chain, oldest first
-        if (k <= kb) {
+    {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = 0 .. t
+        int ks = max(0, kb + 1);
+        for (int k = 0; k < ks; ++k)
             if (k < t) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
-            continue;
-        }
-        float2 pk = tr[(size_t)k * w.Mt];
-        float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, pk, ts, mp, mn);
-        ay += gk.x;
-        ax += gk.y;
-        if (k == t) {
-            float c = (float)t - ts;
-            c0y += c * ay;
-            c0x += c * ax;
-        } else {
-            coy[(size_t)k * M] = -ay;
-            cox[(size_t)k * M] = -ax;
-            float2 q = tr[(size_t)(k + 1) * w.Mt];
-            Taps tp = make_taps(q.x, q.y, H, W);
-            float jyy, jyx, jxy, jxx;
-            quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp), tp, jyy, jyx, jxy, jxx);
-            float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
-            ay = ny;
-            ax = nx;
+        float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
+        if (ks <= t) cur = tr[(size_t)ks * w.Mt];
+        if (ks + 1 <= t) nxt = tr[(size_t)(ks + 1) * w.Mt];
+        for (int k = ks; k <= t; ++k) {
+            float2 nn = make_float2(0.0f, 0.0f);
+            if (k + 2 <= t) nn = tr[(size_t)(k + 2) * w.Mt];
+            float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+            if (k < t) {
+                Taps tp = make_taps(nxt.x, nxt.y, H, W);
+                quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp), tp, jyy, jyx, jxy, jxx);
+            }
+            float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
+            ay += gk.x;
+            ax += gk.y;
+            if (k == t) {
+                float c = (float)t - ts;
+                c0y += c * ay;
+                c0x += c * ax;
+            } else {
+                coy[(size_t)k * M] = -ay;
+                cox[(size_t)k * M] = -ax;
+                float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
+                ay = ny;
+                ax = nx;
+            }
+            cur = nxt;
+            nxt = nn;
         }
     }
     coy[(size_t)t * M] = c0y;
@@ -748,47 +820,53 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, M = w.M;
     int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
-    int npx = (r1 - r0) * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) lds_img[p] = 0.0;
+    const int WP = W + kRowPad;
+    int nlds = (r1 - r0) * WP;
+    for (int p = threadIdx.x; p < nlds; p += blockDim.x) lds_img[p] = 0.0;
     __syncthreads();
-
     const bool iter = (w.kind == TEF_KIND_ITERATIVE);
     const float *co = (comp ? cy : cx) + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
     const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
     const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
-    int s0 = iter ? 0 : w.off[k], s1 = iter ? M : w.off[k + 1];
     const int stride = blockDim.x;
-    for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
-        float cv[kUnroll];
-        float2 p[kUnroll];
+    // pass by pass: the position source (trajectory plane or original location) is uniform inside a pass
+    for (int t = iter ? 0 : k; t < (iter ? w.P : k + 1); ++t) {
+        const int s0 = w.off[t], s1 = w.off[t + 1];
+        const float2 *pl = tr + (size_t)(t < k ? k : k + 1) * w.Mt;
+        for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
+            float cv[kUnroll];
+            float2 p[kUnroll];
 #pragma unroll
-        for (int q = 0; q < kUnroll; ++q) {
-            int sl = sl0 + q * stride;
-            bool ok = sl < s1;
-            sl = ok ? sl : s0;
-            cv[q] = ok ? co[sl] : 0.0f;
-            int t = g.bin[sl];
-            // position this event had when it sampled map k
-            p[q] = (t == k) ? make_float2(ey[sl], ex[sl]) : tr[(size_t)(t < k ? k : k + 1) * w.Mt + sl];
-        }
+            for (int q = 0; q < kUnroll; ++q) {
+                int sl = sl0 + q * stride;
+                bool ok = sl < s1;
+                sl = ok ? sl : s0;
+                cv[q] = ok ? co[sl] : 0.0f;
+                // position this event had when it sampled map k
+                p[q] = (t == k) ? make_float2(ey[sl], ex[sl]) : pl[sl];
+            }
 #pragma unroll
-        for (int q = 0; q < kUnroll; ++q) {
-            if (cv[q] == 0.0f) continue;
-            Taps tp = make_taps(p[q].x, p[q].y, H, W);
-            const int idx[4] = {tp.i00, tp.i01, tp.i10, tp.i11};
-            const float wt[4] = {tp.s * tp.e, tp.s * tp.w, tp.n * tp.e, tp.n * tp.w};
+            for (int q = 0; q < kUnroll; ++q) {
+                if (cv[q] == 0.0f) continue;
+                Taps tp = make_taps(p[q].x, p[q].y, H, W);
+                const int idx[4] = {tp.i00, tp.i01, tp.i10, tp.i11};
+                const float wt[4] = {tp.s * tp.e, tp.s * tp.w, tp.n * tp.e, tp.n * tp.w};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (idx[c] < 0) continue;
-                int iy = idx[c] / W;
-                if (iy < r0 || iy >= r1) continue;
-                atomicAdd(lds_img + (idx[c] - r0 * W), (double)(cv[q] * wt[c]));
+                for (int c = 0; c < 4; ++c) {
+                    if (idx[c] < 0) continue;
+                    int iy = idx[c] / W;
+                    if (iy < r0 || iy >= r1) continue;
+                    atomicAdd(lds_img + (iy - r0) * WP + (idx[c] - iy * W), (double)(cv[q] * wt[c]));
+                }
             }
         }
     }
     __syncthreads();
     float *o = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2 + (comp ? 1 : 0)) * (size_t)(H * W) + (size_t)r0 * W;
-    for (int p = threadIdx.x; p < npx; p += blockDim.x) o[p] = (float)lds_img[p];
+    for (int p = threadIdx.x; p < (r1 - r0) * W; p += blockDim.x) {
+        int r = p / W;
+        o[p] = (float)lds_img[r * WP + (p - r * W)];
+    }
 }
 
 // K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473),
@@ -798,12 +876,13 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 // polarity-uniform (a splat workgroup skips the other polarity a wavefront at a time).
 // One workgroup per sample.  Order inside a (class, tile) bucket follows LDS-atomic arrival.
 constexpr int kPackThreads = 1024;
-constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters
+constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x tiles)
 
 __device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, int H, int W, int tile, int tw,
                                         int ntiles)
 {
-    int cls = (mp == 0.0f && mn == 0.0f) ? 2 : (mn != 0.0f ? 1 : 0);     // positives, negatives, padding
+    // pos-only, neg-only, both polarities (general masks), collate padding
+    int cls = (mp != 0.0f) ? (mn != 0.0f ? 2 : 0) : (mn != 0.0f ? 1 : 3);
     int ty = min(max((int)y, 0), H - 1) / tile, tx = min(max((int)x, 0), W - 1) / tile;
     return cls * ntiles + ty * tw + tx;
 }
@@ -814,10 +893,10 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
                                                                   int H, int W, int tile, float *__restrict__ ts,
                                                                   float *__restrict__ y, float *__restrict__ x,
                                                                   float *__restrict__ mp, float *__restrict__ mn,
-                                                                  uint8_t *__restrict__ bin)
+                                                                  uint8_t *__restrict__ bin, int *__restrict__ cls)
 {
     extern __shared__ int cnt[];          // [nbins] counters, then [kPackThreads] scan scratch
-    const int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile, ntiles = tw * th, nbins = 3 * ntiles;
+    const int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile, ntiles = tw * th, nbins = 4 * ntiles;
     int *part = cnt + nbins;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float4 *evb = reinterpret_cast<const float4 *>(ev) + (size_t)b * N;
@@ -848,6 +927,9 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
         cnt[k] = base;
         base += c;
     }
+    __syncthreads();
+    if (tid < 3)      // run ends of the three event classes of this pass (read by the splat workgroups)
+        cls[((size_t)b * TEF_MAX_PASSES + pass_idx) * 3 + tid] = cnt[(tid + 1) * ntiles];
     __syncthreads();
     for (int e = tid; e < N; e += kPackThreads) {
         float4 v = evb[e];
@@ -895,7 +977,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     if (c->B < 1 || c->H < 2 || c->W < 2 || c->F < 1) return tef::fail("bad B/H/W/F");
     if (c->P < 1 || c->P > TEF_MAX_PASSES) return tef::fail("passes_loss out of range [1, 64]");
     if (c->S < 1 || c->S > TEF_MAX_SCALES) return tef::fail("scales_loss out of range [1, 6]");
-    if ((size_t)c->W * sizeof(double) > kLdsBudget) return tef::fail("image row does not fit the LDS band");
+    if ((size_t)(c->W + kRowPad) * sizeof(double) > kLdsBudget) return tef::fail("image row does not fit the LDS band");
     if (c->kind == TEF_KIND_ITERATIVE) {
         // iterative_mode "four" raises TypeError in the reference itself (loss/flow.py:666-692); only one/two exist here
         if (c->mode_div != 1 && c->mode_div != 2) return tef::fail("iterative_mode must be 'one' or 'two'");
@@ -959,18 +1041,18 @@ Layout make_layout(const Win &w)
 inline Events to_events(const tef_events *e)
 {
     Events r;
-    if (e) { r.ts = e->ts; r.y = e->y; r.x = e->x; r.mp = e->mp; r.mn = e->mn; r.bin = e->bin; r.cap = e->cap; }
-    else { r.ts = r.y = r.x = r.mp = r.mn = nullptr; r.bin = nullptr; r.cap = 0; }
+    if (e) { r.ts = e->ts; r.y = e->y; r.x = e->x; r.mp = e->mp; r.mn = e->mn; r.bin = e->bin; r.cls = e->cls; r.cap = e->cap; }
+    else { r.ts = r.y = r.x = r.mp = r.mn = nullptr; r.bin = nullptr; r.cls = nullptr; r.cap = 0; }
     return r;
 }
 
 inline void band_geometry(const Win &w, int *rows_per_band, int *nbands, size_t *lds)
 {
-    int rows = (int)(kLdsBudget / ((size_t)w.W * sizeof(double)));
+    int rows = (int)(kLdsBudget / ((size_t)(w.W + kRowPad) * sizeof(double)));
     if (rows > w.H) rows = w.H;
     *rows_per_band = rows;
     *nbands = (w.H + rows - 1) / rows;
-    *lds = (size_t)rows * w.W * sizeof(double);
+    *lds = (size_t)rows * (w.W + kRowPad) * sizeof(double);
 }
 
 bool g_attr_done = false;
@@ -1001,20 +1083,20 @@ size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg)
 
 int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
                     int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
-                    uint8_t *bin, void *stream)
+                    uint8_t *bin, int *cls, void *stream)
 {
     if (B < 1 || N < 0 || slot0 < 0 || slot0 + N > cap || pass_idx < 0 || pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
         return tef::fail("tef_pack_events: bad sizes"), TEF_ERR_INVALID;
     if (N == 0) return 0;
     int tile = 8;
-    while (3 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;
-    int nbins = 3 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
+    while (4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;
+    int nbins = 4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     size_t lds = (size_t)(nbins + kPackThreads) * sizeof(int);
     hipStream_t st = (hipStream_t)stream;
     {
         tef::ProfScope ps(tef::PROF_PACK, st);
         hipLaunchKernelGGL(pack_events_kernel, dim3(B), dim3(kPackThreads), lds, st, ev, pm, N, ts_shift, ts_override,
-                           pass_idx, slot0, cap, H, W, tile, ts, y, x, mp, mn, bin);
+                           pass_idx, slot0, cap, H, W, tile, ts, y, x, mp, mn, bin, cls);
     }
     return tef::check_launch("pack_events_kernel");
 }

@@ -29,6 +29,8 @@ class _SoA:
         self.n = 0
         self.off = [0]
         self.ts = self.y = self.x = self.mp = self.mn = self.bin = None
+        # per (sample, pass): ends of the pos-only / neg-only / both-polarity runs (written by tef_pack_events)
+        self.cls = torch.zeros((B, _lib.TEF_MAX_PASSES, 3), dtype=torch.int32, device=device)
 
     def _grow(self, need):
         cap = max(need, 2 * self.cap, 1024)
@@ -61,7 +63,7 @@ class _SoA:
                 src.data_ptr(), pmc.data_ptr(), B, N, shift, ts_override, pass_idx, self.n, self.cap,
                 self.res[0], self.res[1],
                 self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(), self.mn.data_ptr(),
-                self.bin.data_ptr(), _lib.stream_ptr(),
+                self.bin.data_ptr(), self.cls.data_ptr(), _lib.stream_ptr(),
             )
             _lib.check(rc, "tef_pack_events")
         self.n += N
@@ -71,7 +73,7 @@ class _SoA:
         if self.cap == 0:
             self._grow(1)
         return _lib.Events(self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(),
-                           self.mn.data_ptr(), self.bin.data_ptr(), self.cap)
+                           self.mn.data_ptr(), self.bin.data_ptr(), self.cls.data_ptr(), self.cap)
 
 
 class _Window:
