@@ -122,6 +122,55 @@ int tef_smoothing_forward(const tef_loss_cfg *cfg, const float *flows, float spa
 int tef_smoothing_backward(const tef_loss_cfg *cfg, const float *flows, float spat_weight, float temp_weight,
                            void *scratch, const float *grad_out, float *dflows, void *stream);
 
+/* Input representations of dataloader/encodings.py, for one sample (B = 1, the reference's call shape) or a
+ * zero-padded batch.  Element e of sample b of each array sits at base[b * batch_stride + e * elem_stride]
+ * (SoA: elem_stride 1; the collated AoS list [B,N,4] = (ts,y,x,p): elem_stride 4 and xs = ev + 2, ys = ev + 1, ...).
+ *   TEF_ENCODE_IMAGE     events_to_image    encodings.py:8-29    out [B][1][H][W]        += p
+ *   TEF_ENCODE_CHANNELS  events_to_channels encodings.py:59-81   out [B][2][H][W]        per-polarity counts
+ *   TEF_ENCODE_VOXEL     events_to_voxel    encodings.py:32-56   out [B][channels][H][W] temporal bilinear, ts in [0,1]
+ * out is fully overwritten. */
+#define TEF_ENCODE_IMAGE 0
+#define TEF_ENCODE_CHANNELS 1
+#define TEF_ENCODE_VOXEL 2
+int tef_encode_events(const float *xs, const float *ys, const float *ts, const float *ps, int B, long batch_stride,
+                      int elem_stride, int N, int mode, int channels, int H, int W, float *out, void *stream);
+
+/* ---- RecEVFlowNet convolutions (models/submodules.py) -------------------------------------------------------
+ * One 3x3 / 1x1 convolution with padding ksize/2, stride 1 or 2, bias and a fused activation, on NCHW fp32 tensors.
+ * The input is the channel concatenation of up to two tensors, x0 [B,C0,H,W] and x1 [B,C1,H,W] (C1 may be 0), the
+ * second optionally multiplied element-wise by gate1 [B,C1,H,W]: this is exactly what ConvGRU feeds its gates,
+ * torch.cat([input_, prev_state]) and torch.cat([input_, prev_state * reset]) (submodules.py:146,149), without
+ * materialising the concatenation.  weight is the nn.Conv2d parameter [N, C0+C1, k, k], bias [N] (may be NULL).
+ * Replaces ConvLayer.forward :53-62, the three gate convolutions of ConvGRU.forward :134-152, ResidualBlock
+ * conv1/conv2 :207-227 and the conv of UpsampleConvLayer.forward :263-273, and autograd through them.
+ * Arithmetic: fp32 operands, fp32 accumulation on v_mfma_f32_32x32x2_f32. */
+#define TEF_ACT_NONE 0
+#define TEF_ACT_RELU 1
+#define TEF_ACT_TANH 2
+#define TEF_ACT_SIGMOID 3
+typedef struct tef_conv_desc {
+    int B, C0, C1, H, W;   /* input */
+    int N;                 /* output channels */
+    int ksize, stride;     /* 1 or 3; 1 or 2 */
+    int act;               /* TEF_ACT_* applied to conv + bias */
+} tef_conv_desc;
+
+size_t tef_conv_workspace_bytes(const tef_conv_desc *d);
+/* out [B,N,Ho,Wo] = act(conv(cat[x0, x1 * gate1], weight) + bias) */
+int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *weight,
+                     const float *bias, float *out, void *workspace, size_t workspace_bytes, void *stream);
+/* Given dout = d loss / d out (and out itself when act != NONE):
+ *   dx0 [B,C0,H,W], dx1 [B,C1,H,W] = gradient w.r.t. the concatenated conv input (dx1 is w.r.t. x1 * gate1; either may
+ *   be NULL to skip), overwritten;  dweight [N,C0+C1,k,k] and dbias [N] are ACCUMULATED into (+=), NULL to skip. */
+int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                      const float *weight, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
+                      float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+/* ConvGRU state update new_state = prev * (1 - update) + out_inputs * update (submodules.py:150) and its backward
+ * (dh = direct path only; the paths through the gates go through tef_conv_backward). n = element count. */
+int tef_gru_blend(const float *h, const float *u, const float *o, size_t n, float *out, void *stream);
+int tef_gru_blend_backward(const float *dhn, const float *h, const float *u, const float *o, size_t n, float *dh,
+                           float *du, float *dout, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

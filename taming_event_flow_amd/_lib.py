@@ -36,6 +36,14 @@ class LossCfg(ctypes.Structure):
     ]
 
 
+class ConvDesc(ctypes.Structure):
+    """struct tef_conv_desc (include/tef.h)"""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "C0", "C1", "H", "W", "N", "ksize", "stride", "act")]
+
+
+ACT = {None: 0, "relu": 1, "tanh": 2, "sigmoid": 3}
+
 # name -> (restype, argtypes); every symbol include/tef.h declares
 SIGNATURES = {
     "tef_version": (ctypes.c_int, []),
@@ -51,6 +59,15 @@ SIGNATURES = {
                                        _fp, _fp, _fp, _fp, _fp]),
     "tef_pack_flow": (ctypes.c_int, [_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
                                      _fp, _fp]),
+    "tef_encode_events": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    "tef_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "tef_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t,
+                                        _fp]),
+    "tef_conv_backward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                         ctypes.c_size_t, _fp]),
+    "tef_gru_blend": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_size_t, _fp, _fp]),
+    "tef_gru_blend_backward": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),
     "tef_loss_forward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.POINTER(Events), ctypes.POINTER(Events),
                                         _fp, ctypes.c_size_t, _fp, _fp]),

@@ -1,0 +1,98 @@
+// tef_encode.hip — event-count / voxel-grid input representations (dataloader/encodings.py).
+//   events_to_image    :8-29   img[y, x] += p                         (index_put_, accumulate=True)
+//   events_to_channels :59-81  per-polarity counts (both positive)      -> [2, H, W]
+//   events_to_voxel    :32-56  temporal-bilinear voxel grid (signed)    -> [bins, H, W]
+// One workgroup per (sample, output channel[, row band]) keeps its channel in LDS as fp64 (ds_add_f64, the fast
+// LDS float atomic on gfx950) and streams the event list once; counts are exact, voxel sums are independent of
+// the event order to far below fp32 resolution.  Works on one sample (the reference's call shape) or on a
+// zero-padded batch [B, N, 4] straight from the collate (the batched form the DP loop uses).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tef.h"
+#include "tef_common.h"
+
+namespace {
+
+constexpr size_t kLdsBudget = 144 * 1024;
+constexpr int kThreads = 1024;
+
+// xs/ys/ts/ps: element e of sample b at base[b * bs + e * es]
+__global__ __launch_bounds__(kThreads) void encode_kernel(const float *__restrict__ xs, const float *__restrict__ ys,
+                                                          const float *__restrict__ ts, const float *__restrict__ ps,
+                                                          long bs, int es, int N, int mode, int C, int H, int W,
+                                                          int rows_per_band, int nbands, float *__restrict__ out)
+{
+    extern __shared__ double img[];
+    int bid = blockIdx.x;
+    int band = bid % nbands;
+    bid /= nbands;
+    int c = bid % C, b = bid / C;
+    int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
+    int npx = (r1 - r0) * W;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = 0.0;
+    __syncthreads();
+    const float *bx = xs + (size_t)b * bs, *by = ys + (size_t)b * bs, *bp = ps + (size_t)b * bs;
+    const float *bt = ts ? ts + (size_t)b * bs : nullptr;
+    for (int e = threadIdx.x; e < N; e += blockDim.x) {
+        float p = bp[(size_t)e * es];
+        float v;
+        if (mode == TEF_ENCODE_IMAGE) {
+            v = p;
+        } else if (mode == TEF_ENCODE_CHANNELS) {
+            // mask_pos = {p<0: 0, p>0: 1, else p}; mask_neg = {p>0: 0, p<0: -1, else p}   (encodings.py:72-80)
+            float mpos = p > 0.0f ? 1.0f : (p < 0.0f ? 0.0f : p);
+            float mneg = p < 0.0f ? -1.0f : (p > 0.0f ? 0.0f : p);
+            v = p * (c == 0 ? mpos : mneg);
+        } else {
+            float t = bt[(size_t)e * es] * (float)(C - 1);            // encodings.py:47
+            v = p * fmaxf(0.0f, 1.0f - fabsf(t - (float)c));          // :52
+        }
+        if (v == 0.0f) continue;
+        int iy = (int)by[(size_t)e * es], ix = (int)bx[(size_t)e * es];   // .long() truncation (:24-27)
+        if (iy < 0) iy += H;                                             // python-style negative index
+        if (ix < 0) ix += W;
+        if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
+        atomicAdd(img + (iy - r0) * W + ix, (double)v);
+    }
+    __syncthreads();
+    float *o = out + ((size_t)b * C + c) * (size_t)(H * W) + (size_t)r0 * W;
+    for (int p = threadIdx.x; p < npx; p += blockDim.x) o[p] = (float)img[p];
+}
+
+bool g_attr_done = false;
+
+}  // namespace
+
+extern "C" int tef_encode_events(const float *xs, const float *ys, const float *ts, const float *ps, int B,
+                                 long batch_stride, int elem_stride, int N, int mode, int channels, int H, int W,
+                                 float *out, void *stream)
+{
+    if ((N > 0 && (!xs || !ys || !ps)) || !out || B < 1 || N < 0 || H < 1 || W < 1 || elem_stride < 1)
+        return tef::fail("tef_encode_events: bad arguments"), TEF_ERR_INVALID;
+    int C;
+    if (mode == TEF_ENCODE_IMAGE) C = 1;
+    else if (mode == TEF_ENCODE_CHANNELS) C = 2;
+    else if (mode == TEF_ENCODE_VOXEL) {
+        C = channels;
+        if ((N > 0 && !ts) || C < 1) return tef::fail("tef_encode_events: voxel needs ts and bins >= 1"), TEF_ERR_INVALID;
+    } else return tef::fail("tef_encode_events: unknown mode"), TEF_ERR_INVALID;
+    if ((size_t)W * sizeof(double) > kLdsBudget) return tef::fail("tef_encode_events: row too wide"), TEF_ERR_INVALID;
+    if (!g_attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void *)encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)kLdsBudget);
+        if (e != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e), TEF_ERR_LAUNCH;
+        g_attr_done = true;
+    }
+    int rows = (int)(kLdsBudget / ((size_t)W * sizeof(double)));
+    if (rows > H) rows = H;
+    int nbands = (H + rows - 1) / rows;
+    size_t lds = (size_t)rows * W * sizeof(double);
+    hipStream_t st = (hipStream_t)stream;
+    {
+        tef::ProfScope ps_(tef::PROF_ENCODE, st);
+        hipLaunchKernelGGL(encode_kernel, dim3((unsigned)(B * C * nbands)), dim3(kThreads), lds, st, xs, ys, ts, ps,
+                           batch_stride, elem_stride, N, mode, C, H, W, rows, nbands, out);
+    }
+    return tef::check_launch("encode_kernel");
+}

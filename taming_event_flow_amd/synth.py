@@ -102,3 +102,18 @@ def make_window(rng, B, H, W, P, F, n_grad, n_det=0, sigma=2.0, kind="smooth", r
         out["dev"].append(e)
         out["dpm"].append(m)
     return out
+
+
+def make_model_weights(shapes, seed):
+    """Deterministic (numpy PCG64) parameter values for a list of (name, shape): weights ~ N(0, 1/fan_in),
+    biases ~ N(0, 0.05^2).  Used instead of storing 31 M parameters in the golden fixtures."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, shape in shapes:
+        shape = tuple(int(s) for s in shape)
+        if len(shape) == 1:
+            out[name] = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            out[name] = (rng.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+    return out

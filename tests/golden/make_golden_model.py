@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Golden vectors for the network rows (models/*.py), recorded by RUNNING the reference (build container only).
+
+Weights are NOT stored (31 M parameters): they are regenerated from a numpy seed by
+taming_event_flow_amd.synth.make_model_weights; the fixtures hold inputs, outputs and gradient digests.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from taming_event_flow_amd import synth  # noqa: E402
+
+# the reference's `models` package must win over ours on the path
+sys.path.insert(0, "/root/reference")
+from models.model import RecEVFlowNet  # noqa: E402  (reference)
+from models.submodules import ConvGRU, ConvLayer, ResidualBlock, UpsampleConvLayer  # noqa: E402  (reference)
+
+torch.set_num_threads(4)
+
+
+def load_weights(module, seed):
+    sd = module.state_dict()
+    w = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], seed)
+    module.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+
+
+def grad_digest(module):
+    """Per-parameter (L2 norm, first 32 values) of .grad, in state_dict order."""
+    norms, heads = [], []
+    for _, p in module.named_parameters():
+        g = p.grad.detach().numpy().ravel()
+        norms.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        h = np.zeros(32, np.float32)
+        h[: min(32, g.size)] = g[:32]
+        heads.append(h)
+    return np.array(norms, np.float64), np.stack(heads)
+
+
+def save_layers(seed=31):
+    rng = np.random.default_rng(seed)
+    out = {}
+    # ConvLayer 3x3 stride 2 relu, and 1x1 tanh
+    for tag, (cin, cout, k, s, act) in {"conv_s2": (5, 12, 3, 2, "relu"), "conv_1x1": (7, 2, 1, 1, "tanh"),
+                                        "conv_s1": (6, 40, 3, 1, None)}.items():
+        layer = ConvLayer(cin, cout, k, s, act)
+        load_weights(layer, seed + len(tag))
+        x = torch.tensor(rng.standard_normal((2, cin, 14, 18)).astype(np.float32), requires_grad=True)
+        y = layer(x)
+        r = torch.tensor(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+        (y * r).sum().backward()
+        out.update({f"{tag}_x": x.detach().numpy(), f"{tag}_y": y.detach().numpy(), f"{tag}_r": r.numpy(),
+                    f"{tag}_dx": x.grad.numpy(), f"{tag}_dw": layer.conv2d.weight.grad.numpy(),
+                    f"{tag}_db": layer.conv2d.bias.grad.numpy(), f"{tag}_seed": seed + len(tag)})
+    # ConvGRU cell, two steps (state carried)
+    C = 8
+    gru = ConvGRU(C, C, 3)
+    load_weights(gru, seed + 100)
+    x1 = torch.tensor(rng.standard_normal((2, C, 10, 12)).astype(np.float32), requires_grad=True)
+    x2 = torch.tensor(rng.standard_normal((2, C, 10, 12)).astype(np.float32), requires_grad=True)
+    h1, _ = gru(x1, None)
+    h2, _ = gru(x2, h1)
+    r = torch.tensor(rng.standard_normal(tuple(h2.shape)).astype(np.float32))
+    (h2 * r).sum().backward()
+    norms, heads = grad_digest(gru)
+    out.update(gru_x1=x1.detach().numpy(), gru_x2=x2.detach().numpy(), gru_h1=h1.detach().numpy(),
+               gru_h2=h2.detach().numpy(), gru_r=r.numpy(), gru_dx1=x1.grad.numpy(), gru_dx2=x2.grad.numpy(),
+               gru_gnorm=norms, gru_ghead=heads, gru_seed=seed + 100)
+    # ResidualBlock and UpsampleConvLayer
+    rb = ResidualBlock(6, 6)
+    load_weights(rb, seed + 200)
+    x = torch.tensor(rng.standard_normal((2, 6, 9, 11)).astype(np.float32), requires_grad=True)
+    y2, y1 = rb(x)
+    r = torch.tensor(rng.standard_normal(tuple(y2.shape)).astype(np.float32))
+    (y2 * r).sum().backward()
+    norms, heads = grad_digest(rb)
+    out.update(rb_x=x.detach().numpy(), rb_y2=y2.detach().numpy(), rb_y1=y1.detach().numpy(), rb_r=r.numpy(),
+               rb_dx=x.grad.numpy(), rb_gnorm=norms, rb_ghead=heads, rb_seed=seed + 200)
+    up = UpsampleConvLayer(5, 7, 3)
+    load_weights(up, seed + 300)
+    x = torch.tensor(rng.standard_normal((2, 5, 6, 7)).astype(np.float32), requires_grad=True)
+    y = up(x)
+    r = torch.tensor(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * r).sum().backward()
+    norms, heads = grad_digest(up)
+    out.update(up_x=x.detach().numpy(), up_y=y.detach().numpy(), up_r=r.numpy(), up_dx=x.grad.numpy(),
+               up_gnorm=norms, up_ghead=heads, up_seed=seed + 300)
+    np.savez_compressed(os.path.join(HERE, "model_layers.npz"), **out)
+    print("model_layers saved")
+
+
+def save_net(name, H, W, B, passes, seed):
+    rng = np.random.default_rng(seed)
+    net = RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2)
+    load_weights(net, seed)
+    net.train()
+    xs = [torch.tensor(rng.poisson(0.3, (B, 2, H, W)).astype(np.float32)) for _ in range(passes)]
+    rs = [[rng.standard_normal((B, 2, H, W)).astype(np.float32) for _ in range(4)] for _ in range(passes)]
+    out = {"H": H, "W": W, "B": B, "passes": passes, "seed": seed}
+    loss = 0
+    for t in range(passes):
+        flows = net(xs[t])["flow"]
+        for i, fl in enumerate(flows):
+            out[f"flow{t}_{i}"] = fl.detach().numpy()
+            out[f"r{t}_{i}"] = rs[t][i]
+            loss = loss + (fl * torch.tensor(rs[t][i])).sum()
+        out[f"x{t}"] = xs[t].numpy()
+    loss.backward()
+    norms, heads = grad_digest(net)
+    out.update(loss=np.float32(loss.item()), gnorm=norms, ghead=heads)
+    for li, st in enumerate(net.states):
+        out[f"state{li}"] = st.detach().numpy()
+    out["keys"] = np.array([k for k, _ in net.named_parameters()])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "loss", float(loss.item()), "gnorm total", float(np.sqrt((norms ** 2).sum())))
+
+
+if __name__ == "__main__":
+    save_layers()
+    save_net("model_32x32", 32, 32, 1, 2, seed=41)
+    save_net("model_40x52_pad", 40, 52, 2, 2, seed=42)

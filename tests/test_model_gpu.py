@@ -1,0 +1,134 @@
+"""GPU parity of the network rows (models/*.py on the MFMA conv kernels) vs golden vectors recorded from the
+reference's nn.Conv2d implementation (tests/golden/make_golden_model.py).  Tolerance 1e-4 relative (max-norm)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+
+    g.build()
+    return torch.device("cuda:0")
+
+
+def load_weights(module, seed, dev):
+    from taming_event_flow_amd import synth
+
+    sd = module.state_dict()
+    w = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], seed)
+    module.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    return module.to(dev)
+
+
+def digest(module):
+    norms, heads = [], []
+    for _, p in module.named_parameters():
+        g = p.grad.detach().cpu().numpy().ravel()
+        norms.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        h = np.zeros(32, np.float32)
+        h[: min(32, g.size)] = g[:32]
+        heads.append(h)
+    return np.array(norms), np.stack(heads)
+
+
+def check_digest(module, gnorm, ghead, tol=TOL):
+    norms, heads = digest(module)
+    assert np.abs(norms - gnorm).max() <= tol * gnorm.max()
+    for i in range(len(norms)):
+        assert abs(norms[i] - gnorm[i]) <= 10 * tol * max(gnorm[i], 1e-12), i
+        assert np.abs(heads[i] - ghead[i]).max() <= 10 * tol * max(np.abs(ghead[i]).max(), 1e-3 * gnorm[i]), i
+
+
+def test_conv_layers(dev):
+    from taming_event_flow_amd.models.submodules import ConvLayer
+
+    z = np.load(os.path.join(GOLDEN, "model_layers.npz"))
+    for tag, (cin, cout, k, s, act) in {"conv_s2": (5, 12, 3, 2, "relu"), "conv_1x1": (7, 2, 1, 1, "tanh"),
+                                        "conv_s1": (6, 40, 3, 1, None)}.items():
+        layer = load_weights(ConvLayer(cin, cout, k, s, act), int(z[f"{tag}_seed"]), dev)
+        x = torch.tensor(z[f"{tag}_x"], device=dev, requires_grad=True)
+        y = layer(x)
+        assert rel_err(y.detach().cpu().numpy(), z[f"{tag}_y"]) <= TOL, tag
+        (y * torch.tensor(z[f"{tag}_r"], device=dev)).sum().backward()
+        assert rel_err(x.grad.cpu().numpy(), z[f"{tag}_dx"]) <= TOL, tag
+        assert rel_err(layer.conv2d.weight.grad.cpu().numpy(), z[f"{tag}_dw"]) <= TOL, tag
+        assert rel_err(layer.conv2d.bias.grad.cpu().numpy(), z[f"{tag}_db"]) <= TOL, tag
+
+
+def test_convgru_two_steps(dev):
+    from taming_event_flow_amd.models.submodules import ConvGRU
+
+    z = np.load(os.path.join(GOLDEN, "model_layers.npz"))
+    gru = load_weights(ConvGRU(8, 8, 3), int(z["gru_seed"]), dev)
+    x1 = torch.tensor(z["gru_x1"], device=dev, requires_grad=True)
+    x2 = torch.tensor(z["gru_x2"], device=dev, requires_grad=True)
+    h1, _ = gru(x1, None)
+    h2, s2 = gru(x2, h1)
+    assert s2 is h2
+    assert rel_err(h1.detach().cpu().numpy(), z["gru_h1"]) <= TOL
+    assert rel_err(h2.detach().cpu().numpy(), z["gru_h2"]) <= TOL
+    (h2 * torch.tensor(z["gru_r"], device=dev)).sum().backward()
+    assert rel_err(x1.grad.cpu().numpy(), z["gru_dx1"]) <= TOL
+    assert rel_err(x2.grad.cpu().numpy(), z["gru_dx2"]) <= TOL
+    check_digest(gru, z["gru_gnorm"], z["gru_ghead"])
+
+
+def test_resblock_and_upsample(dev):
+    from taming_event_flow_amd.models.submodules import ResidualBlock, UpsampleConvLayer
+
+    z = np.load(os.path.join(GOLDEN, "model_layers.npz"))
+    rb = load_weights(ResidualBlock(6, 6), int(z["rb_seed"]), dev)
+    x = torch.tensor(z["rb_x"], device=dev, requires_grad=True)
+    y2, y1 = rb(x)
+    assert rel_err(y2.detach().cpu().numpy(), z["rb_y2"]) <= TOL
+    assert rel_err(y1.detach().cpu().numpy(), z["rb_y1"]) <= TOL
+    (y2 * torch.tensor(z["rb_r"], device=dev)).sum().backward()
+    assert rel_err(x.grad.cpu().numpy(), z["rb_dx"]) <= TOL
+    check_digest(rb, z["rb_gnorm"], z["rb_ghead"])
+    up = load_weights(UpsampleConvLayer(5, 7, 3), int(z["up_seed"]), dev)
+    x = torch.tensor(z["up_x"], device=dev, requires_grad=True)
+    y = up(x)
+    assert rel_err(y.detach().cpu().numpy(), z["up_y"]) <= TOL
+    (y * torch.tensor(z["up_r"], device=dev)).sum().backward()
+    assert rel_err(x.grad.cpu().numpy(), z["up_dx"]) <= TOL
+    check_digest(up, z["up_gnorm"], z["up_ghead"])
+
+
+@pytest.mark.parametrize("name", ["model_32x32", "model_40x52_pad"])
+def test_recevflownet(name, dev):
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    net = load_weights(RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2), int(z["seed"]), dev)
+    net.train()
+    assert [k for k, _ in net.named_parameters()] == list(z["keys"])
+    passes = int(z["passes"])
+    loss = 0
+    for t in range(passes):
+        flows = net(torch.tensor(z[f"x{t}"], device=dev))["flow"]
+        assert len(flows) == 4
+        for i, fl in enumerate(flows):
+            ref = z[f"flow{t}_{i}"]
+            assert tuple(fl.shape) == ref.shape
+            assert rel_err(fl.detach().cpu().numpy(), ref) <= TOL, (t, i)
+            loss = loss + (fl * torch.tensor(z[f"r{t}_{i}"], device=dev)).sum()
+    assert abs(loss.item() - float(z["loss"])) <= 1e-3 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    for li, st in enumerate(net.states):
+        assert rel_err(st.detach().cpu().numpy(), z[f"state{li}"]) <= TOL
+    check_digest(net, z["gnorm"], z["ghead"])
+    # state API of the reference (models/model.py:42-63)
+    net.detach_states()
+    assert all(not s.requires_grad for s in net.arch.states)
+    net.reset_states()
+    assert net.arch.states == [None] * 4
