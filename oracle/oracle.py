@@ -31,10 +31,18 @@ class _Window(ctypes.Structure):
 
 def build(force=False):
     """Compile the C restatement (gcc only; building the checker is not using it)."""
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+    import hashlib
+
+    with open(_SRC, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()
+    stamp = _LIB + ".srchash"      # content hash, not mtime: mtimes do not survive the copy to the GPU box
+    fresh = os.path.exists(_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest
+    if force or not fresh:
         subprocess.check_call(
             ["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC, "-lm"]
         )
+        with open(stamp, "w") as f:
+            f.write(digest)
     return _LIB
 
 

@@ -21,12 +21,27 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+STAMP = LIB + ".srchash"
+
+
+def source_hash():
+    """Content hash of everything the library is built from (mtimes do not survive the copy to the GPU box)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for p in deps:
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
-    return any(os.path.getmtime(p) > t for p in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_hip(force=False, verbose=False):
@@ -46,6 +61,8 @@ def build_hip(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash())
     return LIB
 
 

@@ -1,0 +1,66 @@
+"""Data-parallel plumbing for the training loop (new functionality: the reference is single-process).
+
+One process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+The loss is a SUM over batch samples (reference loss/flow.py:129), so the single-process gradient of a global
+batch equals the SUM of the per-rank gradients: one all-reduce(SUM) of a flat fp32 gradient bucket per loss
+window, BEFORE clipping (the reference clips the global norm, train_flow.py:127-128).  The reference resets loss /
+state / gradients for the whole batch when ANY slot starts a new sequence (train_flow.py:83-87); ranks therefore
+agree on that flag with an all-reduce(MAX) so that their collectives stay matched.
+"""
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class FlatGradBucket:
+    """All parameter gradients as views of ONE contiguous buffer: zeroing is a single fill, the DP reduction a
+    single collective (125.5 MB for RecEVFlowNet: per-link bound on xGMI, so one large message, not many small)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        p0 = self.params[0]
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
+        o = 0
+        for p in self.params:
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_sum(self):
+        """SUM over ranks (not mean): reproduces the gradient of the global batch exactly."""
+        if is_distributed():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        return self.flat
+
+    def clip_(self, max_norm):
+        """Global-norm clipping on the (already reduced) flat buffer = clip_grad_norm_ (train_flow.py:127-128)."""
+        norm = torch.linalg.vector_norm(self.flat)
+        scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        self.flat.mul_(scale)
+        return norm
+
+
+def any_rank(flag, device):
+    """True on every rank if `flag` is True on at least one (lock-step `new_seq`)."""
+    if not is_distributed():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item())
+
+
+def shard_range(global_batch, rank, world):
+    """Batch slots [lo, hi) owned by `rank` (rank g owns slots [g*b, (g+1)*b))."""
+    if global_batch % world:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    b = global_batch // world
+    return rank * b, (rank + 1) * b

@@ -1,0 +1,105 @@
+"""Training-loop counterpart of the reference's ``train_flow.py`` (:80-156) on the MI355X path.
+
+Reproduces the reference's window semantics — reset on ``new_seq`` (any slot, all ranks), forward, ``x * flow_scaling``,
+``loss.update``; every ``passes_loss`` passes: loss, backward, [DP all-reduce SUM], clip_grad_norm_(clip_grad),
+Adam step, zero_grad, ``detach_states``, ``loss.reset`` — with a synthetic DSEC-shaped batch source instead of the
+HDF5 loader (dataloader/h5.py needs h5py/cv2 and a dataset; out of scope).
+"""
+
+import numpy as np
+import torch
+
+from . import parallel, synth
+from .dataloader import encodings
+from .loss.flow import Iterative, Linear  # noqa: F401  (selected by name like the reference's eval(...))
+from .models.model import RecEVFlowNet  # noqa: F401
+
+DEFAULT_CONFIG = {     # reference configs/train_flow.yml
+    "data": {"passes_loss": 10, "scales_loss": 1, "voxel": None},
+    "model": {"name": "RecEVFlowNet", "final_w_scale": 0.01},
+    "loss": {"warping": "Iterative", "iterative_mode": "two", "round_ts": False, "flow_scaling": 32,
+             "flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "clip_grad": 100.0},
+    "optimizer": {"name": "Adam", "lr": 0.00001},
+    "loader": {"batch_size": 8, "resolution": [128, 128], "max_num_grad_events": 10000, "seed": 0},
+}
+
+
+class SyntheticSequences:
+    """Batch source with the reference loader's batch dict (dataloader/h5.py:413-431 + base.py:392-434 collate):
+    net_input [B,2|bins,H,W], event_list [B,N,4] (ts,y,x,p), event_list_pol_mask [B,N,2], d_event_list,
+    d_event_list_pol_mask; `new_seq` raised every `seq_len` passes.  Events are split into a gradient list of at
+    most `max_num_grad_events` and a detached list (base.py:348-377).  All tensors live on `device`; the input
+    representation is built there by the batched HIP encoder."""
+
+    def __init__(self, config, device, events_per_pass, seq_len=200, pool=4, seed=0):
+        self.cfg, self.device = config, device
+        self.B = config["loader"]["batch_size"]
+        self.H, self.W = config["loader"]["resolution"]
+        self.seq_len, self.t = seq_len, 0
+        self.new_seq = True
+        rng = np.random.default_rng(seed)
+        ng = min(events_per_pass, config["loader"]["max_num_grad_events"] or events_per_pass)
+        nd = events_per_pass - ng
+        self.pool = []
+        for _ in range(pool):       # a small pool of pre-generated passes, cycled (host RNG is not the subject here)
+            ev, pm = synth.make_event_pass(rng, self.B, ng, self.H, self.W)
+            dev_, dpm = synth.make_event_pass(rng, self.B, nd, self.H, self.W)
+            self.pool.append(tuple(torch.tensor(a, device=device) for a in (ev, pm, dev_, dpm)))
+
+    def next(self):
+        ev, pm, dev_, dpm = (a.clone() for a in self.pool[self.t % len(self.pool)])   # update() shifts ts in place
+        allev = torch.cat([ev, dev_], dim=1) if dev_.shape[1] else ev
+        bins = self.cfg["data"]["voxel"]
+        if bins is None:
+            net_input = encodings.event_list_to_channels(allev, (self.H, self.W))
+        else:
+            net_input = encodings.event_list_to_voxel(allev, bins, (self.H, self.W))
+        self.new_seq = self.t % self.seq_len == 0
+        self.t += 1
+        return {"net_input": net_input, "event_list": ev, "event_list_pol_mask": pm, "d_event_list": dev_,
+                "d_event_list_pol_mask": dpm}
+
+
+class Trainer:
+    """model + loss + optimiser wired like reference train_flow.py:60-70, plus the DP gradient bucket."""
+
+    def __init__(self, config, device):
+        self.cfg, self.device = config, device
+        num_bins = 2 if config["data"]["voxel"] is None else config["data"]["voxel"]
+        self.model = eval(config["model"]["name"])(config["model"].copy(), num_bins, key="flow").to(device)
+        self.model.train()
+        self.loss_function = eval(config["loss"]["warping"])(config, device)
+        self.bucket = parallel.FlatGradBucket(self.model.parameters())
+        self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(),
+                                                                           lr=config["optimizer"]["lr"])
+        self.last_loss = None
+        self.last_grad_norm = None
+
+    def reset(self):
+        """train_flow.py:83-87"""
+        self.loss_function.reset()
+        self.model.reset_states()
+        self.bucket.zero()
+
+    def step(self, inputs, new_seq=False):
+        """One pass (train_flow.py:83-137).  Returns True when an optimiser step happened."""
+        cfg = self.cfg
+        if parallel.any_rank(new_seq, self.device):
+            self.reset()
+        x = self.model(inputs["net_input"])
+        flows = [f * cfg["loss"]["flow_scaling"] for f in x["flow"]]
+        self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
+                                  inputs["d_event_list_pol_mask"])
+        if self.loss_function.num_passes < cfg["data"]["passes_loss"]:
+            return False
+        loss = self.loss_function()
+        loss.backward()
+        self.bucket.all_reduce_sum()                    # DP: gradient of the global batch (sum of shards)
+        if cfg["loss"]["clip_grad"] is not None:
+            self.last_grad_norm = self.bucket.clip_(cfg["loss"]["clip_grad"])
+        self.optimizer.step()
+        self.bucket.zero()                              # optimizer.zero_grad() keeping the flat views
+        self.model.detach_states()
+        self.loss_function.reset()
+        self.last_loss = loss.detach()
+        return True

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Golden trace of the reference's training-window semantics (train_flow.py:80-156) — build container only.
+
+Drives the reference's RecEVFlowNet + Iterative loss + Adam exactly like train_flow.py does for 2 consecutive
+loss windows (state carried and detached, loss reset), and records loss, pre-clip gradient norm and per-parameter
+update norms.  The reference's train_flow.py itself cannot be imported (mlflow / h5py missing), so its loop body is
+replayed call by call here; every call goes into reference code.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from taming_event_flow_amd import synth  # noqa: E402
+
+sys.path.insert(0, "/root/reference")
+import warnings  # noqa: E402
+
+warnings.filterwarnings("ignore")
+from dataloader.encodings import events_to_channels  # noqa: E402
+from loss.flow import Iterative  # noqa: E402
+from models.model import RecEVFlowNet  # noqa: E402
+
+torch.set_num_threads(4)
+
+H, W, B, P, N, ND, SEED, LR, CLIP, WINDOWS = 32, 32, 2, 3, 300, 80, 51, 1e-3, 5.0, 2
+config = {
+    "loader": {"resolution": [H, W], "batch_size": B},
+    "loss": {"flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "round_ts": False,
+             "iterative_mode": "two", "flow_scaling": 32, "clip_grad": CLIP},
+    "data": {"passes_loss": P, "scales_loss": 1},
+}
+rng = np.random.default_rng(SEED)
+model = RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2)
+sd = model.state_dict()
+wts = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], SEED)
+model.load_state_dict({k: torch.tensor(v) for k, v in wts.items()})
+model.train()
+loss_function = Iterative(config, torch.device("cpu"))
+optimizer = torch.optim.Adam(model.parameters(), lr=LR)
+optimizer.zero_grad()
+out = dict(H=H, W=W, B=B, P=P, N=N, ND=ND, seed=SEED, lr=LR, clip=CLIP, windows=WINDOWS)
+loss_function.reset()
+model.reset_states()
+for w in range(WINDOWS):
+    before = [p.detach().clone() for p in model.parameters()]
+    for t in range(P):
+        ev, pm = synth.make_event_pass(rng, B, N, H, W)
+        dev, dpm = synth.make_event_pass(rng, B, ND, H, W)
+        out[f"ev{w}_{t}"], out[f"pm{w}_{t}"], out[f"dev{w}_{t}"], out[f"dpm{w}_{t}"] = ev, pm, dev, dpm
+        allev = np.concatenate([ev, dev], 1)
+        net_input = torch.stack([
+            events_to_channels(torch.tensor(allev[b, :, 2]), torch.tensor(allev[b, :, 1]), torch.tensor(allev[b, :, 3]),
+                               sensor_size=(H, W)) for b in range(B)])
+        out[f"inp{w}_{t}"] = net_input.numpy()
+        x = model(net_input)
+        for i in range(len(x["flow"])):
+            x["flow"][i] = x["flow"][i] * config["loss"]["flow_scaling"]
+        loss_function.update(x["flow"], torch.tensor(ev), torch.tensor(pm), torch.tensor(dev), torch.tensor(dpm))
+    loss = loss_function()
+    loss.backward()
+    gn = torch.nn.utils.clip_grad.clip_grad_norm_(model.parameters(), CLIP)
+    optimizer.step()
+    optimizer.zero_grad()
+    model.detach_states()
+    loss_function.reset()
+    delta = np.array([float((p.detach() - b0).double().norm()) for p, b0 in zip(model.parameters(), before)])
+    out[f"loss{w}"] = np.float32(loss.item())
+    out[f"gnorm{w}"] = np.float32(float(gn))
+    out[f"delta{w}"] = delta
+    print(f"window {w}: loss {loss.item():.6f} grad-norm {float(gn):.5f} |dW| {np.sqrt((delta**2).sum()):.5f}")
+np.savez_compressed(os.path.join(HERE, "train_trace.npz"), **out)

@@ -1,0 +1,89 @@
+"""World-size-2 gloo tests (CPU) of the DP plumbing: flat gradient bucket, all-reduce SUM == gradient of the
+global batch for a loss that is a sum over samples, clip-after-reduce, lock-step new_seq flag."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+
+
+def _loss(model, x):
+    return (model(x) ** 2).sum()        # a SUM over batch samples, like the CM loss (reference loss/flow.py:129)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from taming_event_flow_amd import parallel
+
+    torch.manual_seed(123)
+    xg = torch.randn(8, 6)
+    lo, hi = parallel.shard_range(8, rank, world)
+    model = _model()
+    bucket = parallel.FlatGradBucket(model.parameters())
+    _loss(model, xg[lo:hi]).backward()
+    local = bucket.flat.clone()
+    bucket.all_reduce_sum()
+    reduced = bucket.flat.clone()
+    norm = bucket.clip_(0.5)
+    flag = parallel.any_rank(rank == 1, torch.device("cpu"))
+    noflag = parallel.any_rank(False, torch.device("cpu"))
+    q.put((rank, local.numpy(), reduced.numpy(), float(norm), bucket.flat.clone().numpy(), flag, noflag))
+    dist.destroy_process_group()
+
+
+def test_dp_sum_equals_global_batch_gradient():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on the full batch
+    torch.manual_seed(123)
+    xg = torch.randn(8, 6)
+    model = _model()
+    _loss(model, xg).backward()
+    full = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    for rank, local, reduced, norm, clipped, flag, noflag in res:
+        np.testing.assert_allclose(reduced, full, rtol=1e-5, atol=1e-6)          # SUM of shards == global gradient
+        assert abs(norm - np.linalg.norm(full)) <= 1e-4 * np.linalg.norm(full)   # clip sees the GLOBAL norm
+        np.testing.assert_allclose(np.linalg.norm(clipped), min(0.5, np.linalg.norm(full)), rtol=1e-4)
+        assert flag is True and noflag is False                                   # lock-step new_seq
+    np.testing.assert_allclose(res[0][1] + res[1][1], full, rtol=1e-5, atol=1e-6)
+    assert not np.allclose(res[0][1], res[1][1])
+
+
+def test_bucket_views_and_zero():
+    from taming_event_flow_amd import parallel
+
+    model = _model()
+    bucket = parallel.FlatGradBucket(model.parameters())
+    _loss(model, torch.randn(4, 6)).backward()
+    assert bucket.flat.abs().sum() > 0
+    for p in model.parameters():
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr()
+        assert p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.flat.numel() * 4
+    bucket.zero()
+    assert all(float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
+    assert parallel.shard_range(64, 3, 8) == (24, 32)
