@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--res", type=int, nargs=2, default=[128, 128])
     ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
     ap.add_argument("--warping", default="Iterative", choices=["Iterative", "Linear"])
+    ap.add_argument("--mode", default="loss", choices=["loss", "train"],
+                    help="loss: IWE + contrast-max loss fwd+bwd (BASELINE.json metric, configs[1]); "
+                         "train: full training window, RecEVFlowNet + loss + DP all-reduce + Adam (configs[2]/[3])")
     ap.add_argument("--windows", type=int, default=2, help="distinct pre-staged windows cycled through")
     ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
                     help="experiment: pre-sort the synthetic events of each pass on the host")
@@ -111,6 +114,8 @@ def main():
     from taming_event_flow_amd.loss.flow import Iterative, Linear
 
     lib = _lib.lib()
+    if a.mode == "train":
+        return bench_train(a, torch, dist, dev, rank, world, lib)
     H, W = a.res
     B, P, F = a.batch, a.passes, a.heads
     cfg = make_cfg(a)
@@ -227,6 +232,111 @@ def main():
                 "splats_per_launch": splats}
         if not a.no_cpu_baseline and a.warping == "Iterative":
             out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate
+
+
+def conv_flops_per_pass(B, H, W, bins=2):
+    """2*M*N*K of the 28 convolutions of one RecEVFlowNet forward."""
+    fl = 0
+    h, w, cin = H, W, bins
+    enc = []
+    for c in (64, 128, 256, 512):
+        h, w = h // 2, w // 2
+        fl += 2 * B * h * w * c * cin * 9            # strided head conv
+        fl += 3 * 2 * B * h * w * c * (2 * c) * 9    # ConvGRU gates
+        enc.append((c, h, w))
+        cin = c
+    fl += 4 * 2 * B * h * w * 512 * 512 * 9          # 2 residual blocks
+    cin_dec = [512, 258, 130, 66]
+    for (cin_, cout) in zip(cin_dec, (256, 128, 64, 32)):
+        h, w = h * 2, w * 2
+        fl += 2 * B * h * w * cout * cin_ * 9        # upsample conv
+        fl += 2 * B * h * w * 2 * cout               # 1x1 prediction
+    return fl
+
+
+def bench_train(a, torch, dist, dev, rank, world, lib):
+    """Full training window (reference train_flow.py:80-156): P x (encode, RecEVFlowNet forward, loss.update), loss,
+    backward through the window (BPTT), DP all-reduce SUM, clip, Adam.  events/s = events of the window / time."""
+    import copy
+
+    from taming_event_flow_amd import train
+
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"]["batch_size"] = a.batch
+    cfg["loader"]["resolution"] = list(a.res)
+    cfg["loader"]["max_num_grad_events"] = a.events
+    cfg["data"]["passes_loss"] = a.passes
+    cfg["loss"]["warping"] = a.warping
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    tr = train.Trainer(cfg, dev)
+    src = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100 + rank)
+    P = a.passes
+
+    def window():
+        for _ in range(P):
+            tr.step(src.next(), new_seq=False)
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tr.reset()
+    for _ in range(a.warmup):
+        window()
+    barrier()
+    lib.tef_profile_enable(0 if a.no_kernel_events else 1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        window()
+    t_enqueue = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.tef_profile_collect()
+    kern = {}
+    for s in range(lib.tef_profile_slots()):
+        n = lib.tef_profile_calls(s)
+        if n:
+            kern[lib.tef_profile_name(s).decode()] = (lib.tef_profile_ms(s), n)
+    lib.tef_profile_enable(0)
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ev_step = a.batch * P * (a.events + a.detached)
+    if rank == 0:
+        fl_pass = conv_flops_per_pass(a.batch, a.res[0], a.res[1])
+        gemm_ms = {k: v[0] / a.steps for k, v in kern.items() if k.startswith("conv_")}
+        roofline = None
+        if gemm_ms:
+            tot_ms = sum(gemm_ms.values())
+            flops = 3 * fl_pass * P      # forward + input-gradient + weight-gradient contractions
+            ach = flops / (tot_ms * 1e-3) / 1e12
+            roofline = {"kernel": "conv gemm_nt (fwd+dgrad+wgrad)", "bound": "mfma", "achieved": round(ach, 2),
+                        "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
+                        "traffic": None, "gemm_ms_per_window": {k: round(v, 3) for k, v in gemm_ms.items()}}
+        out = {
+            "metric": "events/sec through the full training window (RecEVFlowNet + IWE/contrast-max loss), 128x128 bs=8",
+            "value": round(ev_step * a.steps * world / elapsed, 1), "unit": "events/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"training window: {P} x (count encoding, RecEVFlowNet fwd, update) + {a.warping}/two "
+                                   f"loss + BPTT backward + all-reduce(SUM) + clip + Adam, {a.res[0]}x{a.res[1]}, "
+                                   f"B={a.batch}/GPU, N={a.events}+{a.detached} (BASELINE.json configs[2]/[3])",
+                       "global_batch": a.batch * world, "parallelism": f"dp{world} (RCCL all-reduce SUM of 125.5 MB grads)"},
+            "loss": round(float(tr.last_loss.item()), 6),
+            "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 3),
+            "conv_gflop_per_pass_fwd": round(fl_pass / 1e9, 2),
+            "roofline": roofline,
+            "kernels_ms_per_window": {k: round(v[0] / a.steps, 4) for k, v in kern.items()},
+        }
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()

@@ -62,6 +62,13 @@ SIGNATURES = {
     "tef_encode_events": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
     "tef_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "tef_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_size_t),
+                                                        ctypes.POINTER(ctypes.c_size_t)]),
+    "tef_conv_pack_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "tef_upsample_bilinear": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_float, _fp, _fp]),
+    "tef_upsample_bilinear_backward": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                      ctypes.c_int, ctypes.c_float, _fp, _fp]),
     "tef_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_size_t,
                                         _fp]),
     "tef_conv_backward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,

@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 16;          // k-depth of one LDS stage
 constexpr int LDK = BK + 4;     // padded LDS row (words): 16-byte aligned rows, spreads b128 reads over the banks
 
-enum { EPI_FWD = 0, EPI_PLAIN = 1, EPI_ATOMIC = 2 };
+enum { EPI_FWD = 0, EPI_PLAIN = 1, EPI_ATOMIC = 2, EPI_SLAB = 3 };
 
 struct GemmArgs {
     const float *A;   // [rows][lda]
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     const int wr = wave / (TC / WC), wc = wave % (TC / WC);
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * TC;
     int k_begin = 0, k_end = g.K;
-    if (EPI == EPI_ATOMIC) {
+    if (EPI == EPI_ATOMIC || EPI == EPI_SLAB) {
         k_begin = blockIdx.z * g.ksplit;
         k_end = min(g.K, k_begin + g.ksplit);
         if (k_begin >= k_end) return;
@@ -174,6 +174,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                     g.C[cbase + (size_t)r * g.hw] = apply_act(v, g.act);
                 } else if (EPI == EPI_PLAIN) {
                     g.C[(size_t)r * g.ldc + cbase] = v;
+                } else if (EPI == EPI_SLAB) {
+                    g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + cbase] = v;
                 } else {
                     atomicAdd(g.C + (size_t)r * g.ldc + cbase, v);
                 }
@@ -314,17 +316,21 @@ __global__ void pad_zero_kernel(float *__restrict__ dyt, int M, int N, int Np)
 }
 
 // weights [N][K] -> padded [N][Kp] (forward operand) and transposed [Kp][Np] (dgrad operand)
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int N, int K, int Kp, int Np,
-                                                          float *__restrict__ wp, float *__restrict__ wt)
+// `rows` weight rows (a whole nn.Conv2d parameter, or one part of a row-concatenated one) go to rows
+// [row0, row0 + rows) of the packed operands; the last part also zero-fills the n-padding of wt.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int rows, int row0, int N,
+                                                          int K, int Kp, int Np, float *__restrict__ wp,
+                                                          float *__restrict__ wt)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (size_t)N * Kp) {
+    if (idx < (size_t)rows * Kp) {
         int n = (int)(idx / Kp), k = (int)(idx - (size_t)n * Kp);
-        wp[idx] = k < K ? w[(size_t)n * K + k] : 0.0f;
+        wp[(size_t)(row0 + n) * Kp + k] = k < K ? w[(size_t)n * K + k] : 0.0f;
     }
-    if (idx < (size_t)Kp * Np) {
-        int k = (int)(idx / Np), n = (int)(idx - (size_t)k * Np);
-        wt[idx] = (k < K && n < N) ? w[(size_t)n * K + k] : 0.0f;
+    int ncols = (row0 + rows == N) ? Np - row0 : rows;      // columns of wt this part is responsible for
+    if (idx < (size_t)Kp * ncols) {
+        int k = (int)(idx / ncols), n = (int)(idx - (size_t)k * ncols);
+        wt[(size_t)k * Np + row0 + n] = (k < K && n < rows) ? w[(size_t)n * K + k] : 0.0f;
     }
 }
 
@@ -353,7 +359,35 @@ __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float *__restr
     dout[i] = g * uu;
 }
 
+// split-K epilogue of the forward GEMM: out[b][n][p] = act(bias[n] + sum_z slab[z][n][m]),  m = b * hw + p
+__global__ __launch_bounds__(256) void splitk_fwd_reduce_kernel(const float *__restrict__ slab, int z, int rows,
+                                                                int cols, const float *__restrict__ bias, int act,
+                                                                int hw, float *__restrict__ out)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)rows * cols) return;
+    int r = (int)(idx / cols), c = (int)(idx - (size_t)r * cols);
+    float v = bias ? bias[r] : 0.0f;
+    for (int k = 0; k < z; ++k) v += slab[((size_t)k * rows + r) * cols + c];
+    int img = c / hw, px = c - img * hw;
+    out[((size_t)img * rows + r) * hw + px] = apply_act(v, act);
+}
+
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// forward GEMMs of the deep levels have few output tiles (M = B*h*w = 512 at 8x8) and a long K (up to 9216):
+// split K over blockIdx.z so that the launch covers the chip, then reduce the slabs with the bias/activation.
+inline int fwd_splits(int rows, int cols, int K)
+{
+    int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
+    int tiles = ((cols + 127) / 128) * ((rows + tr - 1) / tr);
+    if (tiles >= 192 || K < 512) return 1;
+    int z = (384 + tiles - 1) / tiles;
+    int zmax = K / 128;
+    if (z > zmax) z = zmax;
+    if (z > 16) z = 16;
+    return z < 1 ? 1 : z;
+}
 
 template <int EPI>
 int launch_gemm(const GemmArgs &g, int zsplits, hipStream_t st)
@@ -391,7 +425,7 @@ bool fill_col(const tef_conv_desc *d, ColArgs *a)
 }
 
 struct ConvLayout {
-    size_t col, wp, wt, dyt, dyn, total;
+    size_t col, dyt, dyn, slab, total;
 };
 
 ConvLayout conv_layout(const tef_conv_desc *d, const ColArgs &a)
@@ -402,10 +436,9 @@ ConvLayout conv_layout(const tef_conv_desc *d, const ColArgs &a)
     int Np = round_up(d->N, 16);
     size_t colsz = (size_t)a.Mp * a.Kp;      // covers [M][Kp] and [Kp][Mp]
     L.col = take(colsz);
-    L.wp = take((size_t)d->N * a.Kp);
-    L.wt = take((size_t)a.Kp * Np);
     L.dyt = take((size_t)a.M * Np);
     L.dyn = take((size_t)d->N * a.Mp);
+    L.slab = take((size_t)fwd_splits(d->N, a.M, a.Kp) * d->N * a.M);
     L.total = o;
     return L;
 }
@@ -421,25 +454,42 @@ size_t tef_conv_workspace_bytes(const tef_conv_desc *d)
     return conv_layout(d, a).total;
 }
 
-int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *weight,
+size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, size_t *wt_floats)
+{
+    ColArgs a;
+    if (!fill_col(d, &a)) return 0;
+    size_t np_ = (size_t)d->N * a.Kp, nt = (size_t)a.Kp * round_up(d->N, 16);
+    if (wp_floats) *wp_floats = np_;
+    if (wt_floats) *wt_floats = nt;
+    return np_ + nt;
+}
+
+int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, int row0, float *wp, float *wt,
+                         void *stream)
+{
+    ColArgs a;
+    if (!fill_col(d, &a)) return TEF_ERR_INVALID;
+    if (!weight || !wp || !wt || rows < 1 || row0 < 0 || row0 + rows > d->N)
+        return tef::fail("tef_conv_pack_weight: bad arguments"), TEF_ERR_INVALID;
+    int Np = round_up(d->N, 16);
+    size_t n = std::max((size_t)rows * a.Kp, (size_t)a.Kp * (Np - row0));
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
+                       rows, row0, d->N, a.K, a.Kp, Np, wp, wt);
+    return tef::check_launch("pack_weight_kernel");
+}
+
+int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
                      const float *bias, float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     ColArgs a;
     if (!fill_col(d, &a)) return TEF_ERR_INVALID;
-    if (!x0 || (d->C1 > 0 && !x1) || !weight || !out || !workspace) return tef::fail("tef_conv_forward: null pointer"), TEF_ERR_INVALID;
+    if (!x0 || (d->C1 > 0 && !x1) || !wp || !out || !workspace) return tef::fail("tef_conv_forward: null pointer"), TEF_ERR_INVALID;
     ConvLayout L = conv_layout(d, a);
     if (workspace_bytes < L.total) return tef::fail("tef_conv_forward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    float *col = (float *)(ws + L.col), *wp = (float *)(ws + L.wp), *wt = (float *)(ws + L.wt);
+    float *col = (float *)(ws + L.col);
     a.src0 = x0; a.src1 = x1; a.gate1 = gate1;
-    int Np = round_up(d->N, 16);
-    {
-        size_t n = std::max((size_t)d->N * a.Kp, (size_t)a.Kp * Np);
-        hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, weight, d->N, a.K, a.Kp,
-                           Np, wp, wt);
-        if (int rc = tef::check_launch("pack_weight_kernel")) return rc;
-    }
     {
         size_t n = (size_t)a.M * a.Kp;
         hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, col, 0);
@@ -449,24 +499,35 @@ int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, c
     g.A = wp; g.lda = a.Kp; g.rows = d->N;
     g.B = col; g.ldb = a.Kp; g.cols = a.M;
     g.K = a.Kp; g.C = out; g.bias = bias; g.act = d->act; g.hw = a.Ho * a.Wo;
+    int z = fwd_splits(d->N, a.M, a.Kp);
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
-    return launch_gemm<EPI_FWD>(g, 1, st);
+    if (z == 1) return launch_gemm<EPI_FWD>(g, 1, st);
+    float *slab = (float *)(ws + L.slab);
+    g.C = slab; g.ldc = a.M; g.valid_cols = a.M;
+    g.ksplit = round_up((a.Kp + z - 1) / z, BK);
+    z = (a.Kp + g.ksplit - 1) / g.ksplit;
+    if (int rc = launch_gemm<EPI_SLAB>(g, z, st)) return rc;
+    size_t n = (size_t)d->N * a.M;
+    hipLaunchKernelGGL(splitk_fwd_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, a.M,
+                       bias, d->act, a.Ho * a.Wo, out);
+    return tef::check_launch("splitk_fwd_reduce_kernel");
 }
 
 int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
-                      const float *weight, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
+                      const float *wt, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream)
 {
     ColArgs a;
     if (!fill_col(d, &a)) return TEF_ERR_INVALID;
-    if (!x0 || (d->C1 > 0 && !x1) || !weight || !dout || !workspace) return tef::fail("tef_conv_backward: null pointer"), TEF_ERR_INVALID;
+    if (!x0 || (d->C1 > 0 && !x1) || !dout || !workspace) return tef::fail("tef_conv_backward: null pointer"), TEF_ERR_INVALID;
     if (d->act != TEF_ACT_NONE && !out) return tef::fail("tef_conv_backward: activation needs the forward output"), TEF_ERR_INVALID;
     ConvLayout L = conv_layout(d, a);
     if (workspace_bytes < L.total) return tef::fail("tef_conv_backward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    float *col = (float *)(ws + L.col), *wp = (float *)(ws + L.wp), *wt = (float *)(ws + L.wt);
+    float *col = (float *)(ws + L.col);
     float *dyt = (float *)(ws + L.dyt), *dyn = (float *)(ws + L.dyn);
+    if ((dx0 || dx1) && !wt) return tef::fail("tef_conv_backward: input gradient needs the packed transposed weight"), TEF_ERR_INVALID;
     a.src0 = x0; a.src1 = x1; a.gate1 = gate1;
     const int N = d->N, Np = round_up(N, 16), HW = a.Ho * a.Wo;
     const bool need_dx = dx0 || dx1;
@@ -496,12 +557,6 @@ int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, 
         if (int rc = launch_gemm<EPI_ATOMIC>(g, z, st)) return rc;
     }
     if (need_dx) {   // dcol[m][k] = sum_n g[m][n] W[n][k], then gather back to the input layout
-        {
-            size_t n = std::max((size_t)N * a.Kp, (size_t)a.Kp * Np);
-            hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, weight, N, a.K,
-                               a.Kp, Np, wp, wt);
-            if (int rc = tef::check_launch("pack_weight_kernel")) return rc;
-        }
         if (Np > N) {
             size_t n = (size_t)a.M * (Np - N);
             hipLaunchKernelGGL(pad_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dyt, a.M, N, Np);

@@ -1,0 +1,101 @@
+// tef_resize.hip — bilinear up-sampling by an integer factor, align_corners=False, forward and backward.
+// Reference: torch.nn.functional.interpolate(mode="bilinear", align_corners=False) as called by
+// models/submodules.py:264 (decoder features, x2) and models/model.py:79 (flow heads, x8/x4/x2/x1, times a scalar).
+// ATen semantics (UpSample.h area_pixel_compute_source_index): src = max((dst + 0.5) / s - 0.5, 0),
+// i0 = floor(src), i1 = i0 + (i0 < n - 1), weights (1 - l, l) with l = src - i0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tef.h"
+#include "tef_common.h"
+
+namespace {
+
+__device__ __forceinline__ void src_index(int o, float inv, int n, int &i0, int &i1, float &l0, float &l1)
+{
+    float s = inv * ((float)o + 0.5f) - 0.5f;
+    s = s < 0.0f ? 0.0f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restrict__ x, int planes, int H, int W, int sh,
+                                                           int sw, float mul, float *__restrict__ y)
+{
+    const int Ho = H * sh, Wo = W * sw;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * Ho * Wo) return;
+    int ox = (int)(idx % Wo);
+    size_t t = idx / Wo;
+    int oy = (int)(t % Ho), pl = (int)(t / Ho);
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(oy, 1.0f / (float)sh, H, y0, y1, ly0, ly1);
+    src_index(ox, 1.0f / (float)sw, W, x0, x1, lx0, lx1);
+    const float *p = x + (size_t)pl * H * W;
+    float v = ly0 * (lx0 * p[y0 * W + x0] + lx1 * p[y0 * W + x1]) + ly1 * (lx0 * p[y1 * W + x0] + lx1 * p[y1 * W + x1]);
+    y[idx] = mul * v;
+}
+
+// exact adjoint in gather form: input pixel (iy, ix) collects from the outputs whose taps include it
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
+                                                           int sh, int sw, float mul, float *__restrict__ dx)
+{
+    const int Ho = H * sh, Wo = W * sw;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * H * W) return;
+    int ix = (int)(idx % W);
+    size_t t = idx / W;
+    int iy = (int)(t % H), pl = (int)(t / H);
+    const float *g = dy + (size_t)pl * Ho * Wo;
+    int oy_lo = max(0, (iy - 1) * sh), oy_hi = min(Ho, (iy + 2) * sh);
+    int ox_lo = max(0, (ix - 1) * sw), ox_hi = min(Wo, (ix + 2) * sw);
+    float acc = 0.0f;
+    for (int oy = oy_lo; oy < oy_hi; ++oy) {
+        int y0, y1;
+        float ly0, ly1;
+        src_index(oy, 1.0f / (float)sh, H, y0, y1, ly0, ly1);
+        float wy = (y0 == iy ? ly0 : 0.0f) + (y1 == iy ? ly1 : 0.0f);
+        if (wy == 0.0f) continue;
+        float row = 0.0f;
+        for (int ox = ox_lo; ox < ox_hi; ++ox) {
+            int x0, x1;
+            float lx0, lx1;
+            src_index(ox, 1.0f / (float)sw, W, x0, x1, lx0, lx1);
+            float wx = (x0 == ix ? lx0 : 0.0f) + (x1 == ix ? lx1 : 0.0f);
+            if (wx != 0.0f) row += wx * g[(size_t)oy * Wo + ox];
+        }
+        acc += wy * row;
+    }
+    dx[idx] = mul * acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tef_upsample_bilinear(const float *x, int planes, int H, int W, int scale_h, int scale_w, float mul, float *y,
+                          void *stream)
+{
+    if (!x || !y || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1)
+        return tef::fail("tef_upsample_bilinear: bad arguments"), TEF_ERR_INVALID;
+    size_t n = (size_t)planes * H * scale_h * W * scale_w;
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, planes,
+                       H, W, scale_h, scale_w, mul, y);
+    return tef::check_launch("upsample_fwd_kernel");
+}
+
+int tef_upsample_bilinear_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
+                                   float *dx, void *stream)
+{
+    if (!dy || !dx || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1)
+        return tef::fail("tef_upsample_bilinear_backward: bad arguments"), TEF_ERR_INVALID;
+    size_t n = (size_t)planes * H * W;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, planes,
+                       H, W, scale_h, scale_w, mul, dx);
+    return tef::check_launch("upsample_bwd_kernel");
+}
+
+}

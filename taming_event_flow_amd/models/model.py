@@ -12,6 +12,7 @@ from .arch import *  # noqa: F401,F403
 from .arch import MultiResUNetRecurrent
 from .base import BaseModel
 from .model_util import ImagePadder, copy_states
+from .submodules import upsample_bilinear
 
 __all__ = ["RecEVFlowNet", "MultiResUNetRecurrent"]
 
@@ -79,8 +80,6 @@ class RecEVFlowNet(BaseModel):
             scaling_h = x.shape[2] / flow.shape[2]
             scaling_w = x.shape[3] / flow.shape[3]
             scaling_flow = 2 ** (self.num_encoders - i - 1)
-            upflow = scaling_flow * torch.nn.functional.interpolate(
-                flow, scale_factor=(scaling_h, scaling_w), mode="bilinear", align_corners=False
-            )
+            upflow = upsample_bilinear(flow, scaling_h, scaling_w, mul=float(scaling_flow))
             flow_list.append(self.image_padder.unpad(upflow))
         return {self.key: flow_list}

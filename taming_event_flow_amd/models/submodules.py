@@ -20,65 +20,150 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+class PackedWeights:
+    """GEMM operands of one convolution's weight (include/tef.h tef_conv_pack_weight), re-packed only when a
+    parameter changed (optimizer step / load_state_dict), i.e. once per loss window instead of once per call."""
+
+    def __init__(self):
+        self.key = None
+        self.wp = self.wt = None
+
+    def get(self, weights, desc):
+        key = tuple((w.data_ptr(), w._version) for w in weights) + (desc.C0 + desc.C1, desc.N, desc.ksize)
+        if key != self.key:
+            lib = _lib.lib()
+            np_, nt = ctypes.c_size_t(), ctypes.c_size_t()
+            lib.tef_conv_packed_weight_floats(ctypes.byref(desc), ctypes.byref(np_), ctypes.byref(nt))
+            dev = weights[0].device
+            self.wp = torch.empty((np_.value,), dtype=torch.float32, device=dev)
+            self.wt = torch.empty((nt.value,), dtype=torch.float32, device=dev)
+            row0 = 0
+            for w in weights:
+                wc = w.detach().contiguous()
+                rc = lib.tef_conv_pack_weight(ctypes.byref(desc), wc.data_ptr(), wc.shape[0], row0, self.wp.data_ptr(),
+                                              self.wt.data_ptr(), _lib.stream_ptr())
+                _lib.check(rc, "tef_conv_pack_weight")
+                row0 += wc.shape[0]
+            self.key = key
+        return self.wp, self.wt
+
+
 class _ConvFn(torch.autograd.Function):
-    """act(conv2d(cat[x0, x1 * gate1], weight, bias)) with padding k//2; see include/tef.h tef_conv_forward."""
+    """act(conv2d(cat[x0, x1 * gate1], cat(weights, 0), cat(biases, 0))) with padding k//2 (include/tef.h
+    tef_conv_forward).  `nw` weight tensors are row-concatenated without materialising the concatenation."""
 
     @staticmethod
-    def forward(ctx, x0, x1, gate1, weight, bias, stride, act):
+    def forward(ctx, packer, stride, act, nw, x0, x1, gate1, *wb):
         lib = _lib.lib()
         _lib.require_device_tensor(x0, "conv input")
+        weights, biases = wb[:nw], wb[nw:]
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         gate1 = gate1.contiguous() if gate1 is not None else None
-        weight = weight.contiguous()
         B, C0, H, W = x0.shape
         C1 = x1.shape[1] if x1 is not None else 0
-        N, Ct, k, _ = weight.shape
+        N = sum(w.shape[0] for w in weights)
+        Ct, k = weights[0].shape[1], weights[0].shape[2]
         assert Ct == C0 + C1, (Ct, C0, C1)
         d = _lib.ConvDesc(B, C0, C1, H, W, N, k, stride, _lib.ACT[act])
+        wp, wt = packer.get(weights, d)
+        bias = None
+        if biases and biases[0] is not None:
+            bias = biases[0] if len(biases) == 1 else torch.cat([b.detach() for b in biases])
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         out = torch.empty((B, N, Ho, Wo), dtype=torch.float32, device=x0.device)
         nbytes = lib.tef_conv_workspace_bytes(ctypes.byref(d))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
-        rc = lib.tef_conv_forward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), weight.data_ptr(), _ptr(bias),
+        rc = lib.tef_conv_forward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), wp.data_ptr(), _ptr(bias),
                                   out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr())
         _lib.check(rc, "tef_conv_forward")
-        ctx.desc = d
+        ctx.desc, ctx.nw, ctx.wt = d, nw, wt
+        ctx.rows = [w.shape[0] for w in weights]
+        ctx.wshape = tuple(weights[0].shape[1:])
         ctx.has = (x1 is not None, gate1 is not None, bias is not None)
-        ctx.save_for_backward(x0, x1, gate1, weight, out if act is not None else None)
+        ctx.save_for_backward(x0, x1, gate1, out if act is not None else None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.lib()
-        x0, x1, gate1, weight, out = ctx.saved_tensors
-        d = ctx.desc
+        x0, x1, gate1, out = ctx.saved_tensors
+        d, nw = ctx.desc, ctx.nw
         has_x1, has_gate, has_bias = ctx.has
-        need = ctx.needs_input_grad
+        need = ctx.needs_input_grad          # (packer, stride, act, nw, x0, x1, gate1, *weights, *biases)
         dout = dout.contiguous()
-        dx0 = torch.empty_like(x0) if need[0] else None
-        dxg = torch.empty_like(x1) if has_x1 and (need[1] or need[2]) else None
-        dw = torch.zeros_like(weight) if need[3] else None
-        db = torch.zeros((d.N,), dtype=torch.float32, device=dout.device) if (has_bias and need[4]) else None
+        dev = dout.device
+        dx0 = torch.empty_like(x0) if need[4] else None
+        dxg = torch.empty_like(x1) if has_x1 and (need[5] or need[6]) else None
+        need_w = any(need[7:7 + nw])
+        need_b = has_bias and any(need[7 + nw:])
+        dw = torch.zeros((d.N,) + ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
+        db = torch.zeros((d.N,), dtype=torch.float32, device=dev) if need_b else None
         nbytes = lib.tef_conv_workspace_bytes(ctypes.byref(d))
-        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dout.device)
-        rc = lib.tef_conv_backward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), weight.data_ptr(), _ptr(out),
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        rc = lib.tef_conv_backward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(), _ptr(out),
                                    dout.data_ptr(), _ptr(dx0), _ptr(dxg), _ptr(dw), _ptr(db), ws.data_ptr(), nbytes,
                                    _lib.stream_ptr())
         _lib.check(rc, "tef_conv_backward")
         dx1 = dgate = None
         if dxg is not None:
             if has_gate:
-                dx1 = dxg * gate1 if need[1] else None
-                dgate = dxg * x1 if need[2] else None
+                dx1 = dxg * gate1 if need[5] else None
+                dgate = dxg * x1 if need[6] else None
             else:
                 dx1 = dxg
-        return dx0, dx1, dgate, dw, db, None, None
+        gw, gb, r0 = [], [], 0
+        for r in ctx.rows:
+            gw.append(dw[r0:r0 + r] if dw is not None else None)
+            gb.append(db[r0:r0 + r] if db is not None else None)
+            r0 += r
+        if not has_bias:
+            gb = [None] * (len(need) - 7 - nw)
+        return (None, None, None, None, dx0, dx1, dgate) + tuple(gw) + tuple(gb)
 
 
-def conv2d(x0, weight, bias, stride=1, act=None, x1=None, gate1=None):
-    return _ConvFn.apply(x0, x1, gate1, weight, bias, stride, act)
+def conv2d(packer, x0, weights, biases, stride=1, act=None, x1=None, gate1=None):
+    """weights / biases: a parameter or a tuple of parameters to be row-concatenated (same input, one GEMM)."""
+    if not isinstance(weights, (tuple, list)):
+        weights, biases = (weights,), (biases,)
+    return _ConvFn.apply(packer, stride, act, len(weights), x0, x1, gate1, *weights, *biases)
+
+
+class _UpsampleFn(torch.autograd.Function):
+    """mul * F.interpolate(x, scale_factor=(sh, sw), mode="bilinear", align_corners=False) for integer factors."""
+
+    @staticmethod
+    def forward(ctx, x, sh, sw, mul):
+        _lib.require_device_tensor(x, "upsample input")
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H * sh, W * sw), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().tef_upsample_bilinear(x.data_ptr(), B * C, H, W, sh, sw, mul, y.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "tef_upsample_bilinear")
+        ctx.geom = (B, C, H, W, sh, sw, mul)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, sh, sw, mul = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty((B, C, H, W), dtype=torch.float32, device=dy.device)
+        rc = _lib.lib().tef_upsample_bilinear_backward(dy.data_ptr(), B * C, H, W, sh, sw, mul, dx.data_ptr(),
+                                                       _lib.stream_ptr())
+        _lib.check(rc, "tef_upsample_bilinear_backward")
+        return dx, None, None, None
+
+
+def upsample_bilinear(x, scale_h, scale_w, mul=1.0):
+    """Integer-factor bilinear up-sampling (align_corners=False) on the HIP kernel; other factors are not used by
+    RecEVFlowNet (power-of-two pyramid on a padded input)."""
+    sh, sw = int(round(scale_h)), int(round(scale_w))
+    if sh != scale_h or sw != scale_w or sh < 1 or sw < 1:
+        raise NotImplementedError(f"non-integer bilinear scale ({scale_h}, {scale_w})")
+    if sh == 1 and sw == 1:
+        return x * mul if mul != 1.0 else x
+    return _UpsampleFn.apply(x, sh, sw, float(mul))
 
 
 class _GruBlendFn(torch.autograd.Function):
@@ -138,9 +223,10 @@ class ConvLayer(nn.Module):
         self.activation = _act_name(activation)
         self.stride = stride
         self.norm = norm
+        self._packed = PackedWeights()
 
     def forward(self, x):
-        return conv2d(x, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
+        return conv2d(self._packed, x, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
 
 
 class ConvGRU(nn.Module):
@@ -161,6 +247,7 @@ class ConvGRU(nn.Module):
         nn.init.constant_(self.reset_gate.bias, 0.0)
         nn.init.constant_(self.update_gate.bias, 0.0)
         nn.init.constant_(self.out_gate.bias, 0.0)
+        self._packed_ur, self._packed_o = PackedWeights(), PackedWeights()
 
     def forward(self, input_, prev_state):
         if prev_state is None:
@@ -168,12 +255,12 @@ class ConvGRU(nn.Module):
                                      dtype=input_.dtype, device=input_.device)
         C = self.hidden_size
         # update and reset gates share their input: one GEMM with 2C output channels
-        w_ur = torch.cat([self.update_gate.weight, self.reset_gate.weight], dim=0)
-        b_ur = torch.cat([self.update_gate.bias, self.reset_gate.bias], dim=0)
-        ur = conv2d(input_, w_ur, b_ur, 1, "sigmoid", x1=prev_state)
+        ur = conv2d(self._packed_ur, input_, (self.update_gate.weight, self.reset_gate.weight),
+                    (self.update_gate.bias, self.reset_gate.bias), 1, "sigmoid", x1=prev_state)
         update, reset = ur[:, :C].contiguous(), ur[:, C:].contiguous()
         # tanh(out_gate(cat[input_, prev_state * reset])): the product is formed inside the im2col gather
-        out_inputs = conv2d(input_, self.out_gate.weight, self.out_gate.bias, 1, "tanh", x1=prev_state, gate1=reset)
+        out_inputs = conv2d(self._packed_o, input_, self.out_gate.weight, self.out_gate.bias, 1, "tanh",
+                            x1=prev_state, gate1=reset)
         new_state = _GruBlendFn.apply(prev_state, update, out_inputs)
         return new_state, new_state
 
@@ -214,10 +301,11 @@ class ResidualBlock(nn.Module):
         self.stride = stride
         self.norm = norm
         self.downsample = downsample
+        self._packed1, self._packed2 = PackedWeights(), PackedWeights()
 
     def forward(self, x):
-        out1 = conv2d(x, self.conv1.weight, self.conv1.bias, self.stride, self.activation)
-        out2 = conv2d(out1, self.conv2.weight, self.conv2.bias, self.stride, None)
+        out1 = conv2d(self._packed1, x, self.conv1.weight, self.conv1.bias, self.stride, self.activation)
+        out2 = conv2d(self._packed2, out1, self.conv2.weight, self.conv2.bias, self.stride, None)
         out2 = out2 + x
         if self.activation is not None:
             out2 = getattr(torch, self.activation)(out2)
@@ -234,10 +322,11 @@ class UpsampleConvLayer(nn.Module):
         self.activation = _act_name(activation)
         self.stride = stride
         self.norm = norm
+        self._packed = PackedWeights()
 
     def forward(self, x):
-        x_upsampled = f.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
-        return conv2d(x_upsampled, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
+        x_upsampled = upsample_bilinear(x, 2, 2)
+        return conv2d(self._packed, x_upsampled, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
 
 
 class TransposedConvLayer(nn.Module):
