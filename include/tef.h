@@ -156,21 +156,21 @@ typedef struct tef_conv_desc {
 } tef_conv_desc;
 
 size_t tef_conv_workspace_bytes(const tef_conv_desc *d);
-/* GEMM operands of the weight: wp = [N][Kp] (K = (C0+C1) k k padded to 16; forward) and wt = [Kp][Np] (transposed, N
- * padded to 16; input gradient).  Sizes in floats via tef_conv_packed_weight_floats (returns their sum).  Pack once per
- * optimiser step, not per call.  A row-concatenation of several parameters (ConvGRU update|reset gates sharing one
- * GEMM) is packed part by part: `rows` rows of `weight` land at row `row0`. */
-size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, size_t *wt_floats);
-int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, int row0, float *wp, float *wt,
+/* GEMM operands of the weight: wp = [N][Kp], k = (ci, ky, kx) padded to 16 (forward) and w2 = [C0+C1][K2p],
+ * k' = (n, ky, kx) padded to 16 (input gradient).  Sizes in floats via tef_conv_packed_weight_floats (returns their
+ * sum).  Pack once per optimiser step, not per call.  A row-concatenation of several parameters (ConvGRU
+ * update|reset gates sharing one GEMM) is packed part by part: `rows` rows of `weight` land at row `row0`. */
+size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, size_t *w2_floats);
+int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, int row0, float *wp, float *w2,
                          void *stream);
 /* out [B,N,Ho,Wo] = act(conv(cat[x0, x1 * gate1], weight) + bias), weight given as its packed form wp */
 int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
                      const float *bias, float *out, void *workspace, size_t workspace_bytes, void *stream);
 /* Given dout = d loss / d out (and out itself when act != NONE):
  *   dx0 [B,C0,H,W], dx1 [B,C1,H,W] = gradient w.r.t. the concatenated conv input (dx1 is w.r.t. x1 * gate1; either may
- *   be NULL to skip; needs the packed transposed weight wt), overwritten;  dweight [N,C0+C1,k,k] and dbias [N] are ACCUMULATED into (+=), NULL to skip. */
+ *   together be NULL to skip; needs the packed weight w2), overwritten;  dweight [N,C0+C1,k,k] and dbias [N] are ACCUMULATED into (+=), NULL to skip. */
 int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
-                      const float *wt, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
+                      const float *w2, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream);
 /* ConvGRU state update new_state = prev * (1 - update) + out_inputs * update (submodules.py:150) and its backward
  * (dh = direct path only; the paths through the gates go through tef_conv_backward). n = element count. */

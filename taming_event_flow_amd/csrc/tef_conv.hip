@@ -6,11 +6,14 @@
 // no xf32/TF32), so results match the reference's fp32 convolutions to summation-order noise — the north star's
 // 1e-4 bar rules out plain bf16.
 //
-// Structure (v1): every convolution is  im2col (gather, optional channel concat / gating product)  +  one
-// "NT" GEMM  C[r][c] = sum_k A[r][k] * B[c][k]  with both operands k-contiguous and K padded to 16:
-//     forward   out[n][m]  = W[n][k]    x col[m][k]      epilogue: + bias, activation, NCHW store
-//     dgrad     dcol[m][k] = dYt[m][n]  x Wt[k][n]       epilogue: plain store, then col2im (gather form)
-//     wgrad     dW[n][k]  += dYn[n][m]  x colT[k][m]     epilogue: atomic accumulate into param.grad, split over m
+// Structure: implicit GEMM.  One "NT" kernel  C[r][c] = sum_k A[r][k] * B[c][k]  whose operand loaders either read a
+// plain k-contiguous matrix or gather the im2col element on the fly (channel concat of two NCHW sources, optional
+// gating product, stride / transposed-stride geometry), so no im2col / col2im / transposed copies exist in memory:
+//     forward   out[n][m]   = Wp[n][k]   x gather_x[m][k]       k = (ci, ky, kx)     epilogue: bias, act, NCHW
+//     dgrad     dx[ci][m']  = W2[ci][k'] x gather_g[m'][k']     k' = (n, ky, kx)     epilogue: NCHW, split x0 | x1
+//     wgrad     dW[n][k]   += g[n][m]    x gather_x^T[k][m]     reduction over pixels, split over blockIdx.z, atomics
+// where g = dout * act'(out) (one elementwise pass that also reduces the bias gradient).  Deep levels (M = B*h*w as
+// small as 512, K up to 9216) are split over K into slabs and reduced with the epilogue.
 // 128x128 (or 64x128 / 32x128) workgroup tiles, 4 waves, 32x32x2 MFMA tiles, LDS staged with register prefetch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,22 +27,40 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;          // k-depth of one LDS stage
+constexpr int BK = 32;          // k-depth of one LDS stage (long enough to cover the gather latency of the next)
+constexpr int PPR = BK / 4;     // 4-float pieces per tile row
+constexpr int LOGP = 3;         // log2(PPR)
+static_assert((1 << LOGP) == PPR, "pieces per row");
 constexpr int LDK = BK + 4;     // padded LDS row (words): 16-byte aligned rows, spreads b128 reads over the banks
 
-enum { EPI_FWD = 0, EPI_PLAIN = 1, EPI_ATOMIC = 2, EPI_SLAB = 3 };
+enum { EPI_FWD = 0, EPI_ATOMIC = 2, EPI_SLAB = 3 };
+enum { A_PLAIN = 0, A_NCHW = 1 };
+enum { B_GATHER = 1, B_GATHER_T = 2 };
+
+// im2col element source: value(pixel p = (b, py, px) of the output grid, k = (ci, ky, kx))
+struct Gather {
+    const float *src0, *src1, *gate1;   // NCHW sources, channel-concatenated; src1 optionally times gate1
+    int C0, C1;          // channels of the two sources
+    int SH, SW;          // source spatial size
+    int OH, OW;          // output-grid size (pixels are decomposed against this)
+    int ks, pad;         // kernel size (1 | 3), padding
+    int mul, div, sgn;   // source y = (py * mul + sgn * (ky - pad)) / div   (forward: mul = stride, div = 1, sgn = +1;
+                         //  input gradient: mul = 1, div = stride, sgn = -1, only exact multiples contribute)
+    int K;               // true reduction length (ci, ky, kx); k >= K reads as zero
+    int npix;            // B * OH * OW; pixels >= npix read as zero
+};
 
 struct GemmArgs {
-    const float *A;   // [rows][lda]
-    const float *B;   // [cols][ldb]
-    float *C;
-    const float *bias;    // [rows] or null (EPI_FWD)
-    int rows, cols, K;    // K % 16 == 0
-    int lda, ldb, ldc;
-    int act;              // TEF_ACT_*
-    int hw;               // EPI_FWD: pixels per image; column c -> image c / hw, pixel c % hw; C is [B][rows][hw]
-    int ksplit;           // EPI_ATOMIC: k-range per blockIdx.z
-    int valid_cols;       // EPI_ATOMIC / EPI_PLAIN: columns >= valid_cols are padding and not stored
+    const float *A;       // A_PLAIN: [rows][lda];  A_NCHW: g [B][rows][hwA] read as A[r][kk = (b, p)]
+    Gather G;             // B operand
+    float *C, *C2;        // EPI_FWD: NCHW outputs, rows < split go to C ([B][split][hw]), the rest to C2
+    const float *bias;
+    int rows, cols, K;    // K % 16 == 0 (padded reduction length)
+    int lda, ldc;
+    int act, hw, split;
+    int hwA;              // A_NCHW: pixels per image of g
+    int ksplit;           // EPI_ATOMIC / EPI_SLAB: reduction range per blockIdx.z
+    int valid_cols;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act)
@@ -50,8 +71,51 @@ __device__ __forceinline__ float apply_act(float v, int act)
     return v;
 }
 
+struct Pix { int b, py, px; bool ok; };
+
+__device__ __forceinline__ Pix decode_pixel(const Gather &G, int p)
+{
+    Pix q;
+    q.ok = p < G.npix;
+    int pp = q.ok ? p : 0;
+    int ohw = G.OH * G.OW;
+    q.b = pp / ohw;
+    int r = pp - q.b * ohw;
+    q.py = r / G.OW;
+    q.px = r - q.py * G.OW;
+    return q;
+}
+
+__device__ __forceinline__ float gather_value(const Gather &G, const Pix &q, int k)
+{
+    if (!q.ok || k >= G.K) return 0.0f;
+    int ci, ky, kx;
+    if (G.ks == 3) {
+        ci = k / 9;
+        int r = k - ci * 9;
+        ky = r / 3;
+        kx = r - ky * 3;
+    } else {
+        ci = k;
+        ky = kx = 0;
+    }
+    int ty = q.py * G.mul + G.sgn * (ky - G.pad), tx = q.px * G.mul + G.sgn * (kx - G.pad);
+    if (ty < 0 || tx < 0) return 0.0f;
+    if (G.div > 1) {
+        if ((ty % G.div) | (tx % G.div)) return 0.0f;
+        ty /= G.div;
+        tx /= G.div;
+    }
+    if (ty >= G.SH || tx >= G.SW) return 0.0f;
+    if (ci < G.C0) return G.src0[(((size_t)q.b * G.C0 + ci) * G.SH + ty) * G.SW + tx];
+    size_t o = (((size_t)q.b * G.C1 + (ci - G.C0)) * G.SH + ty) * G.SW + tx;
+    float v = G.src1[o];
+    if (G.gate1) v *= G.gate1[o];
+    return v;
+}
+
 // TR x TC workgroup tile, WR x WC wave tile (multiples of 32), 256 threads.
-template <int TR, int TC, int WR, int WC, int EPI>
+template <int TR, int TC, int WR, int WC, int AM, int BM, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 {
     static_assert((TR / WR) * (TC / WC) == 4, "4 waves per workgroup");
@@ -69,41 +133,149 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         if (k_begin >= k_end) return;
     }
 
-    // global -> register staging: each thread moves float4 pieces (row = piece / 4, k offset = 4 * (piece % 4))
-    constexpr int APIECES = TR * 4 / 256, BPIECES = TC * 4 / 256;
-    static_assert(TR * 4 % 256 == 0 || TR * 4 < 256, "tile rows");
-    float4 ra[APIECES > 0 ? APIECES : 1], rb[BPIECES > 0 ? BPIECES : 1];
+    // staging: each thread moves 4-float pieces (tile row = piece / PPR, k offset = 4 * (piece % PPR))
+    constexpr int AP = (TR * PPR + 255) / 256, BP = (TC * PPR + 255) / 256;
+    float4 ra[AP], rb[BP];
+    const int SHW = g.G.SH * g.G.SW;
+    const int kk2 = g.G.ks * g.G.ks;
+
+    // B_GATHER: per tile row (= output pixel) the 9 (ky, kx) source offsets are tabulated once in LDS (-1 = padding /
+    // stride miss); the (ci, r = ky * 3 + kx) decomposition of k is advanced incrementally, so the per-element cost
+    // of the implicit im2col is one LDS read, a compare and an add instead of divisions and bounds tests.
+    __shared__ int soff[BM == B_GATHER ? TC : 1][BM == B_GATHER ? 9 : 1];
+    int pb0[BP], pb1[BP];      // batch base offsets of the two sources for this piece's pixel
+    int ci0[BP], r0[BP];       // (ci, r) of element 0 of the piece at the current k0
+    if (BM == B_GATHER) {
+        for (int t = tid; t < TC * 9; t += 256) {
+            int row = t / 9, r = t - row * 9;
+            Pix q = decode_pixel(g.G, col0 + row);
+            int off = -1;
+            if (q.ok && r < kk2) {
+                int ky = r / g.G.ks, kx = r - ky * g.G.ks;
+                int ty = q.py * g.G.mul + g.G.sgn * (ky - g.G.pad), tx = q.px * g.G.mul + g.G.sgn * (kx - g.G.pad);
+                bool ok = ty >= 0 && tx >= 0;
+                if (ok && g.G.div > 1) {
+                    ok = !((ty % g.G.div) | (tx % g.G.div));
+                    ty /= g.G.div;
+                    tx /= g.G.div;
+                }
+                if (ok && ty < g.G.SH && tx < g.G.SW) off = ty * g.G.SW + tx;
+            }
+            soff[row][r] = off;
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            int piece = tid + p * 256;
+            Pix q = decode_pixel(g.G, col0 + (piece >> LOGP));
+            pb0[p] = q.b * g.G.C0 * SHW;
+            pb1[p] = q.b * g.G.C1 * SHW;
+            int k = k_begin + (piece & (PPR - 1)) * 4;
+            ci0[p] = k / kk2;
+            r0[p] = k - ci0[p] * kk2;
+        }
+        __syncthreads();
+    }
+    // B_GATHER_T: the tile row is a fixed (ci, ky, kx); the reduction index walks over output pixels
+    const float *tsrc[BP], *tgate[BP];
+    int tky[BP], tkx[BP], tcs[BP];
+    if (BM == B_GATHER_T) {
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            int k = col0 + ((tid + p * 256) >> LOGP);
+            int ci = k / kk2, r = k - ci * kk2;
+            tky[p] = r / g.G.ks;
+            tkx[p] = r - tky[p] * g.G.ks;
+            bool second = ci >= g.G.C0;
+            tcs[p] = second ? g.G.C1 : g.G.C0;
+            int cl = second ? ci - g.G.C0 : ci;
+            tsrc[p] = k < g.G.K ? (second ? g.G.src1 : g.G.src0) + (size_t)cl * SHW : nullptr;
+            tgate[p] = (k < g.G.K && second && g.G.gate1) ? g.G.gate1 + (size_t)cl * SHW : nullptr;
+        }
+    }
 
     auto load_tiles = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < (APIECES > 0 ? APIECES : 1); ++p) {
+        for (int p = 0; p < AP; ++p) {
             int piece = tid + p * 256;
-            int r = piece >> 2, kq = (piece & 3) * 4;
-            bool ok = (TR * 4 >= 256 || piece < TR * 4) && (row0 + r) < g.rows;
-            ra[p] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(row0 + r) * g.lda + k0 + kq)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
+            bool ok = (TR * PPR % 256 == 0 || piece < TR * PPR) && (row0 + r) < g.rows;
+            if (AM == A_PLAIN) {
+                ra[p] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(row0 + r) * g.lda + k0 + kq)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {            // A[r][kk], kk = (image, pixel) of an NCHW tensor with `rows` channels
+                float v[4];
+                int kk = k0 + kq;
+                int img = kk / g.hwA, px = kk - img * g.hwA;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = (ok && kk + j < g.G.npix) ? g.A[((size_t)img * g.rows + row0 + r) * g.hwA + px] : 0.0f;
+                    if (++px == g.hwA) { px = 0; ++img; }
+                }
+                ra[p] = make_float4(v[0], v[1], v[2], v[3]);
+            }
         }
 #pragma unroll
-        for (int p = 0; p < (BPIECES > 0 ? BPIECES : 1); ++p) {
+        for (int p = 0; p < BP; ++p) {
             int piece = tid + p * 256;
-            int r = piece >> 2, kq = (piece & 3) * 4;
-            bool ok = (TC * 4 >= 256 || piece < TC * 4) && (col0 + r) < g.cols;
-            rb[p] = ok ? *reinterpret_cast<const float4 *>(g.B + (size_t)(col0 + r) * g.ldb + k0 + kq)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+            int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
+            bool ok = (TC * PPR % 256 == 0 || piece < TC * PPR) && (col0 + r) < g.cols;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BM == B_GATHER) {
+                int ci = ci0[p], rr = r0[p];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int so = soff[r][rr];
+                    if (ok && so >= 0 && ci < g.G.C0 + g.G.C1) {
+                        if (ci < g.G.C0) {
+                            v[j] = g.G.src0[(size_t)pb0[p] + (size_t)ci * SHW + so];
+                        } else {
+                            size_t o = (size_t)pb1[p] + (size_t)(ci - g.G.C0) * SHW + so;
+                            float t = g.G.src1[o];
+                            v[j] = g.G.gate1 ? t * g.G.gate1[o] : t;
+                        }
+                    }
+                    if (++rr == kk2) { rr = 0; ++ci; }
+                }
+                // advance (ci, r) by BK for the next stage
+                if (kk2 == 9) {
+                    ci0[p] += BK / 9;
+                    r0[p] += BK % 9;
+                    if (r0[p] >= 9) { r0[p] -= 9; ci0[p] += 1; }
+                } else {
+                    ci0[p] += BK;
+                }
+            } else if (ok && tsrc[p]) {        // B_GATHER_T
+                Pix q = decode_pixel(g.G, k0 + kq);
+                int m = k0 + kq;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (m + j < g.G.npix) {
+                        int ty = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
+                        int tx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
+                        if (ty >= 0 && tx >= 0 && ty < g.G.SH && tx < g.G.SW) {
+                            size_t o = (size_t)q.b * tcs[p] * SHW + ty * g.G.SW + tx;
+                            float t = tsrc[p][o];
+                            v[j] = tgate[p] ? t * tgate[p][o] : t;
+                        }
+                    }
+                    if (++q.px == g.G.OW) { q.px = 0; if (++q.py == g.G.OH) { q.py = 0; ++q.b; } }
+                }
+            }
+            rb[p] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < (APIECES > 0 ? APIECES : 1); ++p) {
+        for (int p = 0; p < AP; ++p) {
             int piece = tid + p * 256;
-            if (TR * 4 >= 256 || piece < TR * 4)
-                *reinterpret_cast<float4 *>(&As[buf][piece >> 2][(piece & 3) * 4]) = ra[p];
+            if (TR * PPR % 256 == 0 || piece < TR * PPR)
+                *reinterpret_cast<float4 *>(&As[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = ra[p];
         }
 #pragma unroll
-        for (int p = 0; p < (BPIECES > 0 ? BPIECES : 1); ++p) {
+        for (int p = 0; p < BP; ++p) {
             int piece = tid + p * 256;
-            if (TC * 4 >= 256 || piece < TC * 4)
-                *reinterpret_cast<float4 *>(&Bs[buf][piece >> 2][(piece & 3) * 4]) = rb[p];
+            if (TC * PPR % 256 == 0 || piece < TC * PPR)
+                *reinterpret_cast<float4 *>(&Bs[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = rb[p];
         }
     };
 
@@ -156,13 +328,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         for (int j = 0; j < MC; ++j) {
             int c = col0 + wc * WC + j * 32 + (lane & 31);
             if (c >= g.cols) continue;
-            size_t cbase;
+            int img = 0, px = 0;
             if (EPI == EPI_FWD) {
-                int img = c / g.hw, px = c - img * g.hw;
-                cbase = (size_t)img * g.rows * g.hw + px;
-            } else {
-                if (c >= g.valid_cols) continue;
-                cbase = (size_t)c;
+                img = c / g.hw;
+                px = c - img * g.hw;
+            } else if (c >= g.valid_cols) {
+                continue;
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -171,128 +342,55 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                 float v = acc[i][j][e];
                 if (EPI == EPI_FWD) {
                     if (g.bias) v += g.bias[r];
-                    g.C[cbase + (size_t)r * g.hw] = apply_act(v, g.act);
-                } else if (EPI == EPI_PLAIN) {
-                    g.C[(size_t)r * g.ldc + cbase] = v;
+                    v = apply_act(v, g.act);
+                    if (r < g.split) g.C[((size_t)img * g.split + r) * g.hw + px] = v;
+                    else g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
                 } else if (EPI == EPI_SLAB) {
-                    g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + cbase] = v;
+                    g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + c] = v;
                 } else {
-                    atomicAdd(g.C + (size_t)r * g.ldc + cbase, v);
+                    atomicAdd(g.C + (size_t)r * g.ldc + c, v);
                 }
             }
         }
 }
 
-// ---------------------------------------------------------------------------------------------
-// im2col of a 3x3 / 1x1 convolution input made of up to two channel-concatenated NCHW sources
-// (torch.cat([a, b], 1), models/submodules.py:146,149), the second optionally multiplied element-wise by a
-// gate (prev_state * reset, :149).  k = (ci * kh + ky) * kw + kx, zero padding, K padded to Kp with zeros.
-//   transposed = 0:  col [M][Kp]   (forward / dgrad operand)      transposed = 1:  colT [Kp][Mp]  (wgrad operand)
-// ---------------------------------------------------------------------------------------------
-struct ColArgs {
-    const float *src0, *src1, *gate1;
-    int C0, C1;
-    int B, H, W, Ho, Wo, ksize, stride, pad;
-    int K, Kp, M, Mp;
-};
-
-__global__ __launch_bounds__(256) void im2col_kernel(ColArgs a, float *__restrict__ col, int transposed)
+// split-K epilogue: out = act(bias[r] + sum_z slab[z][r][c]) scattered to the NCHW output(s)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int z, int rows, int cols,
+                                                            const float *__restrict__ bias, int act, int hw, int split,
+                                                            float *__restrict__ out, float *__restrict__ out2)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int m, k;
-    if (!transposed) {
-        if (idx >= (size_t)a.M * a.Kp) return;
-        m = (int)(idx / a.Kp);
-        k = (int)(idx - (size_t)m * a.Kp);
-    } else {
-        if (idx >= (size_t)a.Kp * a.Mp) return;
-        k = (int)(idx / a.Mp);
-        m = (int)(idx - (size_t)k * a.Mp);
-    }
-    float v = 0.0f;
-    if (k < a.K && m < a.M) {
-        int kk = a.ksize * a.ksize;
-        int ci = k / kk, rem = k - ci * kk, ky = rem / a.ksize, kx = rem - ky * a.ksize;
-        int howo = a.Ho * a.Wo;
-        int b = m / howo, p = m - b * howo, oy = p / a.Wo, ox = p - oy * a.Wo;
-        int iy = oy * a.stride + ky - a.pad, ix = ox * a.stride + kx - a.pad;
-        if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-            if (ci < a.C0) {
-                v = a.src0[(((size_t)b * a.C0 + ci) * a.H + iy) * a.W + ix];
-            } else {
-                size_t o = (((size_t)b * a.C1 + (ci - a.C0)) * a.H + iy) * a.W + ix;
-                v = a.src1[o];
-                if (a.gate1) v *= a.gate1[o];
-            }
-        }
-    }
-    col[idx] = v;
+    if (idx >= (size_t)rows * cols) return;
+    int r = (int)(idx / cols), c = (int)(idx - (size_t)r * cols);
+    float v = bias ? bias[r] : 0.0f;
+    for (int k = 0; k < z; ++k) v += slab[((size_t)k * rows + r) * cols + c];
+    v = apply_act(v, act);
+    int img = c / hw, px = c - img * hw;
+    if (r < split) out[((size_t)img * split + r) * hw + px] = v;
+    else out2[((size_t)img * (rows - split) + (r - split)) * hw + px] = v;
 }
 
-// col2im in gather form: dx[b][ci][iy][ix] = sum over the (ky, kx, oy, ox) that read this input pixel.
-// Writes d(src0) and d(cat source 1) (the latter still multiplied into by the caller for gated inputs).
-__global__ __launch_bounds__(256) void col2im_kernel(ColArgs a, const float *__restrict__ dcol,
-                                                     float *__restrict__ d0, float *__restrict__ d1)
-{
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int Ct = a.C0 + a.C1;
-    size_t total = (size_t)a.B * Ct * a.H * a.W;
-    if (idx >= total) return;
-    int ix = (int)(idx % a.W);
-    size_t t = idx / a.W;
-    int iy = (int)(t % a.H);
-    t /= a.H;
-    int ci = (int)(t % Ct), b = (int)(t / Ct);
-    float acc = 0.0f;
-    for (int ky = 0; ky < a.ksize; ++ky) {
-        int ty = iy + a.pad - ky;
-        if (ty < 0 || ty % a.stride) continue;
-        int oy = ty / a.stride;
-        if (oy >= a.Ho) continue;
-        for (int kx = 0; kx < a.ksize; ++kx) {
-            int tx = ix + a.pad - kx;
-            if (tx < 0 || tx % a.stride) continue;
-            int ox = tx / a.stride;
-            if (ox >= a.Wo) continue;
-            int m = (b * a.Ho + oy) * a.Wo + ox;
-            int k = (ci * a.ksize + ky) * a.ksize + kx;
-            acc += dcol[(size_t)m * a.Kp + k];
-        }
-    }
-    if (ci < a.C0) {
-        if (d0) d0[(((size_t)b * a.C0 + ci) * a.H + iy) * a.W + ix] = acc;
-    } else if (d1) {
-        d1[(((size_t)b * a.C1 + (ci - a.C0)) * a.H + iy) * a.W + ix] = acc;
-    }
-}
-
-// Activation backward + re-layout of the upstream gradient of one convolution:
-//   g = dY * act'(out)    (out = post-activation: relu' = out > 0, tanh' = 1 - out^2, sigmoid' = out (1 - out))
-//   dYt [M][Np]  (dgrad operand, n contiguous)    dYn [N][Mp]  (wgrad operand, m contiguous)   db[n] += sum_m g
+// g = dout * act'(out) (out = post-activation: relu' = out > 0, tanh' = 1 - out^2, sigmoid' = out (1 - out)),
+// db[n] += sum over batch and pixels of g.   One block row per channel.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ out,
-                                                      int act, int B, int N, int HW, int Np, int Mp,
-                                                      float *__restrict__ dyt, float *__restrict__ dyn,
+                                                      int act, int B, int N, int HW, float *__restrict__ gbuf,
                                                       float *__restrict__ dbias)
 {
     __shared__ float red[256];
     int n = blockIdx.y;
     float local = 0.0f;
     int M = B * HW;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < Mp; m += gridDim.x * blockDim.x) {
-        float gval = 0.0f;
-        if (m < M) {
-            int b = m / HW, p = m - b * HW;
-            size_t o = ((size_t)b * N + n) * HW + p;
-            gval = dy[o];
-            if (act != TEF_ACT_NONE) {
-                float y = out[o];
-                if (act == TEF_ACT_RELU) gval = y > 0.0f ? gval : 0.0f;
-                else if (act == TEF_ACT_TANH) gval *= (1.0f - y * y);
-                else gval *= y * (1.0f - y);
-            }
-            if (dyt) dyt[(size_t)m * Np + n] = gval;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+        int b = m / HW, p = m - b * HW;
+        size_t o = ((size_t)b * N + n) * HW + p;
+        float gval = dy[o];
+        if (act != TEF_ACT_NONE) {
+            float y = out[o];
+            if (act == TEF_ACT_RELU) gval = y > 0.0f ? gval : 0.0f;
+            else if (act == TEF_ACT_TANH) gval *= (1.0f - y * y);
+            else gval *= y * (1.0f - y);
+            gbuf[o] = gval;
         }
-        if (dyn) dyn[(size_t)n * Mp + m] = gval;
         local += gval;
     }
     if (!dbias) return;
@@ -305,37 +403,34 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
     if (threadIdx.x == 0) atomicAdd(dbias + n, red[0]);
 }
 
-// zero the k-padding columns of dYt ([M][N..Np)) — tiny
-__global__ void pad_zero_kernel(float *__restrict__ dyt, int M, int N, int Np)
-{
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int w = Np - N;
-    if (w <= 0 || idx >= (size_t)M * w) return;
-    int m = (int)(idx / w), j = (int)(idx - (size_t)m * w);
-    dyt[(size_t)m * Np + N + j] = 0.0f;
-}
-
-// weights [N][K] -> padded [N][Kp] (forward operand) and transposed [Kp][Np] (dgrad operand)
-// `rows` weight rows (a whole nn.Conv2d parameter, or one part of a row-concatenated one) go to rows
-// [row0, row0 + rows) of the packed operands; the last part also zero-fills the n-padding of wt.
+// weight part [rows][Ct][ks][ks] -> rows [row0, row0 + rows) of
+//   wp [N][Kp]      k  = (ci, ky, kx)   forward A operand
+//   w2 [Ct][K2p]    k' = (n, ky, kx)    input-gradient A operand
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int rows, int row0, int N,
-                                                          int K, int Kp, int Np, float *__restrict__ wp,
-                                                          float *__restrict__ wt)
+                                                          int Ct, int kk, int Kp, int K2p, float *__restrict__ wp,
+                                                          float *__restrict__ w2)
 {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = Ct * kk;
     if (idx < (size_t)rows * Kp) {
         int n = (int)(idx / Kp), k = (int)(idx - (size_t)n * Kp);
         wp[(size_t)(row0 + n) * Kp + k] = k < K ? w[(size_t)n * K + k] : 0.0f;
     }
-    int ncols = (row0 + rows == N) ? Np - row0 : rows;      // columns of wt this part is responsible for
-    if (idx < (size_t)Kp * ncols) {
-        int k = (int)(idx / ncols), n = (int)(idx - (size_t)k * ncols);
-        wt[(size_t)k * Np + row0 + n] = (k < K && n < rows) ? w[(size_t)n * K + k] : 0.0f;
+    // w2 columns owned by this part: n in [row0, row0 + rows) (+ the zero padding when it is the last part)
+    int c_lo = row0 * kk, c_hi = (row0 + rows == N) ? K2p : (row0 + rows) * kk;
+    int wcols = c_hi - c_lo;
+    if (idx < (size_t)Ct * wcols) {
+        int ci = (int)(idx / wcols), c = c_lo + (int)(idx - (size_t)ci * wcols);
+        float v = 0.0f;
+        if (c < N * kk) {
+            int n = c / kk, r = c - n * kk;
+            v = w[((size_t)(n - row0) * Ct + ci) * kk + r];
+        }
+        w2[(size_t)ci * K2p + c] = v;
     }
 }
 
 // ConvGRU state update (models/submodules.py:150) and its backward.
-//   h' = h * (1 - u) + o * u
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ h, const float *__restrict__ u,
                                                         const float *__restrict__ o, size_t n, float *__restrict__ out)
 {
@@ -345,7 +440,6 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict_
     out[i] = h[i] * (1.0f - uu) + o[i] * uu;
 }
 
-// given dh' : dh = dh' * (1 - u) (direct path), du = dh' * (o - h), do = dh' * u
 __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float *__restrict__ dhn, const float *__restrict__ h,
                                                             const float *__restrict__ u, const float *__restrict__ o,
                                                             size_t n, float *__restrict__ dh, float *__restrict__ du,
@@ -359,25 +453,28 @@ __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float *__restr
     dout[i] = g * uu;
 }
 
-// split-K epilogue of the forward GEMM: out[b][n][p] = act(bias[n] + sum_z slab[z][n][m]),  m = b * hw + p
-__global__ __launch_bounds__(256) void splitk_fwd_reduce_kernel(const float *__restrict__ slab, int z, int rows,
-                                                                int cols, const float *__restrict__ bias, int act,
-                                                                int hw, float *__restrict__ out)
-{
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * cols) return;
-    int r = (int)(idx / cols), c = (int)(idx - (size_t)r * cols);
-    float v = bias ? bias[r] : 0.0f;
-    for (int k = 0; k < z; ++k) v += slab[((size_t)k * rows + r) * cols + c];
-    int img = c / hw, px = c - img * hw;
-    out[((size_t)img * rows + r) * hw + px] = apply_act(v, act);
-}
-
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// forward GEMMs of the deep levels have few output tiles (M = B*h*w = 512 at 8x8) and a long K (up to 9216):
-// split K over blockIdx.z so that the launch covers the chip, then reduce the slabs with the bias/activation.
-inline int fwd_splits(int rows, int cols, int K)
+template <int AM, int BM, int EPI>
+int launch_gemm(const GemmArgs &g, int zsplits, hipStream_t st)
+{
+    dim3 block(256);
+    if (g.rows > 64) {
+        dim3 grid((g.cols + 127) / 128, (g.rows + 127) / 128, zsplits);
+        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AM, BM, EPI>), grid, block, 0, st, g);
+    } else if (g.rows > 32) {
+        dim3 grid((g.cols + 127) / 128, (g.rows + 63) / 64, zsplits);
+        hipLaunchKernelGGL((gemm_nt_kernel<64, 128, 64, 32, AM, BM, EPI>), grid, block, 0, st, g);
+    } else {
+        dim3 grid((g.cols + 127) / 128, (g.rows + 31) / 32, zsplits);
+        hipLaunchKernelGGL((gemm_nt_kernel<32, 128, 32, 32, AM, BM, EPI>), grid, block, 0, st, g);
+    }
+    return tef::check_launch("gemm_nt_kernel");
+}
+
+// GEMMs with few output tiles and a long reduction (deep levels: M = B*h*w = 512 at 8x8, K up to 9216) are split over
+// the reduction so that the launch covers the chip; the slabs are reduced together with the epilogue.
+inline int k_splits(int rows, int cols, int K)
 {
     int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
     int tiles = ((cols + 127) / 128) * ((rows + tr - 1) / tr);
@@ -389,58 +486,55 @@ inline int fwd_splits(int rows, int cols, int K)
     return z < 1 ? 1 : z;
 }
 
-template <int EPI>
-int launch_gemm(const GemmArgs &g, int zsplits, hipStream_t st)
-{
-    // tile rows follow the (small) channel dimension, tile columns the long one
-    dim3 block(256);
-    if (g.rows > 64) {
-        dim3 grid((g.cols + 127) / 128, (g.rows + 127) / 128, zsplits);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, EPI>), grid, block, 0, st, g);
-    } else if (g.rows > 32) {
-        dim3 grid((g.cols + 127) / 128, (g.rows + 63) / 64, zsplits);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 128, 64, 32, EPI>), grid, block, 0, st, g);
-    } else {
-        dim3 grid((g.cols + 127) / 128, (g.rows + 31) / 32, zsplits);
-        hipLaunchKernelGGL((gemm_nt_kernel<32, 128, 32, 32, EPI>), grid, block, 0, st, g);
-    }
-    return tef::check_launch("gemm_nt_kernel");
-}
+struct Geo {
+    int Ct, Ho, Wo, kk, K, Kp, K2, K2p, M, Mp, Min;   // M = output pixels, Min = input pixels
+};
 
-bool fill_col(const tef_conv_desc *d, ColArgs *a)
+bool make_geo(const tef_conv_desc *d, Geo *q)
 {
     if (!d || d->B < 1 || d->C0 < 1 || d->C1 < 0 || d->N < 1 || d->H < 1 || d->W < 1) return tef::fail("tef_conv: bad shape");
     if (d->ksize != 1 && d->ksize != 3) return tef::fail("tef_conv: kernel size must be 1 or 3");
     if (d->stride != 1 && d->stride != 2) return tef::fail("tef_conv: stride must be 1 or 2");
-    a->C0 = d->C0; a->C1 = d->C1; a->B = d->B; a->H = d->H; a->W = d->W;
-    a->ksize = d->ksize; a->stride = d->stride; a->pad = d->ksize / 2;
-    a->Ho = (d->H + 2 * a->pad - d->ksize) / d->stride + 1;
-    a->Wo = (d->W + 2 * a->pad - d->ksize) / d->stride + 1;
-    a->K = (d->C0 + d->C1) * d->ksize * d->ksize;
-    a->Kp = round_up(a->K, 16);
-    a->M = d->B * a->Ho * a->Wo;
-    a->Mp = round_up(a->M, 16);
-    a->src0 = a->src1 = a->gate1 = nullptr;
+    int pad = d->ksize / 2;
+    q->Ct = d->C0 + d->C1;
+    q->Ho = (d->H + 2 * pad - d->ksize) / d->stride + 1;
+    q->Wo = (d->W + 2 * pad - d->ksize) / d->stride + 1;
+    q->kk = d->ksize * d->ksize;
+    q->K = q->Ct * q->kk;
+    q->Kp = round_up(q->K, BK);
+    q->K2 = d->N * q->kk;
+    q->K2p = round_up(q->K2, BK);
+    q->M = d->B * q->Ho * q->Wo;
+    q->Mp = round_up(q->M, BK);
+    q->Min = d->B * d->H * d->W;
     return true;
 }
 
 struct ConvLayout {
-    size_t col, dyt, dyn, slab, total;
+    size_t gbuf, slab, total;
 };
 
-ConvLayout conv_layout(const tef_conv_desc *d, const ColArgs &a)
+ConvLayout conv_layout(const tef_conv_desc *d, const Geo &q)
 {
     ConvLayout L;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n * sizeof(float) + 255) & ~(size_t)255; return r; };
-    int Np = round_up(d->N, 16);
-    size_t colsz = (size_t)a.Mp * a.Kp;      // covers [M][Kp] and [Kp][Mp]
-    L.col = take(colsz);
-    L.dyt = take((size_t)a.M * Np);
-    L.dyn = take((size_t)d->N * a.Mp);
-    L.slab = take((size_t)fwd_splits(d->N, a.M, a.Kp) * d->N * a.M);
+    L.gbuf = take((size_t)d->N * q.M);
+    size_t s_fwd = (size_t)k_splits(d->N, q.M, q.Kp) * d->N * q.M;
+    size_t s_bwd = (size_t)k_splits(q.Ct, q.Min, q.K2p) * q.Ct * q.Min;
+    L.slab = take(std::max(s_fwd, s_bwd));
     L.total = o;
     return L;
+}
+
+Gather forward_gather(const tef_conv_desc *d, const Geo &q, const float *x0, const float *x1, const float *gate1)
+{
+    Gather G{};
+    G.src0 = x0; G.src1 = x1; G.gate1 = gate1;
+    G.C0 = d->C0; G.C1 = d->C1; G.SH = d->H; G.SW = d->W; G.OH = q.Ho; G.OW = q.Wo;
+    G.ks = d->ksize; G.pad = d->ksize / 2; G.mul = d->stride; G.div = 1; G.sgn = 1;
+    G.K = q.K; G.npix = q.M;
+    return G;
 }
 
 }  // namespace
@@ -449,130 +543,130 @@ extern "C" {
 
 size_t tef_conv_workspace_bytes(const tef_conv_desc *d)
 {
-    ColArgs a;
-    if (!fill_col(d, &a)) return 0;
-    return conv_layout(d, a).total;
+    Geo q;
+    if (!make_geo(d, &q)) return 0;
+    return conv_layout(d, q).total;
 }
 
-size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, size_t *wt_floats)
+size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, size_t *w2_floats)
 {
-    ColArgs a;
-    if (!fill_col(d, &a)) return 0;
-    size_t np_ = (size_t)d->N * a.Kp, nt = (size_t)a.Kp * round_up(d->N, 16);
+    Geo q;
+    if (!make_geo(d, &q)) return 0;
+    size_t np_ = (size_t)d->N * q.Kp, n2 = (size_t)q.Ct * q.K2p;
     if (wp_floats) *wp_floats = np_;
-    if (wt_floats) *wt_floats = nt;
-    return np_ + nt;
+    if (w2_floats) *w2_floats = n2;
+    return np_ + n2;
 }
 
-int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, int row0, float *wp, float *wt,
+int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, int row0, float *wp, float *w2,
                          void *stream)
 {
-    ColArgs a;
-    if (!fill_col(d, &a)) return TEF_ERR_INVALID;
-    if (!weight || !wp || !wt || rows < 1 || row0 < 0 || row0 + rows > d->N)
+    Geo q;
+    if (!make_geo(d, &q)) return TEF_ERR_INVALID;
+    if (!weight || !wp || !w2 || rows < 1 || row0 < 0 || row0 + rows > d->N)
         return tef::fail("tef_conv_pack_weight: bad arguments"), TEF_ERR_INVALID;
-    int Np = round_up(d->N, 16);
-    size_t n = std::max((size_t)rows * a.Kp, (size_t)a.Kp * (Np - row0));
+    int c_lo = row0 * q.kk, c_hi = (row0 + rows == d->N) ? q.K2p : (row0 + rows) * q.kk;
+    size_t n = std::max((size_t)rows * q.Kp, (size_t)q.Ct * (c_hi - c_lo));
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
-                       rows, row0, d->N, a.K, a.Kp, Np, wp, wt);
+                       rows, row0, d->N, q.Ct, q.kk, q.Kp, q.K2p, wp, w2);
     return tef::check_launch("pack_weight_kernel");
 }
 
 int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
                      const float *bias, float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
-    ColArgs a;
-    if (!fill_col(d, &a)) return TEF_ERR_INVALID;
+    Geo q;
+    if (!make_geo(d, &q)) return TEF_ERR_INVALID;
     if (!x0 || (d->C1 > 0 && !x1) || !wp || !out || !workspace) return tef::fail("tef_conv_forward: null pointer"), TEF_ERR_INVALID;
-    ConvLayout L = conv_layout(d, a);
+    ConvLayout L = conv_layout(d, q);
     if (workspace_bytes < L.total) return tef::fail("tef_conv_forward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    float *col = (float *)(ws + L.col);
-    a.src0 = x0; a.src1 = x1; a.gate1 = gate1;
-    {
-        size_t n = (size_t)a.M * a.Kp;
-        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, col, 0);
-        if (int rc = tef::check_launch("im2col_kernel")) return rc;
-    }
     GemmArgs g{};
-    g.A = wp; g.lda = a.Kp; g.rows = d->N;
-    g.B = col; g.ldb = a.Kp; g.cols = a.M;
-    g.K = a.Kp; g.C = out; g.bias = bias; g.act = d->act; g.hw = a.Ho * a.Wo;
-    int z = fwd_splits(d->N, a.M, a.Kp);
+    g.A = wp; g.lda = q.Kp; g.rows = d->N;
+    g.G = forward_gather(d, q, x0, x1, gate1);
+    g.cols = q.M; g.K = q.Kp;
+    g.C = out; g.C2 = nullptr; g.split = d->N; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
+    int z = k_splits(d->N, q.M, q.Kp);
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
-    if (z == 1) return launch_gemm<EPI_FWD>(g, 1, st);
+    if (z == 1) return launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st);
     float *slab = (float *)(ws + L.slab);
-    g.C = slab; g.ldc = a.M; g.valid_cols = a.M;
-    g.ksplit = round_up((a.Kp + z - 1) / z, BK);
-    z = (a.Kp + g.ksplit - 1) / g.ksplit;
-    if (int rc = launch_gemm<EPI_SLAB>(g, z, st)) return rc;
-    size_t n = (size_t)d->N * a.M;
-    hipLaunchKernelGGL(splitk_fwd_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, a.M,
-                       bias, d->act, a.Ho * a.Wo, out);
-    return tef::check_launch("splitk_fwd_reduce_kernel");
+    g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
+    g.ksplit = round_up((q.Kp + z - 1) / z, BK);
+    z = (q.Kp + g.ksplit - 1) / g.ksplit;
+    if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_SLAB>(g, z, st)) return rc;
+    size_t n = (size_t)d->N * q.M;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
+                       d->act, q.Ho * q.Wo, d->N, out, (float *)nullptr);
+    return tef::check_launch("splitk_reduce_kernel");
 }
 
-int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
-                      const float *wt, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
-                      float *dbias, void *workspace, size_t workspace_bytes, void *stream)
+int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *w2,
+                      const float *out, const float *dout, float *dx0, float *dx1, float *dweight, float *dbias,
+                      void *workspace, size_t workspace_bytes, void *stream)
 {
-    ColArgs a;
-    if (!fill_col(d, &a)) return TEF_ERR_INVALID;
+    Geo q;
+    if (!make_geo(d, &q)) return TEF_ERR_INVALID;
     if (!x0 || (d->C1 > 0 && !x1) || !dout || !workspace) return tef::fail("tef_conv_backward: null pointer"), TEF_ERR_INVALID;
     if (d->act != TEF_ACT_NONE && !out) return tef::fail("tef_conv_backward: activation needs the forward output"), TEF_ERR_INVALID;
-    ConvLayout L = conv_layout(d, a);
+    const bool need_dx = dx0 || dx1;
+    if (need_dx && !w2) return tef::fail("tef_conv_backward: input gradient needs the packed weight w2"), TEF_ERR_INVALID;
+    if (need_dx && ((d->C1 > 0) != (dx1 != nullptr) || !dx0))
+        return tef::fail("tef_conv_backward: dx0 and dx1 must be requested together"), TEF_ERR_INVALID;
+    ConvLayout L = conv_layout(d, q);
     if (workspace_bytes < L.total) return tef::fail("tef_conv_backward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    float *col = (float *)(ws + L.col);
-    float *dyt = (float *)(ws + L.dyt), *dyn = (float *)(ws + L.dyn);
-    if ((dx0 || dx1) && !wt) return tef::fail("tef_conv_backward: input gradient needs the packed transposed weight"), TEF_ERR_INVALID;
-    a.src0 = x0; a.src1 = x1; a.gate1 = gate1;
-    const int N = d->N, Np = round_up(N, 16), HW = a.Ho * a.Wo;
-    const bool need_dx = dx0 || dx1;
+    float *gbuf = (float *)(ws + L.gbuf), *slab = (float *)(ws + L.slab);
+    const int N = d->N, HW = q.Ho * q.Wo;
+    const float *gsrc = dout;
 
-    {   // g = dY * act'(out) in both operand layouts (+ bias gradient)
-        dim3 grid((unsigned)std::min<size_t>(64, (a.Mp + 255) / 256), N);
-        hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, out, d->act, d->B, N, HW, Np, a.Mp,
-                           need_dx ? dyt : nullptr, dweight ? dyn : nullptr, dbias);
+    if (d->act != TEF_ACT_NONE || dbias) {   // g = dY * act'(out) (+ bias gradient)
+        dim3 grid((unsigned)std::min<size_t>(64, ((size_t)q.M + 255) / 256), N);
+        hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, out, d->act, d->B, N, HW, gbuf, dbias);
         if (int rc = tef::check_launch("act_bwd_kernel")) return rc;
+        if (d->act != TEF_ACT_NONE) gsrc = gbuf;
     }
-    if (dweight) {   // dW[n][k] += sum_m g[n][m] col[m][k]
-        size_t n = (size_t)a.Kp * a.Mp;
-        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, col, 1);
-        if (int rc = tef::check_launch("im2col_kernel(T)")) return rc;
+    if (dweight) {   // dW[n][k] += sum_m g[n][m] * x_gather[m][k]
         GemmArgs g{};
-        g.A = dyn; g.lda = a.Mp; g.rows = N;
-        g.B = col; g.ldb = a.Mp; g.cols = a.Kp;
-        g.K = a.Mp; g.C = dweight; g.ldc = a.K; g.valid_cols = a.K;
-        // split the long reduction (m) so that the launch fills the chip
-        int tiles = ((a.Kp + 127) / 128) * ((N + 127) / 128);
+        g.A = gsrc; g.rows = N; g.hwA = HW;
+        g.G = forward_gather(d, q, x0, x1, gate1);
+        g.cols = q.Kp; g.K = q.Mp;
+        g.C = dweight; g.ldc = q.K; g.valid_cols = q.K;
+        int tiles = ((q.Kp + 127) / 128) * ((N + 127) / 128);
         int want = std::max(1, 512 / std::max(1, tiles));
-        int ks = round_up((a.Mp + want - 1) / want, BK);
-        if (ks < 256) ks = std::min(256, a.Mp);
+        int ks = round_up((q.Mp + want - 1) / want, BK);
+        if (ks < 256) ks = std::min(256, q.Mp);
         g.ksplit = ks;
-        int z = (a.Mp + ks - 1) / ks;
+        int z = (q.Mp + ks - 1) / ks;
         tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
-        if (int rc = launch_gemm<EPI_ATOMIC>(g, z, st)) return rc;
+        if (int rc = launch_gemm<A_NCHW, B_GATHER_T, EPI_ATOMIC>(g, z, st)) return rc;
     }
-    if (need_dx) {   // dcol[m][k] = sum_n g[m][n] W[n][k], then gather back to the input layout
-        if (Np > N) {
-            size_t n = (size_t)a.M * (Np - N);
-            hipLaunchKernelGGL(pad_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dyt, a.M, N, Np);
-            if (int rc = tef::check_launch("pad_zero_kernel")) return rc;
-        }
+    if (need_dx) {   // dx[ci][m'] = sum_{n,ky,kx} W[n][ci][ky][kx] * g[n][(m' + pad - k) / stride]
         GemmArgs g{};
-        g.A = dyt; g.lda = Np; g.rows = a.M;
-        g.B = wt; g.ldb = Np; g.cols = a.Kp;
-        g.K = Np; g.C = col; g.ldc = a.Kp; g.valid_cols = a.Kp;
-        {
-            tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
-            if (int rc = launch_gemm<EPI_PLAIN>(g, 1, st)) return rc;
+        g.A = w2; g.lda = q.K2p; g.rows = q.Ct;
+        Gather G{};
+        G.src0 = gsrc; G.src1 = nullptr; G.gate1 = nullptr;
+        G.C0 = N; G.C1 = 0; G.SH = q.Ho; G.SW = q.Wo; G.OH = d->H; G.OW = d->W;
+        G.ks = d->ksize; G.pad = d->ksize / 2; G.mul = 1; G.div = d->stride; G.sgn = -1;
+        G.K = q.K2; G.npix = q.Min;
+        g.G = G;
+        g.cols = q.Min; g.K = q.K2p;
+        g.C = dx0; g.C2 = dx1; g.split = d->C0; g.bias = nullptr; g.act = TEF_ACT_NONE; g.hw = d->H * d->W;
+        int z = k_splits(q.Ct, q.Min, q.K2p);
+        tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
+        if (z == 1) {
+            if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st)) return rc;
+        } else {
+            g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
+            g.ksplit = round_up((q.K2p + z - 1) / z, BK);
+            z = (q.K2p + g.ksplit - 1) / g.ksplit;
+            if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_SLAB>(g, z, st)) return rc;
+            size_t n = (size_t)q.Ct * q.Min;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min,
+                               (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1);
+            if (int rc = tef::check_launch("splitk_reduce_kernel")) return rc;
         }
-        size_t n = (size_t)d->B * (d->C0 + d->C1) * d->H * d->W;
-        hipLaunchKernelGGL(col2im_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, col, dx0, dx1);
-        if (int rc = tef::check_launch("col2im_kernel")) return rc;
     }
     return 0;
 }

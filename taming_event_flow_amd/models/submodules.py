@@ -94,8 +94,9 @@ class _ConvFn(torch.autograd.Function):
         need = ctx.needs_input_grad          # (packer, stride, act, nw, x0, x1, gate1, *weights, *biases)
         dout = dout.contiguous()
         dev = dout.device
-        dx0 = torch.empty_like(x0) if need[4] else None
-        dxg = torch.empty_like(x1) if has_x1 and (need[5] or need[6]) else None
+        need_dx = need[4] or (has_x1 and (need[5] or need[6]))      # the kernel produces dx0 and dx1 together
+        dx0 = torch.empty_like(x0) if need_dx else None
+        dxg = torch.empty_like(x1) if (has_x1 and need_dx) else None
         need_w = any(need[7:7 + nw])
         need_b = has_bias and any(need[7 + nw:])
         dw = torch.zeros((d.N,) + ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
@@ -106,6 +107,8 @@ class _ConvFn(torch.autograd.Function):
                                    dout.data_ptr(), _ptr(dx0), _ptr(dxg), _ptr(dw), _ptr(db), ws.data_ptr(), nbytes,
                                    _lib.stream_ptr())
         _lib.check(rc, "tef_conv_backward")
+        if not need[4]:
+            dx0 = None
         dx1 = dgate = None
         if dxg is not None:
             if has_gate:
