@@ -62,6 +62,20 @@ def make_cfg(a):
     }
 
 
+def pmc_traffic(a):
+    """HBM bytes per launch measured with rocprofv3 PMC counters (profiles/r01_pmc_traffic.json), only when the
+    benchmark runs the exact configuration they were collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        d = json.load(f)
+    c = d["config"]
+    same = (c["batch"] == a.batch and c["passes"] == a.passes and c["heads"] == a.heads and c["events"] == a.events
+            and c["detached"] == a.detached and list(c["res"]) == list(a.res) and c["warping"] == a.warping)
+    return {k: v["traffic_bytes"] for k, v in d["kernels"].items()} if same else {}
+
+
 def algorithmic_bytes(a, delta):
     """Per-launch algorithmic bytes of each kernel for the Iterative window."""
     B, P, F, N, Nd = a.batch, a.passes, a.heads, a.events, a.detached
@@ -152,13 +166,13 @@ def main():
         staged.append((L, flows))
 
     def step(k):
+        # loss forward + backward w.r.t. the F*P flow tensors; autograd.grad hands the gradient
+        # views back directly (leaf .grad accumulation would add 40 copy kernels that a training loop never runs:
+        # there the flows are network outputs, not leaves)
         L, flows = staged[k % len(staged)]
-        for row in flows:           # like optimizer.zero_grad(set_to_none=True): no gradient-accumulate kernels
-            for f in row:
-                f.grad = None
         loss = L()
-        loss.backward()
-        return loss
+        grads = torch.autograd.grad(loss, [f for row in flows for f in row])
+        return loss, grads
 
     def barrier():
         if dist:
@@ -171,7 +185,7 @@ def main():
     lib.tef_profile_enable(0 if a.no_kernel_events else 1)       # HIP events around every kernel, on the launch stream
     t0 = time.perf_counter()
     for k in range(a.steps):
-        last = step(k)
+        last, last_grads = step(k)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (diagnostic: host- vs device-bound)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -183,6 +197,7 @@ def main():
             kern[lib.tef_profile_name(s).decode()] = (lib.tef_profile_ms(s) / n, n)
     lib.tef_profile_enable(0)
     loss_val = float(last.item())
+    assert all(torch.isfinite(g_).all().item() for g_ in last_grads[:4])
 
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -203,12 +218,13 @@ def main():
                 e["algorithmic_bytes"] = alg[name]
                 e["GBps"] = round(alg[name] / (ms * 1e-3) / 1e9, 1)
             kernels[name] = e
+        traffic = pmc_traffic(a)
         dominant = max(kern, key=lambda k_: kern[k_][0] * kern[k_][1]) if kern else None
         roofline = None
         if dominant and dominant in alg and a.warping == "Iterative":
             ach = alg[dominant] / (kern[dominant][0] * 1e-3) / 1e9
             roofline = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(dominant)}
         out = {
             "metric": "events/sec through IWE+contrast-max loss, 128x128 bs=8",
             "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -228,7 +244,8 @@ def main():
         if "iwe_splat" in kernels and "GBps" in kernels["iwe_splat"]:
             out["roofline_scatter"] = {
                 "kernel": "iwe_splat", "bound": "hbm", "achieved": kernels["iwe_splat"]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4),
+                "traffic": traffic.get("iwe_splat"),
                 "splats_per_launch": splats}
         if not a.no_cpu_baseline and a.warping == "Iterative":
             out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
