@@ -170,15 +170,15 @@ __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
 struct Quad2 { float2 v00, v01, v10, v11; };
 
 // two horizontally adjacent float2 pixels in one 16-byte load (global_load_dwordx4 only needs 4-byte alignment)
-struct __attribute__((aligned(8))) Pair2 { float2 a, b; };
+typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
 __device__ __forceinline__ void load_row(const float2 *__restrict__ map, int i0, int i1, float2 &v0, float2 &v1)
 {
     const float2 z = make_float2(0.0f, 0.0f);
     if (i0 >= 0 && i1 >= 0) {
-        Pair2 p = *reinterpret_cast<const Pair2 *>(map + i0);
-        v0 = p.a;
-        v1 = p.b;
+        f32x4_a8 p = *reinterpret_cast<const f32x4_a8 *>(map + i0);
+        v0 = make_float2(p.x, p.y);
+        v1 = make_float2(p.z, p.w);
     } else {
         v0 = i0 >= 0 ? map[i0] : z;
         v1 = i1 >= 0 ? map[i1] : z;
@@ -627,6 +627,9 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
                                                      int k, float gout, float2 p, float ts, float mp, float mn)
 {
     float2 g = make_float2(0.0f, 0.0f);
+#ifdef TEF_ABL_NOIWE
+    return make_float2(p.x * 1e-9f, p.y * 1e-9f);       // diagnostic build: no IWE lookups
+#endif
     for (int s = 0; s < w.S; ++s) {
         if (!((bits >> s) & 1u)) continue;
         int scale = w.P >> s, wi = t / scale;
@@ -650,7 +653,10 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
 // adjoint picks up (I + dt * J^T) per step, and every step leaves dt * adjoint as the gradient of the
 // sampled flow vector.  cy/cx[(ib*P + k)*M + sl] = d/d f_y, d/d f_x of this event's sample of map k.
 // =============================================================================================
-__global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
+#ifndef TEF_CHAIN_WAVES
+#define TEF_CHAIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
                                                              const uint32_t *__restrict__ meta,
                                                              const float2 *__restrict__ ar,
@@ -695,10 +701,12 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
             float2 nn = make_float2(0.0f, 0.0f);
             if (k - 2 > t) nn = tr[(size_t)(k - 2) * w.Mt];
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+#ifndef TEF_ABL_NOFLOW
             if (k - 1 > t) {
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
                 quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp), tp, jyy, jyx, jxy, jxx);
             }
+#endif
             float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
             ay += gk.x;
             ax += gk.y;
@@ -730,10 +738,12 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
             float2 nn = make_float2(0.0f, 0.0f);
             if (k + 2 <= t) nn = tr[(size_t)(k + 2) * w.Mt];
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+#ifndef TEF_ABL_NOFLOW
             if (k < t) {
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
                 quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp), tp, jyy, jyx, jxy, jxx);
             }
+#endif
             float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
             ay += gk.x;
             ax += gk.y;
@@ -1088,7 +1098,10 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, fl
     if (B < 1 || N < 0 || slot0 < 0 || slot0 + N > cap || pass_idx < 0 || pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
         return tef::fail("tef_pack_events: bad sizes"), TEF_ERR_INVALID;
     if (N == 0) return 0;
-    int tile = 8;
+#ifndef TEF_SORT_TILE
+#define TEF_SORT_TILE 8
+#endif
+    int tile = TEF_SORT_TILE;
     while (4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;
     int nbins = 4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     size_t lds = (size_t)(nbins + kPackThreads) * sizeof(int);
