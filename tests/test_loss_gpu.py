@@ -109,6 +109,31 @@ def test_empty_and_padding_only_lists(dev):
     assert rel_err(g, od) <= TOL
 
 
+@pytest.mark.parametrize("kind", ["Iterative", "Linear"])
+def test_general_float_masks(kind, dev):
+    """Polarity masks are plain float multipliers in the reference (utils/iwe.py:127-128): non-unit values and events
+    with BOTH masks set must go through the slow-path branches of the splat / gradient kernels unchanged."""
+    from oracle import oracle
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(11)
+    B, H, W, P, F = 2, 24, 28, 4, 2
+    win = synth.make_window(rng, B, H, W, P, F, 300, 120, sigma=1.5, ragged=True)
+    for key in ("pm", "dpm"):
+        for t in range(P):
+            m = win[key][t]
+            n = m.shape[1]
+            sel = rng.random((B, n)) < 0.3
+            m[..., 0] = np.where(sel, m[..., 0] * 0.5 + 0.25, m[..., 0])      # 0.75 / 0.25: both non-zero, non-unit
+            m[..., 1] = np.where(sel, m[..., 1] * 1.5 + 0.5, m[..., 1])       # 2.0 / 0.5
+            m *= (win["ev" if key == "pm" else "dev"][t][..., 3:4] != 0)      # keep collate padding at (0, 0)
+    meta = dict(H=H, W=W, B=B, P=P, S=1, mode="two", spat=None, temp=None, round_ts=False)
+    l, g, _ = run_hip(kind, make_cfg(meta), win, dev)
+    ol, od = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"]).loss(kind)
+    assert abs(l - ol) <= TOL * abs(ol), (l, float(ol))
+    assert rel_err(g, od) <= TOL
+
+
 def test_full_size_properties(dev):
     """BASELINE config (128x128, B=8, P=10, F=4, N=10k): size-independent properties instead of the slow oracle."""
     from taming_event_flow_amd import synth
