@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--mode", default="loss", choices=["loss", "train"],
                     help="loss: IWE + contrast-max loss fwd+bwd (BASELINE.json metric, configs[1]); "
                          "train: full training window, RecEVFlowNet + loss + DP all-reduce + Adam (configs[2]/[3])")
+    ap.add_argument("--graph", action="store_true", help="train mode: replay the window from a captured hipGraph")
     ap.add_argument("--windows", type=int, default=2, help="distinct pre-staged windows cycled through")
     ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
                     help="experiment: pre-sort the synthetic events of each pass on the host")
@@ -292,6 +293,8 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
     cfg["data"]["passes_loss"] = a.passes
     cfg["loss"]["warping"] = a.warping
     torch.manual_seed(1234)                      # identical initial weights on every rank
+    if a.graph:
+        cfg["optimizer"]["capturable"] = True
     tr = train.Trainer(cfg, dev)
     src = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100 + rank)
     P = a.passes
@@ -300,12 +303,17 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
         for _ in range(P):
             tr.step(src.next(), new_seq=False)
 
+    if a.graph:
+        tr.reset()
+        window = tr.capture_window([src.next() for _ in range(P)])
+
     def barrier():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    tr.reset()
+    if not a.graph:
+        tr.reset()
     for _ in range(a.warmup):
         window()
     barrier()
@@ -347,7 +355,8 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
             "config": {"workload": f"training window: {P} x (count encoding, RecEVFlowNet fwd, update) + {a.warping}/two "
                                    f"loss + BPTT backward + all-reduce(SUM) + clip + Adam, {a.res[0]}x{a.res[1]}, "
                                    f"B={a.batch}/GPU, N={a.events}+{a.detached} (BASELINE.json configs[2]/[3])",
-                       "global_batch": a.batch * world, "parallelism": f"dp{world} (RCCL all-reduce SUM of 125.5 MB grads)"},
+                       "global_batch": a.batch * world, "parallelism": f"dp{world} (RCCL all-reduce SUM of 125.5 MB grads)",
+                       "launch": "hipGraph replay of the whole window" if a.graph else "eager"},
             "loss": round(float(tr.last_loss.item()), 6),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 3),
             "conv_gflop_per_pass_fwd": round(fl_pass / 1e9, 2),

@@ -70,8 +70,10 @@ class Trainer:
         self.model.train()
         self.loss_function = eval(config["loss"]["warping"])(config, device)
         self.bucket = parallel.FlatGradBucket(self.model.parameters())
-        self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(),
-                                                                           lr=config["optimizer"]["lr"])
+        opt_kwargs = {"lr": config["optimizer"]["lr"]}
+        if config["optimizer"].get("capturable"):
+            opt_kwargs["capturable"] = True      # optimiser state stays on the device: the window can live in a hipGraph
+        self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
         self.last_grad_norm = None
 
@@ -81,10 +83,52 @@ class Trainer:
         self.model.reset_states()
         self.bucket.zero()
 
+    def capture_window(self, batches, warmup=2):
+        """Capture one whole loss window (P passes of `batches`, loss, BPTT backward, clip, optimiser step) into a
+        hipGraph and return a zero-argument replay function: ~10^3 kernel launches become one graph launch, so the
+        window is device-bound instead of host-bound.  Static shapes and buffers: the caller refreshes the contents of
+        the `batches` tensors in place before each replay.  Single-process only (the lock-step flag needs a host sync);
+        under DP the gradient all-reduce would be captured too, but the flag is exchanged outside the graph."""
+        if parallel.is_distributed():
+            raise NotImplementedError("graph capture of the DP window is not wired yet")
+        P = self.cfg["data"]["passes_loss"]
+        assert len(batches) == P
+        if warmup < 1:
+            raise ValueError("capture needs at least one eager window (allocations, recurrent state buffers)")
+        originals = [{k: v.clone() for k, v in b.items()} for b in batches]
+
+        def run():
+            for b, o in zip(batches, originals):
+                for k in b:
+                    b[k].copy_(o[k])            # update() shifts the timestamps of the caller's lists in place
+                self.step(b, new_seq=False)
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self.warmup_losses = []
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                run()
+                self.warmup_losses.append(self.last_loss)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.warmup_losses = [float(x.item()) for x in self.warmup_losses]
+        # the recurrent state lives in static buffers: the graph reads them at its start and writes the detached
+        # end-of-window state back, so consecutive replays carry the state exactly like the eager loop
+        static_states = [s.detach().clone() for s in self.model.arch.states]
+        self.model.arch.states = static_states
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+            for dst, src in zip(static_states, self.model.arch.states):
+                dst.copy_(src.detach())
+        self.model.arch.states = static_states
+        return graph.replay
+
     def step(self, inputs, new_seq=False):
         """One pass (train_flow.py:83-137).  Returns True when an optimiser step happened."""
         cfg = self.cfg
-        if parallel.any_rank(new_seq, self.device):
+        if new_seq is not False and parallel.any_rank(new_seq, self.device):
             self.reset()
         x = self.model(inputs["net_input"])
         flows = [f * cfg["loss"]["flow_scaling"] for f in x["flow"]]

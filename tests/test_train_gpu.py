@@ -53,3 +53,47 @@ def test_two_window_trace():
         assert np.abs(delta - ref).max() <= 5e-2 * ref.max(), win
         assert tr.loss_function.num_passes == 0
         assert all(s is not None and not s.requires_grad for s in tr.model.arch.states)
+
+
+def test_graph_replay_matches_eager():
+    """A loss window captured into a hipGraph (Trainer.capture_window) reproduces the eager window."""
+    import copy
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import train
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"].update(batch_size=2, resolution=[32, 32], max_num_grad_events=300)
+    cfg["data"]["passes_loss"] = 3
+    cfg["optimizer"].update(lr=1e-4, capturable=True)
+
+    def fresh():
+        torch.manual_seed(7)
+        tr = train.Trainer(cfg, dev)
+        src = train.SyntheticSequences(cfg, dev, 380, seq_len=10 ** 9, seed=3)
+        tr.reset()
+        return tr, [src.next() for _ in range(3)]
+
+    tr_e, batches = fresh()
+    losses_e = []
+    for _ in range(3):
+        for b in batches:
+            tr_e.step({k: v.clone() for k, v in b.items()}, new_seq=False)
+        losses_e.append(float(tr_e.last_loss.item()))
+
+    tr_g, batches = fresh()
+    replay = tr_g.capture_window(batches, warmup=1)      # window 1 runs eagerly, then the window is captured
+    l1 = tr_g.warmup_losses[0]
+    replay()
+    torch.cuda.synchronize()
+    l2 = float(tr_g.last_loss.item())
+    replay()
+    torch.cuda.synchronize()
+    l3 = float(tr_g.last_loss.item())
+    assert abs(l1 - losses_e[0]) <= 1e-5 * abs(losses_e[0]), (l1, losses_e)
+    assert abs(l2 - losses_e[1]) <= 1e-3 * abs(losses_e[1]), (l2, losses_e)      # state + weights carried over
+    assert abs(l3 - losses_e[2]) <= 1e-3 * abs(losses_e[2]), (l3, losses_e)
+    assert len({l1, l2, l3}) == 3
