@@ -114,14 +114,32 @@ __device__ __forceinline__ float gather_value(const Gather &G, const Pix &q, int
     return v;
 }
 
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 // TR x TC workgroup tile, WR x WC wave tile (multiples of 32), 256 threads.
+//
+// Operand staging (the part that decides the speed of an implicit GEMM):
+//   A, plain:        float4 along k, LDS row-major [TR][BK+4], fragments by ds_read_b128.
+//   A, NCHW (wgrad): g[n][(b, p)], float4 along the pixels when an image is a multiple of 4 pixels.
+//   B, gather:       a thread owns a QUAD of 4 consecutive output pixels and one k per load: for stride-1 convolutions
+//                    the 4 source elements are contiguous, so the im2col gather is ONE 16-byte load (wave-coalesced
+//                    along the pixels), staged k-major [BK][TC+4] with one ds_write_b128.  The 9 tap offsets of every
+//                    pixel live in an LDS table; (ci, tap) advance incrementally.  Quads that touch the padding, cross
+//                    a row, or belong to strided / transposed-strided geometry fall back to 4 predicated loads.
+//   B, gather^T (wgrad): the tile row is a fixed (ci, ky, kx), the reduction walks over pixels; same 16-byte trick,
+//                    LDS row-major [TC][BK+4].
 template <int TR, int TC, int WR, int WC, int AM, int BM, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 {
     static_assert((TR / WR) * (TC / WC) == 4, "4 waves per workgroup");
+    static_assert(TC == 128 && BK == 32, "the quad staging below is written for 128 columns x 32 k");
     constexpr int MR = WR / 32, MC = WC / 32;          // MFMA tiles per wave
+    constexpr int LDB = TC + 4;                        // k-major B rows (floats), 16-byte multiple
+    constexpr int BFLOATS = (BM == B_GATHER) ? BK * LDB : TC * LDK;
     __shared__ __attribute__((aligned(16))) float As[2][TR][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TC][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BFLOATS];
+    __shared__ __attribute__((aligned(16))) int soff[BM == B_GATHER ? 9 : 1][BM == B_GATHER ? TC : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / (TC / WC), wc = wave % (TC / WC);
@@ -132,23 +150,59 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         k_end = min(g.K, k_begin + g.ksplit);
         if (k_begin >= k_end) return;
     }
-
-    // staging: each thread moves 4-float pieces (tile row = piece / PPR, k offset = 4 * (piece % PPR))
-    constexpr int AP = (TR * PPR + 255) / 256, BP = (TC * PPR + 255) / 256;
-    float4 ra[AP], rb[BP];
     const int SHW = g.G.SH * g.G.SW;
     const int kk2 = g.G.ks * g.G.ks;
+    const int Ct = g.G.C0 + g.G.C1;
 
-    // B_GATHER: per tile row (= output pixel) the 9 (ky, kx) source offsets are tabulated once in LDS (-1 = padding /
-    // stride miss); the (ci, r = ky * 3 + kx) decomposition of k is advanced incrementally, so the per-element cost
-    // of the implicit im2col is one LDS read, a compare and an add instead of divisions and bounds tests.
-    __shared__ int soff[BM == B_GATHER ? TC : 1][BM == B_GATHER ? 9 : 1];
-    int pb0[BP], pb1[BP];      // batch base offsets of the two sources for this piece's pixel
-    int ci0[BP], r0[BP];       // (ci, r) of element 0 of the piece at the current k0
+    // ---- A staging: 4-float pieces (tile row = piece / PPR, k offset = 4 * (piece % PPR)) ----
+    constexpr int AP = (TR * PPR + 255) / 256;
+    float4 ra[AP];
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int piece = tid + p * 256;
+            int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
+            bool ok = (TR * PPR % 256 == 0 || piece < TR * PPR) && (row0 + r) < g.rows;
+            if (AM == A_PLAIN) {
+                ra[p] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(row0 + r) * g.lda + k0 + kq)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {            // A[r][kk], kk = (image, pixel) of an NCHW tensor with `rows` channels
+                int kk = k0 + kq;
+                int img = kk / g.hwA, px = kk - img * g.hwA;
+                if (ok && (g.hwA & 3) == 0 && kk + 3 < g.G.npix) {
+                    ra[p] = *reinterpret_cast<const float4 *>(g.A + ((size_t)img * g.rows + row0 + r) * g.hwA + px);
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = (ok && kk + j < g.G.npix) ? g.A[((size_t)img * g.rows + row0 + r) * g.hwA + px] : 0.0f;
+                        if (++px == g.hwA) { px = 0; ++img; }
+                    }
+                    ra[p] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int piece = tid + p * 256;
+            if (TR * PPR % 256 == 0 || piece < TR * PPR)
+                *reinterpret_cast<float4 *>(&As[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = ra[p];
+        }
+    };
+
+    // ---- B staging ----
+    constexpr int BP = 4;          // loads per thread per stage in both B modes (128 x 32 floats / 256 threads / 4)
+    float4 rb[BP];
+    // B_GATHER: thread = (quad of 4 pixels, k slot); k = k0 + kslot + 8 j
+    const int quad = tid & 31, kslot = tid >> 5;
+    int qb[4];                     // image index of the quad's pixels
+    int ci0 = 0, r0 = 0;           // (ci, tap) of k = k0 + kslot
     if (BM == B_GATHER) {
         for (int t = tid; t < TC * 9; t += 256) {
-            int row = t / 9, r = t - row * 9;
-            Pix q = decode_pixel(g.G, col0 + row);
+            int r = t / TC, pix = t - r * TC;
+            Pix q = decode_pixel(g.G, col0 + pix);
             int off = -1;
             if (q.ok && r < kk2) {
                 int ky = r / g.G.ks, kx = r - ky * g.G.ks;
@@ -161,21 +215,16 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                 }
                 if (ok && ty < g.G.SH && tx < g.G.SW) off = ty * g.G.SW + tx;
             }
-            soff[row][r] = off;
+            soff[r][pix] = off;
         }
 #pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            int piece = tid + p * 256;
-            Pix q = decode_pixel(g.G, col0 + (piece >> LOGP));
-            pb0[p] = q.b * g.G.C0 * SHW;
-            pb1[p] = q.b * g.G.C1 * SHW;
-            int k = k_begin + (piece & (PPR - 1)) * 4;
-            ci0[p] = k / kk2;
-            r0[p] = k - ci0[p] * kk2;
-        }
+        for (int e = 0; e < 4; ++e) qb[e] = decode_pixel(g.G, col0 + 4 * quad + e).b;
+        int k = k_begin + kslot;
+        ci0 = k / kk2;
+        r0 = k - ci0 * kk2;
         __syncthreads();
     }
-    // B_GATHER_T: the tile row is a fixed (ci, ky, kx); the reduction index walks over output pixels
+    // B_GATHER_T: piece = (tile row = (ci, ky, kx), 4 consecutive pixels of the reduction)
     const float *tsrc[BP], *tgate[BP];
     int tky[BP], tkx[BP], tcs[BP];
     if (BM == B_GATHER_T) {
@@ -193,89 +242,95 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         }
     }
 
-    auto load_tiles = [&](int k0) {
+    auto load_b = [&](int k0) {
+        if (BM == B_GATHER) {
+            int ci = ci0, rr = r0;
 #pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            int piece = tid + p * 256;
-            int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
-            bool ok = (TR * PPR % 256 == 0 || piece < TR * PPR) && (row0 + r) < g.rows;
-            if (AM == A_PLAIN) {
-                ra[p] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(row0 + r) * g.lda + k0 + kq)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {            // A[r][kk], kk = (image, pixel) of an NCHW tensor with `rows` channels
-                float v[4];
-                int kk = k0 + kq;
-                int img = kk / g.hwA, px = kk - img * g.hwA;
+            for (int j = 0; j < BP; ++j) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ci < Ct) {
+                    i32x4 so = *reinterpret_cast<const i32x4 *>(&soff[rr][4 * quad]);
+                    bool second = ci >= g.G.C0;
+                    const float *src = second ? g.G.src1 : g.G.src0;
+                    int cs = second ? g.G.C1 : g.G.C0, cl = second ? ci - g.G.C0 : ci;
+                    bool contiguous = (so.x >= 0) & (so.y == so.x + 1) & (so.z == so.x + 2) & (so.w == so.x + 3) &
+                                      (qb[0] == qb[3]);
+                    if (contiguous) {
+                        size_t o = ((size_t)qb[0] * cs + cl) * SHW + so.x;
+                        f32x4_a4 t = *reinterpret_cast<const f32x4_a4 *>(src + o);
+                        if (second && g.G.gate1) {
+                            f32x4_a4 gt = *reinterpret_cast<const f32x4_a4 *>(g.G.gate1 + o);
+                            t *= gt;
+                        }
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+                        const int sov[4] = {so.x, so.y, so.z, so.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = (ok && kk + j < g.G.npix) ? g.A[((size_t)img * g.rows + row0 + r) * g.hwA + px] : 0.0f;
-                    if (++px == g.hwA) { px = 0; ++img; }
-                }
-                ra[p] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            int piece = tid + p * 256;
-            int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
-            bool ok = (TC * PPR % 256 == 0 || piece < TC * PPR) && (col0 + r) < g.cols;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (BM == B_GATHER) {
-                int ci = ci0[p], rr = r0[p];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int so = soff[r][rr];
-                    if (ok && so >= 0 && ci < g.G.C0 + g.G.C1) {
-                        if (ci < g.G.C0) {
-                            v[j] = g.G.src0[(size_t)pb0[p] + (size_t)ci * SHW + so];
-                        } else {
-                            size_t o = (size_t)pb1[p] + (size_t)(ci - g.G.C0) * SHW + so;
-                            float t = g.G.src1[o];
-                            v[j] = g.G.gate1 ? t * g.G.gate1[o] : t;
+                        for (int e = 0; e < 4; ++e) {
+                            if (sov[e] < 0) continue;
+                            size_t o = ((size_t)qb[e] * cs + cl) * SHW + sov[e];
+                            float t = src[o];
+                            v[e] = (second && g.G.gate1) ? t * g.G.gate1[o] : t;
                         }
                     }
-                    if (++rr == kk2) { rr = 0; ++ci; }
                 }
-                // advance (ci, r) by BK for the next stage
-                if (kk2 == 9) {
-                    ci0[p] += BK / 9;
-                    r0[p] += BK % 9;
-                    if (r0[p] >= 9) { r0[p] -= 9; ci0[p] += 1; }
-                } else {
-                    ci0[p] += BK;
-                }
-            } else if (ok && tsrc[p]) {        // B_GATHER_T
-                Pix q = decode_pixel(g.G, k0 + kq);
-                int m = k0 + kq;
+                rb[j] = make_float4(v[0], v[1], v[2], v[3]);
+                // k += 8
+                if (kk2 == 9) { rr += 8; if (rr >= 9) { rr -= 9; ++ci; } }
+                else ci += 8;
+            }
+            // k0 += BK (32) for the next stage
+            if (kk2 == 9) { ci0 += 3; r0 += 5; if (r0 >= 9) { r0 -= 9; ++ci0; } }
+            else ci0 += BK;
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (m + j < g.G.npix) {
-                        int ty = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
-                        int tx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
-                        if (ty >= 0 && tx >= 0 && ty < g.G.SH && tx < g.G.SW) {
-                            size_t o = (size_t)q.b * tcs[p] * SHW + ty * g.G.SW + tx;
-                            float t = tsrc[p][o];
-                            v[j] = tgate[p] ? t * tgate[p][o] : t;
+            for (int p = 0; p < BP; ++p) {
+                int piece = tid + p * 256;
+                int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((col0 + r) < g.cols && tsrc[p]) {
+                    int m = k0 + kq;
+                    Pix q = decode_pixel(g.G, m);
+                    int ty = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
+                    int tx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
+                    bool fast = (g.G.mul == 1) & (m + 3 < g.G.npix) & (q.px + 3 < g.G.OW) & (ty >= 0) & (ty < g.G.SH) &
+                                (tx >= 0) & (tx + 3 < g.G.SW);
+                    if (fast) {
+                        size_t o = (size_t)q.b * tcs[p] * SHW + ty * g.G.SW + tx;
+                        f32x4_a4 t = *reinterpret_cast<const f32x4_a4 *>(tsrc[p] + o);
+                        if (tgate[p]) t *= *reinterpret_cast<const f32x4_a4 *>(tgate[p] + o);
+                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (m + j < g.G.npix) {
+                                int yy = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
+                                int xx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
+                                if (yy >= 0 && xx >= 0 && yy < g.G.SH && xx < g.G.SW) {
+                                    size_t o = (size_t)q.b * tcs[p] * SHW + yy * g.G.SW + xx;
+                                    float t = tsrc[p][o];
+                                    v[j] = tgate[p] ? t * tgate[p][o] : t;
+                                }
+                            }
+                            if (++q.px == g.G.OW) { q.px = 0; if (++q.py == g.G.OH) { q.py = 0; ++q.b; } }
                         }
                     }
-                    if (++q.px == g.G.OW) { q.px = 0; if (++q.py == g.G.OH) { q.py = 0; ++q.b; } }
                 }
+                rb[p] = make_float4(v[0], v[1], v[2], v[3]);
             }
-            rb[p] = make_float4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_b = [&](int buf) {
+        if (BM == B_GATHER) {
 #pragma unroll
-        for (int p = 0; p < AP; ++p) {
-            int piece = tid + p * 256;
-            if (TR * PPR % 256 == 0 || piece < TR * PPR)
-                *reinterpret_cast<float4 *>(&As[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = ra[p];
-        }
+            for (int j = 0; j < BP; ++j)
+                *reinterpret_cast<float4 *>(&Bs[buf][(kslot + 8 * j) * LDB + 4 * quad]) = rb[j];
+        } else {
 #pragma unroll
-        for (int p = 0; p < BP; ++p) {
-            int piece = tid + p * 256;
-            if (TC * PPR % 256 == 0 || piece < TC * PPR)
-                *reinterpret_cast<float4 *>(&Bs[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = rb[p];
+            for (int p = 0; p < BP; ++p) {
+                int piece = tid + p * 256;
+                *reinterpret_cast<float4 *>(&Bs[buf][(piece >> LOGP) * LDK + (piece & (PPR - 1)) * 4]) = rb[p];
+            }
         }
     };
 
@@ -287,13 +342,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    load_tiles(k_begin);
-    store_tiles(0);
+    load_a(k_begin);
+    load_b(k_begin);
+    store_a(0);
+    store_b(0);
     __syncthreads();
     int buf = 0;
     for (int k0 = k_begin; k0 < k_end; k0 += BK) {
         bool more = (k0 + BK) < k_end;
-        if (more) load_tiles(k0 + BK);          // next stage in flight while this one is multiplied
+        if (more) {                 // next stage in flight while this one is multiplied
+            load_a(k0 + BK);
+            load_b(k0 + BK);
+        }
         // lane l feeds row/col (l & 31) and k = 4 * (l >> 5) + j of each 8-wide half stage
 #pragma unroll
         for (int kh = 0; kh < BK; kh += 8) {
@@ -302,8 +362,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
             for (int i = 0; i < MR; ++i)
                 fa[i] = *reinterpret_cast<const float4 *>(&As[buf][wr * WR + i * 32 + (lane & 31)][kh + 4 * (lane >> 5)]);
 #pragma unroll
-            for (int j = 0; j < MC; ++j)
-                fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][wc * WC + j * 32 + (lane & 31)][kh + 4 * (lane >> 5)]);
+            for (int j = 0; j < MC; ++j) {
+                if (BM == B_GATHER) {
+                    const float *bp = &Bs[buf][(kh + 4 * (lane >> 5)) * LDB + wc * WC + j * 32 + (lane & 31)];
+                    fb[j] = make_float4(bp[0], bp[LDB], bp[2 * LDB], bp[3 * LDB]);
+                } else {
+                    fb[j] = *reinterpret_cast<const float4 *>(&Bs[buf][(wc * WC + j * 32 + (lane & 31)) * LDK + kh + 4 * (lane >> 5)]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -315,7 +381,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                 }
         }
         if (more) {
-            store_tiles(buf ^ 1);
+            store_a(buf ^ 1);
+            store_b(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
