@@ -248,7 +248,7 @@ def main():
                 "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic.get("iwe_splat"),
                 "splats_per_launch": splats}
-        if not a.no_cpu_baseline and a.warping == "Iterative":
+        if not a.no_cpu_baseline and a.warping == "Iterative" and world == 1:     # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
         print(json.dumps(out), flush=True)
     if dist:

