@@ -186,6 +186,33 @@ int tef_upsample_bilinear(const float *x, int planes, int H, int W, int scale_h,
 int tef_upsample_bilinear_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
                                    float *dx, void *stream);
 
+/* ---- validation metrics (loss/flow_val.py; evaluation only, batch 1, no gradients) ---------------------------------
+ * Flow maps are planar [H][W] (fx, fy separately); event lists are loc [N][2] = (y, x), ts [N], mask [N][2]. */
+/* one warping step: flow lookup at loc (flow_out [N][2] = (f_y, f_x) if not NULL); if do_warp: loc += (tref - ts) * flow,
+ * purge_unfeasible (loc and mask zeroed when out of bounds), ts = tref.  flow_val.py:337-342, :492-517, :528-556 */
+int tef_val_event_step(const float *fx, const float *fy, int H, int W, float *loc, float *ts, float *mask, int N,
+                       float tref, int do_warp, float *flow_out, void *stream);
+/* per-polarity image of an event list, nearest pixel (round_idx, metrics) or bilinear: cnt [2][H][W] (+ tsum [2][H][W]
+ * weighted by ts when both are given).  utils/iwe.py:63-136 as used by flow_val.py:129-143, :174-187, :189-274 */
+int tef_val_event_image(const float *loc, const float *mask, const float *ts, int N, int H, int W, int round_idx,
+                        float *cnt, float *tsum, void *stream);
+/* out2 = (FWL, RSAT) from the warped and un-warped count / timestamp images.  flow_val.py:189-274 */
+int tef_val_metrics(const float *cnt_fw, const float *ts_fw, const float *cnt_zero, const float *ts_zero, int H, int W,
+                    float passes, float *out2, void *stream);
+/* forward propagation of one flow map by dt (scratch3 = 3*H*W floats).  flow_val.py:43-74 */
+int tef_val_forward_prop_flow(const float *fx, const float *fy, int H, int W, float dt, float *scratch3, float *out_x,
+                              float *out_y, void *stream);
+/* accumulated backward flow: indices [2][H][W] (y, x) walk along the newest flow.  flow_val.py:582-604 */
+int tef_val_accum_flow(const float *fx, const float *fy, int H, int W, float *indices, float *out_mask, float *acc_x,
+                       float *acc_y, void *stream);
+/* per-pixel average of P maps over the passes with non-zero flow, optional element-wise divisor [H][W] and event mask
+ * [mask_passes][H][W]; out [2][H][W] = (x, y).  flow_val.py:145-172 */
+int tef_val_average_flow(const float *maps_x, const float *maps_y, int P, int H, int W, const float *divisor,
+                         const float *event_mask, int mask_passes, float *out, void *stream);
+/* average endpoint error over pixels with valid ground truth (and events).  flow_val.py:276-314 */
+int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int mask_passes, int H, int W, float *out,
+                void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,339 @@
+// tef_val.hip — validation metrics of the reference's loss/flow_val.py (FWL, RSAT, AEE, windowed event / IWE / flow
+// images, forward-propagated and accumulated flow).  Evaluation only (batch 1, no gradients): plain one-thread-per-
+// element kernels with global float atomics for the scatters; the training hot path lives in tef_loss.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tef.h"
+#include "tef_common.h"
+
+namespace {
+
+// ---- bilinear flow lookup on planar maps: utils/iwe.py:17-40 + ATen grid_sampler_2d (align_corners=True, zeros) ----
+__device__ __forceinline__ float unnormalize(float v, int size)
+{
+    float nn = (2.0f * v) / (float)(size - 1) - 1.0f;
+    return (nn + 1.0f) * ((float)(size - 1) / 2.0f);
+}
+
+__device__ __forceinline__ void sample_flow(const float *__restrict__ fx, const float *__restrict__ fy, int H, int W,
+                                            float y, float x, float &oy, float &ox)
+{
+    float iy = unnormalize(y, H), ix = unnormalize(x, W);
+    float fy0 = floorf(iy), fx0 = floorf(ix);
+    float n = iy - fy0, w = ix - fx0, s = 1.0f - n, e = 1.0f - w;
+    int y0 = (int)fy0, x0 = (int)fx0, y1 = y0 + 1, x1 = x0 + 1;
+    bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y1 >= 0) & (y1 < H), vx0 = (x0 >= 0) & (x0 < W), vx1 = (x1 >= 0) & (x1 < W);
+    float v00y = 0, v01y = 0, v10y = 0, v11y = 0, v00x = 0, v01x = 0, v10x = 0, v11x = 0;
+    if (vy0 && vx0) { v00y = fy[y0 * W + x0]; v00x = fx[y0 * W + x0]; }
+    if (vy0 && vx1) { v01y = fy[y0 * W + x1]; v01x = fx[y0 * W + x1]; }
+    if (vy1 && vx0) { v10y = fy[y1 * W + x0]; v10x = fx[y1 * W + x0]; }
+    if (vy1 && vx1) { v11y = fy[y1 * W + x1]; v11x = fx[y1 * W + x1]; }
+    oy = v00y * (s * e) + v01y * (s * w) + v10y * (n * e) + v11y * (n * w);
+    ox = v00x * (s * e) + v01x * (s * w) + v10x * (n * e) + v11x * (n * w);
+}
+
+__device__ __forceinline__ bool inbounds(float y, float x, int H, int W)   // utils/iwe.py:52-57
+{
+    return (y >= 0.0f) & (y <= (float)H - 1.0f) & (x >= 0.0f) & (x <= (float)W - 1.0f);
+}
+
+// One warping step of an event list (loss/flow_val.py:337-342 sampling only; :492-517 forward step; :528-556 backward
+// steps): flow lookup at loc, loc += (tref - ts) * flow, purge (loc and mask zeroed when out of bounds), ts = tref.
+__global__ __launch_bounds__(256) void val_event_step_kernel(const float *__restrict__ fx, const float *__restrict__ fy,
+                                                             int H, int W, float *__restrict__ loc,
+                                                             float *__restrict__ ts, float *__restrict__ mask, int N,
+                                                             float tref, int do_warp, float *__restrict__ flow_out)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float y = loc[2 * e], x = loc[2 * e + 1], f_y, f_x;
+    sample_flow(fx, fy, H, W, y, x, f_y, f_x);
+    if (flow_out) { flow_out[2 * e] = f_y; flow_out[2 * e + 1] = f_x; }
+    if (!do_warp) return;
+    float dt = tref - ts[e];
+    y = y + dt * f_y;
+    x = x + dt * f_x;
+    float m = inbounds(y, x, H, W) ? 1.0f : 0.0f;
+    loc[2 * e] = y * m;
+    loc[2 * e + 1] = x * m;
+    mask[2 * e] *= m;
+    mask[2 * e + 1] *= m;
+    ts[e] = tref;
+}
+
+// Image of a (warped) event list: utils/iwe.py:63-136 with round_idx (nearest pixel, torch.round = half-to-even,
+// weight 1; metrics) or bilinear (4 corners; visualisation images).  cnt[2][HW] += w * mask_c; tsum += (w * ts) * mask_c.
+__global__ __launch_bounds__(256) void val_splat_kernel(const float *__restrict__ loc, const float *__restrict__ mask,
+                                                        const float *__restrict__ ts, int N, int H, int W, int round_idx,
+                                                        float *__restrict__ cnt, float *__restrict__ tsum)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float y = loc[2 * e], x = loc[2 * e + 1];
+    float m0 = mask[2 * e], m1 = mask[2 * e + 1];
+    float t = ts ? ts[e] : 0.0f;
+    const int HW = H * W;
+    if (round_idx) {
+        float ry = rintf(y), rx = rintf(x);
+        if (ry >= 0.0f && ry < (float)H && rx >= 0.0f && rx < (float)W) {
+            int p = (int)ry * W + (int)rx;
+            if (m0 != 0.0f) { atomicAdd(cnt + p, m0); if (tsum) atomicAdd(tsum + p, t * m0); }
+            if (m1 != 0.0f) { atomicAdd(cnt + HW + p, m1); if (tsum) atomicAdd(tsum + HW + p, t * m1); }
+        }
+        return;
+    }
+    float cy[2] = {floorf(y), floorf(y + 1.0f)}, cx[2] = {floorf(x), floorf(x + 1.0f)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float iy = cy[k >> 1], ix = cx[k & 1];
+        if (!(iy >= 0.0f && iy < (float)H && ix >= 0.0f && ix < (float)W)) continue;
+        float w = fmaxf(0.0f, 1.0f - fabsf(y - iy)) * fmaxf(0.0f, 1.0f - fabsf(x - ix));
+        if (w == 0.0f) continue;
+        int p = (int)iy * W + (int)ix;
+        if (m0 != 0.0f) { atomicAdd(cnt + p, w * m0); if (tsum) atomicAdd(tsum + p, (w * t) * m0); }
+        if (m1 != 0.0f) { atomicAdd(cnt + HW + p, w * m1); if (tsum) atomicAdd(tsum + HW + p, (w * t) * m1); }
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh)
+{
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// FWL (loss/flow_val.py:189-212) = var(fw count image) / var(zero count image) (unbiased, over all pixels);
+// RSAT (:214-274) = [sum (T/(C+eps)/passes)^2 / #{C_pos+C_neg > 0}]_fw / [same]_zero.     out = (fwl, rsat)
+__global__ __launch_bounds__(1024) void val_metrics_kernel(const float *__restrict__ cf, const float *__restrict__ tf,
+                                                           const float *__restrict__ cz, const float *__restrict__ tz,
+                                                           int HW, float passes, float *__restrict__ out)
+{
+    __shared__ double sh[1024];
+    double s1[2] = {0, 0}, s2[2] = {0, 0}, sq[2] = {0, 0}, nz[2] = {0, 0};
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float *c = k ? cz : cf, *t = k ? tz : tf;
+            float c0 = c[p], c1 = c[HW + p];
+            float img = c0 + c1;
+            s1[k] += img;
+            s2[k] += (double)img * img;
+            float a0 = t[p] / (c0 + 1e-9f) / passes, a1 = t[HW + p] / (c1 + 1e-9f) / passes;
+            sq[k] += (double)(a0 * a0) + (double)(a1 * a1);
+            nz[k] += (img > 0.0f) ? 1.0 : 0.0;
+        }
+    }
+    double r[8];
+    for (int k = 0; k < 2; ++k) {
+        r[k] = block_sum(s1[k], sh);
+        r[2 + k] = block_sum(s2[k], sh);
+        r[4 + k] = block_sum(sq[k], sh);
+        r[6 + k] = block_sum(nz[k], sh);
+    }
+    if (threadIdx.x == 0) {
+        double n = (double)HW;
+        double var_f = (r[2] - r[0] * r[0] / n) / (n - 1.0), var_z = (r[3] - r[1] * r[1] / n) / (n - 1.0);
+        out[0] = (float)(var_f / var_z);
+        out[1] = (float)((r[4] / r[6]) / (r[5] / r[7]));
+    }
+}
+
+// Forward propagation of a flow map (loss/flow_val.py:43-74): every pixel carries its flow vector to
+// pixel + dt * flow and splats it bilinearly; acc = (weight, weight * f_y, weight * f_x) planes [3][HW].
+__global__ __launch_bounds__(256) void val_prop_splat_kernel(const float *__restrict__ fx, const float *__restrict__ fy,
+                                                             int H, int W, float dt, float *__restrict__ acc)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    float py = (float)(p / W), px = (float)(p % W), f_y, f_x;
+    sample_flow(fx, fy, H, W, py, px, f_y, f_x);
+    float y = py + dt * f_y, x = px + dt * f_x;
+    if (!inbounds(y, x, H, W)) return;        // purged: weight 0 (the zeroed location gets nothing either)
+    float cy[2] = {floorf(y), floorf(y + 1.0f)}, cx[2] = {floorf(x), floorf(x + 1.0f)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float iy = cy[k >> 1], ix = cx[k & 1];
+        if (!(iy >= 0.0f && iy < (float)H && ix >= 0.0f && ix < (float)W)) continue;
+        float w = fmaxf(0.0f, 1.0f - fabsf(y - iy)) * fmaxf(0.0f, 1.0f - fabsf(x - ix));
+        if (w == 0.0f) continue;
+        int q = (int)iy * W + (int)ix;
+        atomicAdd(acc + q, w);
+        atomicAdd(acc + HW + q, w * f_y);
+        atomicAdd(acc + 2 * HW + q, w * f_x);
+    }
+}
+
+__global__ __launch_bounds__(256) void val_prop_divide_kernel(const float *__restrict__ acc, int HW,
+                                                              float *__restrict__ out_x, float *__restrict__ out_y)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float w = acc[p] + 1e-9f;
+    out_y[p] = acc[HW + p] / w;
+    out_x[p] = acc[2 * HW + p] / w;
+}
+
+// Accumulated backward flow (loss/flow_val.py:582-604): indices (y, x planes) walk along the newest flow.
+__global__ __launch_bounds__(256) void val_accum_flow_kernel(const float *__restrict__ fx, const float *__restrict__ fy,
+                                                             int H, int W, float *__restrict__ idx,
+                                                             float *__restrict__ out_mask, float *__restrict__ acc_x,
+                                                             float *__restrict__ acc_y)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int HW = H * W;
+    if (p >= HW) return;
+    float y = idx[p], x = idx[HW + p], f_y, f_x;
+    float valid = inbounds(y, x, H, W) ? 1.0f : 0.0f;
+    out_mask[p] += valid;
+    sample_flow(fx, fy, H, W, y, x, f_y, f_x);
+    y = y + f_y * valid;
+    x = x + f_x * valid;
+    idx[p] = y;
+    idx[HW + p] = x;
+    acc_y[p] = y - (float)(p / W);
+    acc_x[p] = x - (float)(p % W);
+}
+
+// Per-pixel average of P flow maps over the passes where the flow is non-zero (loss/flow_val.py:145-172).
+__global__ __launch_bounds__(256) void val_avg_flow_kernel(const float *__restrict__ mx, const float *__restrict__ my,
+                                                           int P, int HW, const float *__restrict__ div,
+                                                           const float *__restrict__ event_mask, int PM,
+                                                           float *__restrict__ out)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float sx = 0.0f, sy = 0.0f, cnt = 0.0f;
+    for (int i = 0; i < P; ++i) {
+        float vx = mx[(size_t)i * HW + p], vy = my[(size_t)i * HW + p];
+        if (div) { vx /= div[p]; vy /= div[p]; }
+        sx += vx;
+        sy += vy;
+        cnt += (vx != 0.0f || vy != 0.0f) ? 1.0f : 0.0f;
+    }
+    if (event_mask) {
+        float m = 0.0f;
+        for (int i = 0; i < PM; ++i) m += event_mask[(size_t)i * HW + p];
+        float keep = m > 0.0f ? 1.0f : 0.0f;
+        sx *= keep;
+        sy *= keep;
+    }
+    out[p] = sx / (cnt + 1e-9f);
+    out[HW + p] = sy / (cnt + 1e-9f);
+}
+
+// Average endpoint error (loss/flow_val.py:276-314) over pixels with valid ground truth (and input events).
+__global__ __launch_bounds__(1024) void val_aee_kernel(const float *__restrict__ pred, const float *__restrict__ gt,
+                                                       const float *__restrict__ mask, int PM, int HW,
+                                                       float *__restrict__ out)
+{
+    __shared__ double sh[1024];
+    double s = 0.0, n = 0.0;
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+        float gx = gt[p], gy = gt[HW + p];
+        bool ok = !(gx == 0.0f && gy == 0.0f);
+        if (ok && mask) {
+            float m = 0.0f;
+            for (int i = 0; i < PM; ++i) m += mask[(size_t)i * HW + p];
+            ok = m > 0.0f;
+        }
+        if (!ok) continue;
+        float dx = pred[p] - gx, dy = pred[HW + p] - gy;
+        s += (double)sqrtf(dx * dx + dy * dy);
+        n += 1.0;
+    }
+    double ts = block_sum(s, sh), tn = block_sum(n, sh);
+    if (threadIdx.x == 0) out[0] = (float)(ts / tn);
+}
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+extern "C" {
+
+int tef_val_event_step(const float *fx, const float *fy, int H, int W, float *loc, float *ts, float *mask, int N,
+                       float tref, int do_warp, float *flow_out, void *stream)
+{
+    if (!fx || !fy || H < 2 || W < 2 || N < 0 || (N > 0 && !loc) || (do_warp && N > 0 && (!ts || !mask)))
+        return tef::fail("tef_val_event_step: bad arguments"), TEF_ERR_INVALID;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(val_event_step_kernel, dim3(nblk(N)), dim3(256), 0, (hipStream_t)stream, fx, fy, H, W, loc, ts, mask, N,
+                       tref, do_warp, flow_out);
+    return tef::check_launch("val_event_step_kernel");
+}
+
+int tef_val_event_image(const float *loc, const float *mask, const float *ts, int N, int H, int W, int round_idx,
+                        float *cnt, float *tsum, void *stream)
+{
+    if (H < 1 || W < 1 || N < 0 || !cnt || (N > 0 && (!loc || !mask)))
+        return tef::fail("tef_val_event_image: bad arguments"), TEF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(cnt, 0, sizeof(float) * 2 * H * W, st) != hipSuccess) return tef::fail("memset failed"), TEF_ERR_LAUNCH;
+    if (tsum && hipMemsetAsync(tsum, 0, sizeof(float) * 2 * H * W, st) != hipSuccess) return tef::fail("memset failed"), TEF_ERR_LAUNCH;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(val_splat_kernel, dim3(nblk(N)), dim3(256), 0, st, loc, mask, ts, N, H, W, round_idx, cnt, tsum);
+    return tef::check_launch("val_splat_kernel");
+}
+
+int tef_val_metrics(const float *cnt_fw, const float *ts_fw, const float *cnt_zero, const float *ts_zero, int H, int W,
+                    float passes, float *out2, void *stream)
+{
+    if (!cnt_fw || !ts_fw || !cnt_zero || !ts_zero || !out2 || H * W < 2)
+        return tef::fail("tef_val_metrics: bad arguments"), TEF_ERR_INVALID;
+    hipLaunchKernelGGL(val_metrics_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cnt_fw, ts_fw, cnt_zero, ts_zero,
+                       H * W, passes, out2);
+    return tef::check_launch("val_metrics_kernel");
+}
+
+int tef_val_forward_prop_flow(const float *fx, const float *fy, int H, int W, float dt, float *scratch3, float *out_x,
+                              float *out_y, void *stream)
+{
+    if (!fx || !fy || !scratch3 || !out_x || !out_y || H < 2 || W < 2)
+        return tef::fail("tef_val_forward_prop_flow: bad arguments"), TEF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    if (hipMemsetAsync(scratch3, 0, sizeof(float) * 3 * HW, st) != hipSuccess) return tef::fail("memset failed"), TEF_ERR_LAUNCH;
+    hipLaunchKernelGGL(val_prop_splat_kernel, dim3(nblk(HW)), dim3(256), 0, st, fx, fy, H, W, dt, scratch3);
+    if (int rc = tef::check_launch("val_prop_splat_kernel")) return rc;
+    hipLaunchKernelGGL(val_prop_divide_kernel, dim3(nblk(HW)), dim3(256), 0, st, scratch3, HW, out_x, out_y);
+    return tef::check_launch("val_prop_divide_kernel");
+}
+
+int tef_val_accum_flow(const float *fx, const float *fy, int H, int W, float *indices, float *out_mask, float *acc_x,
+                       float *acc_y, void *stream)
+{
+    if (!fx || !fy || !indices || !out_mask || !acc_x || !acc_y || H < 2 || W < 2)
+        return tef::fail("tef_val_accum_flow: bad arguments"), TEF_ERR_INVALID;
+    hipLaunchKernelGGL(val_accum_flow_kernel, dim3(nblk((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, fx, fy, H, W,
+                       indices, out_mask, acc_x, acc_y);
+    return tef::check_launch("val_accum_flow_kernel");
+}
+
+int tef_val_average_flow(const float *maps_x, const float *maps_y, int P, int H, int W, const float *divisor,
+                         const float *event_mask, int mask_passes, float *out, void *stream)
+{
+    if (!maps_x || !maps_y || !out || P < 1 || H < 1 || W < 1)
+        return tef::fail("tef_val_average_flow: bad arguments"), TEF_ERR_INVALID;
+    hipLaunchKernelGGL(val_avg_flow_kernel, dim3(nblk((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, maps_x, maps_y, P,
+                       H * W, divisor, event_mask, mask_passes, out);
+    return tef::check_launch("val_avg_flow_kernel");
+}
+
+int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int mask_passes, int H, int W, float *out,
+                void *stream)
+{
+    if (!pred || !gt || !out || H < 1 || W < 1) return tef::fail("tef_val_aee: bad arguments"), TEF_ERR_INVALID;
+    hipLaunchKernelGGL(val_aee_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, gt, event_mask, mask_passes, H * W,
+                       out);
+    return tef::check_launch("val_aee_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""GPU parity of the validation metrics (loss/flow_val.py mirror on tef_val.hip) vs golden vectors recorded from the
+reference: RSAT / FWL after every pass, windowed event / IWE / flow images, AEE, in-place time shift."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("name", ["val_linear_24x30", "val_iterative_24x30", "val_iterative_20x26"])
+def test_validation_golden(name):
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd.loss import flow_val
+
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    kind, H, W, passes = str(z["kind"]), int(z["H"]), int(z["W"]), int(z["passes"])
+    cfg = {"loader": {"resolution": [H, W]}, "loss": {"round_ts": bool(z["round_ts"])}, "vis": {"mask_output": True},
+           "metrics": {}}
+    V = getattr(flow_val, kind)(cfg, dev)
+    t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    for p in range(passes):
+        ev = t(z[f"ev{p}"])
+        V.update([t(z[f"low{p}"]), t(z[f"flow{p}"])], ev, t(z[f"pm{p}"]), t(z[f"mask{p}"]))
+        np.testing.assert_array_equal(ev.cpu().numpy(), z[f"ev_after{p}"])       # in-place shift (flow_val.py:88)
+        assert V.num_passes == p + 1
+        assert abs(float(V.rsat().item()) - float(z[f"rsat{p}"])) <= TOL * float(z[f"rsat{p}"]), p
+        assert abs(float(V.fwl().item()) - float(z[f"fwl{p}"])) <= TOL * float(z[f"fwl{p}"]), p
+    np.testing.assert_array_equal(V.window_events(round_idx=True).cpu().numpy(), z["events_round"])
+    assert rel_err(V.window_events(round_idx=False).cpu().numpy(), z["events_bilinear"]) <= 1e-6
+    if kind == "Iterative":
+        for mode in ("forward", "backward"):
+            assert rel_err(V.window_iwe(mode=mode, round_idx=True).cpu().numpy(), z[f"iwe_{mode}_round"]) <= 1e-6, mode
+            assert rel_err(V.window_iwe(mode=mode, round_idx=False).cpu().numpy(), z[f"iwe_{mode}"]) <= TOL, mode
+            got, ref = V.window_flow(mode=mode, mask=True).cpu().numpy(), z[f"flow_{mode}"]
+            assert rel_err(np.nan_to_num(got), np.nan_to_num(ref)) <= TOL, mode
+            got, ref = V.window_flow(mode=mode, mask=False).cpu().numpy(), z[f"flow_{mode}_nomask"]
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), mode
+            assert rel_err(np.nan_to_num(got, posinf=0, neginf=0), np.nan_to_num(ref, posinf=0, neginf=0)) <= TOL, mode
+        assert rel_err(V.window_flow(mode=None, mask=True).cpu().numpy(), z["flow_none"]) <= TOL
+    else:
+        assert rel_err(V.window_iwe(round_idx=True).cpu().numpy(), z["iwe_round"]) <= 1e-6
+        assert rel_err(V.window_iwe(round_idx=False).cpu().numpy(), z["iwe"]) <= TOL
+        assert rel_err(V.window_flow(mask=True).cpu().numpy(), z["flow_mask"]) <= TOL
+        assert rel_err(V.window_flow(mask=False).cpu().numpy(), z["flow_nomask"]) <= TOL
+    aee = V.compute_aee(t(z["aee_pred"]), t(z["aee_gt"]))
+    assert abs(float(aee.item()) - float(z["aee_nomask"])) <= TOL * float(z["aee_nomask"])
+    aee = V.compute_aee(t(z["aee_pred"]), t(z["aee_gt"]), mask=V._event_mask.unsqueeze(0))
+    assert abs(float(aee.item()) - float(z["aee_mask"])) <= TOL * float(z["aee_mask"])
+    V.reset()
+    assert V.num_passes == 0
