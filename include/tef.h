@@ -209,6 +209,10 @@ int tef_val_accum_flow(const float *fx, const float *fy, int H, int W, float *in
  * [mask_passes][H][W]; out [2][H][W] = (x, y).  flow_val.py:145-172 */
 int tef_val_average_flow(const float *maps_x, const float *maps_y, int P, int H, int W, const float *divisor,
                          const float *event_mask, int mask_passes, float *out, void *stream);
+/* one-shot per-polarity image of warped events for visualisation: compute_pol_iwe / deblur_events, utils/iwe.py:139-257.
+ * flow [B][2][H][W] (ch0 = x), event_list [B][N][4] (ts in [0,1], y, x, p), pol_mask [B][N][2]; out [B][2][H][W]. */
+int tef_pol_iwe(const float *flow, const float *event_list, const float *pol_mask, int B, int N, int H, int W,
+                int round_idx, int round_flow, float *out, void *stream);
 /* average endpoint error over pixels with valid ground truth (and events).  flow_val.py:276-314 */
 int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int mask_passes, int H, int W, float *out,
                 void *stream);

@@ -85,6 +85,8 @@ SIGNATURES = {
     "tef_val_accum_flow": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]),
     "tef_val_average_flow": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, ctypes.c_int,
                                             _fp, _fp]),
+    "tef_pol_iwe": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, _fp, _fp]),
     "tef_val_aee": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
     "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),
     "tef_loss_forward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.POINTER(Events), ctypes.POINTER(Events),

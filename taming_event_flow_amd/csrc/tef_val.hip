@@ -253,6 +253,65 @@ __global__ __launch_bounds__(1024) void val_aee_kernel(const float *__restrict__
     if (threadIdx.x == 0) out[0] = (float)(ts / tn);
 }
 
+// One-shot per-polarity IWE for visualisation: utils/iwe.py:139-224 deblur_events / :227-257 compute_pol_iwe.
+// The flow lookup here is the reference's own gather (nearest by truncation, or 4-corner bilinear with hat weights),
+// NOT grid_sample; events are warped to tref = 1 and splatted (nearest or bilinear).  out [B][2][H][W].
+__global__ __launch_bounds__(256) void pol_iwe_kernel(const float *__restrict__ flow, const float *__restrict__ ev,
+                                                      const float *__restrict__ pm, int B, int N, int H, int W,
+                                                      int round_idx, int round_flow, float *__restrict__ out)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int b = blockIdx.y;
+    if (e >= N) return;
+    const int HW = H * W;
+    const float *evp = ev + ((size_t)b * N + e) * 4;
+    float ts = evp[0], y = evp[1], x = evp[2];
+    if (!(y >= 0.0f && y < (float)H && x >= 0.0f && x < (float)W)) return;     // mask_unfeasible zeroes the weights
+    const float *fxm = flow + (size_t)b * 2 * HW, *fym = fxm + HW;               // channel 0 = x, 1 = y
+    float f_y, f_x;
+    if (round_flow) {
+        int p = (int)(y * (float)W + x);         // (y * W + x).long()
+        f_y = fym[p];
+        f_x = fxm[p];
+    } else {
+        float cy[2] = {floorf(y), floorf(y + 1.0f)}, cx[2] = {floorf(x), floorf(x + 1.0f)};
+        f_y = 0.0f;
+        f_x = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {            // corner order TL, TR, BL, BR as in the reference's summation
+            float iy = cy[k >> 1], ix = cx[k & 1];
+            bool ok = iy >= 0.0f && iy < (float)H && ix >= 0.0f && ix < (float)W;
+            float w = ok ? fmaxf(0.0f, 1.0f - fabsf(y - iy)) * fmaxf(0.0f, 1.0f - fabsf(x - ix)) : 0.0f;
+            int p = ok ? (int)(iy * (float)W + ix) : 0;
+            f_y += w * fym[p];
+            f_x += w * fxm[p];
+        }
+    }
+    float wy = y + (1.0f - ts) * f_y, wx = x + (1.0f - ts) * f_x;
+    float m0 = pm[((size_t)b * N + e) * 2], m1 = pm[((size_t)b * N + e) * 2 + 1];
+    float *o = out + (size_t)b * 2 * HW;
+    if (round_idx) {
+        float ry = rintf(wy), rx = rintf(wx);
+        if (ry >= 0.0f && ry < (float)H && rx >= 0.0f && rx < (float)W) {
+            int p = (int)ry * W + (int)rx;
+            if (m0 != 0.0f) atomicAdd(o + p, m0);
+            if (m1 != 0.0f) atomicAdd(o + HW + p, m1);
+        }
+        return;
+    }
+    float cy[2] = {floorf(wy), floorf(wy + 1.0f)}, cx[2] = {floorf(wx), floorf(wx + 1.0f)};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float iy = cy[k >> 1], ix = cx[k & 1];
+        if (!(iy >= 0.0f && iy < (float)H && ix >= 0.0f && ix < (float)W)) continue;
+        float w = fmaxf(0.0f, 1.0f - fabsf(wy - iy)) * fmaxf(0.0f, 1.0f - fabsf(wx - ix));
+        if (w == 0.0f) continue;
+        int p = (int)iy * W + (int)ix;
+        if (m0 != 0.0f) atomicAdd(o + p, w * m0);
+        if (m1 != 0.0f) atomicAdd(o + HW + p, w * m1);
+    }
+}
+
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -325,6 +384,19 @@ int tef_val_average_flow(const float *maps_x, const float *maps_y, int P, int H,
     hipLaunchKernelGGL(val_avg_flow_kernel, dim3(nblk((size_t)H * W)), dim3(256), 0, (hipStream_t)stream, maps_x, maps_y, P,
                        H * W, divisor, event_mask, mask_passes, out);
     return tef::check_launch("val_avg_flow_kernel");
+}
+
+int tef_pol_iwe(const float *flow, const float *event_list, const float *pol_mask, int B, int N, int H, int W,
+                int round_idx, int round_flow, float *out, void *stream)
+{
+    if (!flow || !out || B < 1 || N < 0 || H < 1 || W < 1 || (N > 0 && (!event_list || !pol_mask)))
+        return tef::fail("tef_pol_iwe: bad arguments"), TEF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * 2 * H * W, st) != hipSuccess) return tef::fail("memset failed"), TEF_ERR_LAUNCH;
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(pol_iwe_kernel, dim3(nblk(N), B), dim3(256), 0, st, flow, event_list, pol_mask, B, N, H, W, round_idx,
+                       round_flow, out);
+    return tef::check_launch("pol_iwe_kernel");
 }
 
 int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int mask_passes, int H, int W, float *out,

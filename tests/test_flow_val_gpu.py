@@ -57,3 +57,22 @@ def test_validation_golden(name):
     assert abs(float(aee.item()) - float(z["aee_mask"])) <= TOL * float(z["aee_mask"])
     V.reset()
     assert V.num_passes == 0
+
+
+def test_compute_pol_iwe():
+    """utils/iwe.py compute_pol_iwe / deblur_events (one-shot IWE for visualisation) vs the reference, all 4 modes."""
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd.utils import iwe
+
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, "pol_iwe.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    flow, ev, evf, pm = (torch.tensor(z[k], device=dev) for k in ("flow", "ev", "evf", "pm"))
+    for ri in (True, False):
+        for rf in (True, False):       # the reference's nearest-flow gather assumes integer pixel coordinates
+            got = iwe.compute_pol_iwe(flow, ev if rf else evf, (H, W), pm, round_idx=ri, round_flow=rf).cpu().numpy()
+            assert rel_err(got, z[f"iwe_{int(ri)}{int(rf)}"]) <= 1e-5, (ri, rf)
+    one = iwe.deblur_events(flow, ev, (H, W), polarity_mask=pm[:, :, 0:1]).cpu().numpy()
+    assert rel_err(one, z["iwe_11"][:, 0:1]) <= 1e-5
