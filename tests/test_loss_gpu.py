@@ -163,3 +163,18 @@ def test_full_size_properties(dev):
     assert rel_err(g2, g1) <= TOL
     # (3) mean timestamps are in [0, 1] so every image term is in [0, 2]; loss <= 2 * B
     assert 0.0 < l1 <= 2.0 * B
+
+
+def test_eval_resolution_and_long_window(dev):
+    """480x640 (19 LDS row bands) with a short window, and a 20-pass window at low resolution, against the oracle."""
+    from oracle import oracle
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(21)
+    for (H, W, B, P, F, S, N) in [(480, 640, 1, 2, 1, 1, 4000), (32, 40, 1, 20, 1, 2, 300)]:
+        win = synth.make_window(rng, B, H, W, P, F, N, N // 4, sigma=2.0)
+        meta = dict(H=H, W=W, B=B, P=P, S=S, mode="two", spat=None, temp=None, round_ts=False)
+        l, g, _ = run_hip("Iterative", make_cfg(meta), win, dev)
+        ol, od = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=S, mode="two").iterative()
+        assert abs(l - ol) <= TOL * abs(ol), (H, W, l, float(ol))
+        assert rel_err(g, od) <= TOL, (H, W)
