@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
     Taps tp = make_taps(y0, x0, H, W);
     float2 f0 = quad_value(load_quad(flow_map(w, flows, t, i, b), tp), tp);
 
+    // an event of pass t is only ever looked at (IWEs, gradient sweep, flow-gradient splat) at reference times within
+    // delta_passes[0] of t; the chain still runs to both ends of the window because the border mask needs it
+    const int reach = P / w.mode_div;
     int kf = P + 1, kb = -1;
     {   // forward: maps t .. P-1, positions at tref = t+1 .. P
         float y = y0, x = x0;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
             }
             y = y + dt * f.x;
             x = x + dt * f.y;
-            tr[(size_t)(k + 1) * w.Mt] = make_float2(y, x);
+            if (k + 1 <= t + reach) tr[(size_t)(k + 1) * w.Mt] = make_float2(y, x);   // planes beyond are never read
             if (!inbounds(y, x, H, W)) { kf = k + 1; break; }       // cumulative purge, loss/flow.py:575
         }
     }
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
             }
             y = y + dt * f.x;
             x = x + dt * f.y;
-            tr[(size_t)k * w.Mt] = make_float2(y, x);
+            if (k >= t - reach) tr[(size_t)k * w.Mt] = make_float2(y, x);
             if (!inbounds(y, x, H, W)) { kb = k; break; }
         }
     }
@@ -674,14 +677,17 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     float *coy = cy + (size_t)ib * P * M + sl, *cox = cx + (size_t)ib * P * M + sl;
     uint32_t mv = meta[(size_t)ib * w.Mt + sl];
     uint32_t bits = mv & 0xffu;
+    int t = g.bin[sl];
+    // map k receives something from pass t only if |k - t| < delta_passes[0] (largest window and reach); K7 reads
+    // exactly those (pass, map) pairs, so only they need a value
+    const int reach = P / w.mode_div;
     if (bits == 0u) {
-        for (int k = 0; k < P; ++k) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
+        for (int k = max(0, t - reach + 1); k < min(P, t + reach); ++k) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
         return;
     }
     int kb = (int)((mv >> 8) & 0xffu) - 1, kf = (int)((mv >> 16) & 0xffu);
     size_t o = (size_t)b * g.cap + sl;
     float ts = g.ts[o], mp = g.mp[o], mn = g.mn[o];
-    int t = g.bin[sl];
     float gout = grad_out[0];
     const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + sl;
     float c0y = 0.0f, c0x = 0.0f;
@@ -689,10 +695,20 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     // Both sweeps keep the next trajectory position one iteration ahead (cur = p_k, nxt = the position the
     // step into p_k was sampled at), so the IWE lookups at cur and the flow lookups at nxt of one iteration
     // are all independent loads.
+    // reference times that can carry a gradient for this event: tref k contributes at scale s iff the event's window is
+    // valid, lo_s <= k <= hi_s and k - delta_s <= t < k + delta_s; the sweeps start at the outermost such tref (beyond
+    // it the adjoint is still zero, so neither the IWE nor the flow Jacobian need to be looked up)
+    int k_top = t, k_bot = t + 1;
+    for (int s = 0; s < w.S; ++s) {
+        if (!((bits >> s) & 1u)) continue;
+        int scale = P >> s, wi = t / scale, lo = wi * scale, hi = lo + scale, delta = scale / w.mode_div;
+        k_top = max(k_top, min(hi, t + delta));
+        k_bot = min(k_bot, max(lo, t - delta + 1));
+    }
     float ay = 0.0f, ax = 0.0f;
     {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = P .. t+1
-        int ks = min(P, kf - 1);
-        for (int k = P; k > ks; --k)
+        int ks = min(min(P, kf - 1), k_top);
+        for (int k = min(P, t + reach); k > ks; --k)
             if (k - 1 > t) { coy[(size_t)(k - 1) * M] = 0.0f; cox[(size_t)(k - 1) * M] = 0.0f; }
         float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
         if (ks > t) cur = tr[(size_t)ks * w.Mt];
@@ -728,8 +744,8 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     ay = 0.0f;
     ax = 0.0f;
     {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = 0 .. t
-        int ks = max(0, kb + 1);
-        for (int k = 0; k < ks; ++k)
+        int ks = max(max(0, kb + 1), k_bot);
+        for (int k = max(0, t - reach + 1); k < ks; ++k)
             if (k < t) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
         float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
         if (ks <= t) cur = tr[(size_t)ks * w.Mt];
@@ -840,7 +856,8 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
     const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
     const int stride = blockDim.x;
     // pass by pass: the position source (trajectory plane or original location) is uniform inside a pass
-    for (int t = iter ? 0 : k; t < (iter ? w.P : k + 1); ++t) {
+    const int reach = w.P / max(1, w.mode_div);     // Iterative: pass t feeds map k only if |k - t| < delta_passes[0]
+    for (int t = iter ? max(0, k - reach + 1) : k; t < (iter ? min(w.P, k + reach) : k + 1); ++t) {
         const int s0 = w.off[t], s1 = w.off[t + 1];
         const float2 *pl = tr + (size_t)(t < k ? k : k + 1) * w.Mt;
         for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
