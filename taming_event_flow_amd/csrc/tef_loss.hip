@@ -50,7 +50,10 @@ constexpr int kRowPad = TEF_ROWPAD;                  // fp64 LDS rows are W + 8 
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
 constexpr int kMaxSegs = 4 * TEF_MAX_PASSES;
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
-constexpr int kUnroll = 4;
+#ifndef TEF_UNROLL
+#define TEF_UNROLL 4
+#endif
+constexpr int kUnroll = TEF_UNROLL;
 
 // meta word written by K1 per (head, sample, slot)
 constexpr uint32_t kMetaPos = 1u << 24;      // mask_pos != 0
@@ -77,7 +80,7 @@ struct Events {
 
 struct Img {
     int s, plane, le, he, lo, hi;
-    float tref, delta, coef;
+    float tref, delta, inv_delta, coef;
 };
 
 __host__ __device__ inline int images_of_scale(int kind, int P, int s)
@@ -106,6 +109,7 @@ __host__ __device__ inline Img decode_image(const Win &w, int j)
         im.plane = tref;
         im.tref = (float)tref;
         im.delta = (float)delta;
+        im.inv_delta = 1.0f / (float)delta;
         im.coef = 1.0f / ((float)(1 << s) * (float)(2 * delta + 1) * (float)w.S * (float)w.F);
     } else {
         int wi = r >> 1, e = r & 1;
@@ -116,6 +120,7 @@ __host__ __device__ inline Img decode_image(const Win &w, int j)
         im.plane = 2 * s + e;
         im.tref = (float)(e ? im.lo : im.hi);
         im.delta = (float)scale;
+        im.inv_delta = 1.0f / (float)scale;
         im.coef = 1.0f / ((float)(1 << s) * 2.0f * (float)w.S * (float)w.F);
     }
     return im;
@@ -142,9 +147,16 @@ struct Taps {
     float s, n, e, w;         // (1-fy), fy, (1-fx), fx
 };
 
+// True divisions, bit-for-bit the reference's coordinates and timestamps.  (Multiplying by the reciprocal instead —
+// TEF_FAST_DIV, an experiment hook — moves exactly-integer event coordinates across a floor() boundary, fails the
+// golden parity tests and only buys 1 % of the step.)
 __device__ __forceinline__ float unnormalize(float v, int size)
 {
+#ifndef TEF_FAST_DIV
     float nn = (2.0f * v) / (float)(size - 1) - 1.0f;       // utils/iwe.py:30-31
+#else
+    float nn = (2.0f * v) * (1.0f / (float)(size - 1)) - 1.0f;
+#endif
     return (nn + 1.0f) * ((float)(size - 1) / 2.0f);         // ATen ComputeLocation<align_corners=true>
 }
 
@@ -406,12 +418,18 @@ __device__ __forceinline__ void splat_one(const Win &w, const Img &im, float2 p,
 {
     Splat sp = make_splat(p.x, p.y);                 // traj stores (y, x) in (.x, .y)
     float tau = 0.0f;
+#ifndef TEF_FAST_DIV
     if (QT) tau = 1.0f - fabsf(im.tref - ts) / im.delta;     // :94-95
+#else
+    if (QT) tau = 1.0f - fabsf(im.tref - ts) * im.inv_delta;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int iy = sp.iy[k >> 1], ix = sp.ix[k & 1];
         float wgt = sp.wy[k >> 1] * sp.wx[k & 1];
-        if (wgt == 0.0f || iy < r0 || iy >= r1 || ix < 0 || ix >= w.W) continue;
+        // positions of contributing events are inside the frame (border mask), so a corner outside it has weight 0;
+        // only the row-band test is a real filter
+        if (wgt == 0.0f || iy < r0 || iy >= r1) continue;
         float v = QT ? (wgt * tau) * m : wgt * m;
         atomicAdd(img + (iy - r0) * (w.W + kRowPad) + ix, (double)v);
     }
@@ -590,7 +608,11 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     float kimg = kscale / stats[q * 2 + 1];
     const float2 *pos = ar + q * 2 * HW;
     const float2 *neg = pos + HW;
+#ifndef TEF_FAST_DIV
     float tau = 1.0f - fabsf(tref - ts) / delta;
+#else
+    float tau = 1.0f - fabsf(tref - ts) * (1.0f / delta);
+#endif
     Splat sp = make_splat(p.x, p.y);
     float gy = 0.0f, gx = 0.0f;
     bool vx0 = (sp.ix[0] >= 0) & (sp.ix[0] < w.W), vx1 = (sp.ix[1] >= 0) & (sp.ix[1] < w.W);
@@ -875,15 +897,17 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) {
                 if (cv[q] == 0.0f) continue;
-                Taps tp = make_taps(p[q].x, p[q].y, H, W);
-                const int idx[4] = {tp.i00, tp.i01, tp.i10, tp.i11};
-                const float wt[4] = {tp.s * tp.e, tp.s * tp.w, tp.n * tp.e, tp.n * tp.w};
+                // same taps as the forward lookup (make_taps), kept as (row, column) to address the padded LDS plane
+                float fiy = unnormalize(p[q].x, H), fix = unnormalize(p[q].y, W);
+                float fy0 = floorf(fiy), fx0 = floorf(fix);
+                float tn = fiy - fy0, tw = fix - fx0, tsv = 1.0f - tn, te = 1.0f - tw;
+                int y0 = (int)fy0, x0 = (int)fx0;
+                const float wt[4] = {tsv * te, tsv * tw, tn * te, tn * tw};
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    if (idx[c] < 0) continue;
-                    int iy = idx[c] / W;
-                    if (iy < r0 || iy >= r1) continue;
-                    atomicAdd(lds_img + (iy - r0) * WP + (idx[c] - iy * W), (double)(cv[q] * wt[c]));
+                    int iy = y0 + (c >> 1), ix = x0 + (c & 1);
+                    if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
+                    atomicAdd(lds_img + (iy - r0) * WP + ix, (double)(cv[q] * wt[c]));
                 }
             }
         }
