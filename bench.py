@@ -78,26 +78,31 @@ def pmc_traffic(a):
 
 
 def algorithmic_bytes(a, delta):
-    """Per-launch algorithmic bytes of each kernel for the Iterative window."""
+    """Per-launch algorithmic bytes of each kernel for the Iterative window.
+
+    An event of pass t is only looked at (splat, gradient sweep, flow-gradient splat) at reference times within
+    delta of t, so trajectory planes / per-map vectors outside that reach are neither written nor read."""
     B, P, F, N, Nd = a.batch, a.passes, a.heads, a.events, a.detached
     H, W = a.res
-    HW, FB, Mt, M = H * W, F * B, P * (N + Nd), P * N
+    HW, FB = H * W, F * B
     pairs = 0           # (tref, bin) pairs of one window = image/bin incidences
     for tref in range(P + 1):
         pairs += max(0, min(P, tref + delta) - max(0, tref - delta))
+    planes = sum(min(P, t + delta) - max(0, t - delta) + 1 for t in range(P))          # trajectory planes kept, over bins
+    vecs = sum(min(P - 1, t + delta - 1) - max(0, t - delta + 1) + 1 for t in range(P))  # (bin, map) pairs with a vector
     nimg = P + 1
     splats = pairs * (N + Nd) * FB
     maps = P * FB * 2 * HW * 4
     return {
         # 16 B per event-splat (position 8 + timestamp 4 + mask word 4)  [SURVEY.md §8d]; write-out excluded
         "iwe_splat": splats * 16,
-        # per (event, head): 12 B event + 8 B masks in, (P+1) positions + 1 meta word out; flow maps once
-        "warp": FB * Mt * (20 + (P + 1) * 8 + 4) + maps,
-        # per (grad event, head): trajectory in, one vector per map out; IWEs + flow maps once
-        "chain_bwd": FB * M * (20 + (P + 1) * 8 + P * 8) + nimg * FB * 2 * HW * 8 + maps,
-        # per (grad event, head, map): vector 8 + position 8; gradient maps written once
-        "dflow_splat": FB * M * P * 16 + maps,
-        "image_stats": nimg * FB * 2 * HW * 8,
+        # per (event, head): 12 B event + 8 B masks in, kept positions + 1 meta word out; flow maps once
+        "warp": FB * (N + Nd) * (P * (20 + 4) + planes * 8) + maps,
+        # per (grad event, head): kept positions in, one 8-byte vector per reachable map out; (A,R) images + flow maps once
+        "chain_bwd": FB * N * (P * 24 + planes * 8 + vecs * 8) + nimg * FB * 2 * HW * 8 + maps,
+        # per (grad event, head, reachable map): vector 8 + position 8; gradient maps written once
+        "dflow_splat": FB * N * vecs * 16 + maps,
+        "image_stats": nimg * FB * 2 * HW * (8 + 8),
     }, splats
 
 
