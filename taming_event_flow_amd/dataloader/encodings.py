@@ -9,7 +9,10 @@ encode a collated ``[B, N, 4] = (ts, y, x, p)`` list in one launch.  The scatter
 
 import torch
 
-from .. import _lib
+try:
+    from .. import _lib
+except ImportError:      # drop-in mode: this package's directory itself is on sys.path
+    import _lib
 
 MODE_IMAGE, MODE_CHANNELS, MODE_VOXEL = 0, 1, 2
 

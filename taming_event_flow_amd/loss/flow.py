@@ -15,7 +15,10 @@ import ctypes
 
 import torch
 
-from .. import _lib
+try:
+    from .. import _lib
+except ImportError:      # drop-in mode: this package's directory itself is on sys.path
+    import _lib
 
 __all__ = ["BaseEventWarping", "Linear", "Iterative"]
 

@@ -8,7 +8,10 @@ Same classes and methods: ``BaseValidation`` (:12), ``Linear`` (:317), ``Iterati
 
 import torch
 
-from .. import _lib
+try:
+    from .. import _lib
+except ImportError:      # drop-in mode: this package's directory itself is on sys.path
+    import _lib
 
 
 def _f32(t, name):

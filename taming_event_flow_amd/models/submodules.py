@@ -13,7 +13,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as f
 
-from .. import _lib
+try:
+    from .. import _lib
+except ImportError:      # drop-in mode: this package's directory itself is on sys.path
+    import _lib
 
 
 def _ptr(t):

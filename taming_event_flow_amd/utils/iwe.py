@@ -5,7 +5,10 @@ loss kernels (tef_loss.hip) and are not exposed one by one."""
 
 import torch
 
-from .. import _lib
+try:
+    from .. import _lib
+except ImportError:      # drop-in mode: this package's directory itself is on sys.path
+    import _lib
 
 
 def compute_pol_iwe(flow, event_list, res, pol_mask, round_idx=True, round_flow=True):
