@@ -134,6 +134,30 @@ int tef_smoothing_backward(const tef_loss_cfg *cfg, const float *flows, float sp
 #define TEF_ENCODE_VOXEL 2
 int tef_encode_events(const float *xs, const float *ys, const float *ts, const float *ps, int B, long batch_stride,
                       int elem_stride, int N, int mode, int channels, int H, int W, float *out, void *stream);
+/* The same representations from the two collated lists of one batch, event_list [B][N][4] and d_event_list [B][Nd][4]
+ * (either may be empty): the loader encodes all events of the window before it splits them (h5.py:371-385). */
+int tef_encode_event_lists(const float *event_list, int N, const float *d_event_list, int Nd, int B, int mode,
+                           int channels, int H, int W, float *out, void *stream);
+
+/* ---- loader stage: format, augment, split and collate the raw events of a whole batch ------------------------------
+ * Raw events of sample b are elements [offsets[b], offsets[b+1]) of xs, ys, ts, ps (device, fp32; ps in {0,1}, ts
+ * increasing); offsets (host, offsets[0] = 0), flags (host, TEF_AUG_* bits per sample or NULL).  Per sample, as one
+ * __getitem__ of the reference does (dataloader/h5.py:340-345,349-366,413-416; base.py:153-177,192-222,252-278,348-377):
+ * <= 10 events -> none; p = 2 ps - 1; ts = (ts - ts[0]) / (ts[-1] - ts[0]); flips; event (ts,y,x,p), mask (p>0, p<0);
+ * with max_grad > 0 and more than max_grad events, event sampled[b][j] (device int32 [B][max_grad], the caller's
+ * multinomial draw, distinct) becomes gradient event j and the others form the detached list in stream order.  Then
+ * custom_collate (base.py:392-434): lists zero-padded to N / Nd (>= the values tef_collate_counts returns).
+ * Outputs event_list [B][N][4], pol_mask [B][N][2], d_event_list [B][Nd][4], d_pol_mask [B][Nd][2], fully written. */
+#define TEF_MAX_BATCH 64
+#define TEF_AUG_HORIZONTAL 1   /* x -> W-1-x   base.py:206-210 */
+#define TEF_AUG_VERTICAL   2   /* y -> H-1-y   base.py:212-216 */
+#define TEF_AUG_POLARITY   4   /* p -> -p      base.py:218-220 */
+int tef_collate_counts(const int *offsets, int B, int max_grad, int *n_grad, int *n_detached);
+size_t tef_collate_workspace_bytes(const int *offsets, int B);
+int tef_collate_events(const float *xs, const float *ys, const float *ts, const float *ps, const int *offsets,
+                       const int *sampled, const int *flags, int B, int max_grad, int N, int Nd, int H, int W,
+                       void *workspace, size_t workspace_bytes, float *event_list, float *pol_mask,
+                       float *d_event_list, float *d_pol_mask, void *stream);
 
 /* ---- RecEVFlowNet convolutions (models/submodules.py) -------------------------------------------------------
  * One 3x3 / 1x1 convolution with padding ksize/2, stride 1 or 2, bias and a fused activation, on NCHW fp32 tensors.

@@ -61,6 +61,15 @@ SIGNATURES = {
                                      _fp, _fp]),
     "tef_encode_events": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    "tef_encode_event_lists": (ctypes.c_int, [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    "tef_collate_counts": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "tef_collate_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ctypes.c_int), ctypes.c_int]),
+    "tef_collate_events": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.POINTER(ctypes.c_int), _fp,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_size_t, _fp, _fp, _fp,
+                                          _fp, _fp]),
     "tef_conv_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "tef_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_size_t),
                                                         ctypes.POINTER(ctypes.c_size_t)]),

@@ -17,11 +17,13 @@ namespace {
 constexpr size_t kLdsBudget = 144 * 1024;
 constexpr int kThreads = 1024;
 
-// xs/ys/ts/ps: element e of sample b at base[b * bs + e * es]
+// xs/ys/ts/ps: element e of sample b at base[b * bs + e * es]; an optional second AoS list [B][N2][4] (ts,y,x,p)
+// follows the first (the detached events of the collated batch)
 __global__ __launch_bounds__(kThreads) void encode_kernel(const float *__restrict__ xs, const float *__restrict__ ys,
                                                           const float *__restrict__ ts, const float *__restrict__ ps,
-                                                          long bs, int es, int N, int mode, int C, int H, int W,
-                                                          int rows_per_band, int nbands, float *__restrict__ out)
+                                                          long bs, int es, int N, const float *__restrict__ list2, int N2,
+                                                          int mode, int C, int H, int W, int rows_per_band, int nbands,
+                                                          float *__restrict__ out)
 {
     extern __shared__ double img[];
     int bid = blockIdx.x;
@@ -32,10 +34,19 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(const float *__restric
     int npx = (r1 - r0) * W;
     for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = 0.0;
     __syncthreads();
-    const float *bx = xs + (size_t)b * bs, *by = ys + (size_t)b * bs, *bp = ps + (size_t)b * bs;
-    const float *bt = ts ? ts + (size_t)b * bs : nullptr;
-    for (int e = threadIdx.x; e < N; e += blockDim.x) {
-        float p = bp[(size_t)e * es];
+    for (int ee = threadIdx.x; ee < N + N2; ee += blockDim.x) {
+        const float *bx, *by, *bp, *bt;
+        int e = ee;
+        if (ee < N) {
+            bx = xs + (size_t)b * bs, by = ys + (size_t)b * bs, bp = ps + (size_t)b * bs;
+            bt = ts ? ts + (size_t)b * bs : nullptr;
+        } else {
+            e = ee - N;
+            const float *l = list2 + (size_t)b * N2 * 4;
+            bt = l, by = l + 1, bx = l + 2, bp = l + 3;
+        }
+        int es_ = ee < N ? es : 4;
+        float p = bp[(size_t)e * es_];
         float v;
         if (mode == TEF_ENCODE_IMAGE) {
             v = p;
@@ -45,11 +56,11 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(const float *__restric
             float mneg = p < 0.0f ? -1.0f : (p > 0.0f ? 0.0f : p);
             v = p * (c == 0 ? mpos : mneg);
         } else {
-            float t = bt[(size_t)e * es] * (float)(C - 1);            // encodings.py:47
+            float t = bt[(size_t)e * es_] * (float)(C - 1);            // encodings.py:47
             v = p * fmaxf(0.0f, 1.0f - fabsf(t - (float)c));          // :52
         }
         if (v == 0.0f) continue;
-        int iy = (int)by[(size_t)e * es], ix = (int)bx[(size_t)e * es];   // .long() truncation (:24-27)
+        int iy = (int)by[(size_t)e * es_], ix = (int)bx[(size_t)e * es_];   // .long() truncation (:24-27)
         if (iy < 0) iy += H;                                             // python-style negative index
         if (ix < 0) ix += W;
         if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
@@ -64,11 +75,12 @@ bool g_attr_done = false;
 
 }  // namespace
 
-extern "C" int tef_encode_events(const float *xs, const float *ys, const float *ts, const float *ps, int B,
-                                 long batch_stride, int elem_stride, int N, int mode, int channels, int H, int W,
-                                 float *out, void *stream)
+static int encode(const float *xs, const float *ys, const float *ts, const float *ps, int B, long batch_stride,
+                  int elem_stride, int N, const float *list2, int N2, int mode, int channels, int H, int W, float *out,
+                  void *stream)
 {
-    if ((N > 0 && (!xs || !ys || !ps)) || !out || B < 1 || N < 0 || H < 1 || W < 1 || elem_stride < 1)
+    if ((N > 0 && (!xs || !ys || !ps)) || (N2 > 0 && !list2) || !out || B < 1 || N < 0 || N2 < 0 || H < 1 || W < 1 ||
+        elem_stride < 1)
         return tef::fail("tef_encode_events: bad arguments"), TEF_ERR_INVALID;
     int C;
     if (mode == TEF_ENCODE_IMAGE) C = 1;
@@ -92,7 +104,22 @@ extern "C" int tef_encode_events(const float *xs, const float *ys, const float *
     {
         tef::ProfScope ps_(tef::PROF_ENCODE, st);
         hipLaunchKernelGGL(encode_kernel, dim3((unsigned)(B * C * nbands)), dim3(kThreads), lds, st, xs, ys, ts, ps,
-                           batch_stride, elem_stride, N, mode, C, H, W, rows, nbands, out);
+                           batch_stride, elem_stride, N, list2, N2, mode, C, H, W, rows, nbands, out);
     }
     return tef::check_launch("encode_kernel");
+}
+
+extern "C" int tef_encode_events(const float *xs, const float *ys, const float *ts, const float *ps, int B,
+                                 long batch_stride, int elem_stride, int N, int mode, int channels, int H, int W,
+                                 float *out, void *stream)
+{
+    return encode(xs, ys, ts, ps, B, batch_stride, elem_stride, N, nullptr, 0, mode, channels, H, W, out, stream);
+}
+
+extern "C" int tef_encode_event_lists(const float *event_list, int N, const float *d_event_list, int Nd, int B, int mode,
+                                      int channels, int H, int W, float *out, void *stream)
+{
+    const float *l = event_list;
+    return encode(l ? l + 2 : nullptr, l ? l + 1 : nullptr, l, l ? l + 3 : nullptr, B, (long)N * 4, 4, N, d_event_list, Nd,
+                  mode, channels, H, W, out, stream);
 }

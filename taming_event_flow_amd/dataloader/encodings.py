@@ -54,25 +54,30 @@ def events_to_channels(xs, ys, ps, sensor_size=(180, 240)):
     return _encode(xs, ys, None, ps, MODE_CHANNELS, 2, sensor_size)
 
 
-def _encode_list(event_list, mode, channels, sensor_size):
+def _encode_list(event_list, mode, channels, sensor_size, d_event_list=None):
     ev = _prep(event_list, "event_list")
     B, N, four = ev.shape
     assert four == 4, "event_list must be [B, N, 4] = (ts, y, x, p)"
+    dev, Nd = None, 0
+    if d_event_list is not None and d_event_list.shape[1] > 0:
+        dev = _prep(d_event_list, "d_event_list")
+        assert dev.shape[0] == B and dev.shape[2] == 4
+        Nd = dev.shape[1]
     H, W = int(sensor_size[0]), int(sensor_size[1])
     C = 2 if mode == MODE_CHANNELS else channels
     out = torch.empty((B, C, H, W), dtype=torch.float32, device=ev.device)
-    base = ev.data_ptr()
-    rc = _lib.lib().tef_encode_events(base + 8, base + 4, base, base + 12, B, N * 4, 4, N, mode, C, H, W,
-                                      out.data_ptr(), _lib.stream_ptr())
-    _lib.check(rc, "tef_encode_events")
+    rc = _lib.lib().tef_encode_event_lists(ev.data_ptr() if N else None, N, dev.data_ptr() if Nd else None, Nd, B,
+                                           mode, C, H, W, out.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "tef_encode_event_lists")
     return out
 
 
-def event_list_to_channels(event_list, sensor_size):
-    """Batched events_to_channels over a zero-padded collated list [B, N, 4] -> [B, 2, H, W]."""
-    return _encode_list(event_list, MODE_CHANNELS, 2, sensor_size)
+def event_list_to_channels(event_list, sensor_size, d_event_list=None):
+    """Batched events_to_channels over a zero-padded collated list [B, N, 4] (plus, optionally, the detached list of
+    the same batch) -> [B, 2, H, W]."""
+    return _encode_list(event_list, MODE_CHANNELS, 2, sensor_size, d_event_list)
 
 
-def event_list_to_voxel(event_list, num_bins, sensor_size):
+def event_list_to_voxel(event_list, num_bins, sensor_size, d_event_list=None):
     """Batched events_to_voxel over a collated list [B, N, 4] (ts in [0, 1]) -> [B, num_bins, H, W]."""
-    return _encode_list(event_list, MODE_VOXEL, int(num_bins), sensor_size)
+    return _encode_list(event_list, MODE_VOXEL, int(num_bins), sensor_size, d_event_list)

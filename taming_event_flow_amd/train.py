@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import parallel, synth
-from .dataloader import encodings
+from .dataloader import base as dl_base
 from .loss.flow import Iterative, Linear  # noqa: F401  (selected by name like the reference's eval(...))
 from .models.model import RecEVFlowNet  # noqa: F401
 
@@ -26,38 +26,45 @@ DEFAULT_CONFIG = {     # reference configs/train_flow.yml
 
 class SyntheticSequences:
     """Batch source with the reference loader's batch dict (dataloader/h5.py:413-431 + base.py:392-434 collate):
-    net_input [B,2|bins,H,W], event_list [B,N,4] (ts,y,x,p), event_list_pol_mask [B,N,2], d_event_list,
-    d_event_list_pol_mask; `new_seq` raised every `seq_len` passes.  Events are split into a gradient list of at
-    most `max_num_grad_events` and a detached list (base.py:348-377).  All tensors live on `device`; the input
-    representation is built there by the batched HIP encoder."""
+    net_input [B,2|bins,H,W], event_cnt, event_mask, event_list [B,N,4] (ts,y,x,p), event_list_pol_mask [B,N,2],
+    d_event_list, d_event_list_pol_mask; `new_seq` raised every `seq_len` passes.  Each pass starts from raw event
+    streams (pixel coordinates, raw timestamps, polarity bit) and goes through the batched device loader stage
+    (dataloader/base.py::collate_raw_events: formatting, augmentation, split into at most `max_num_grad_events`
+    gradient events + detached rest, zero-padded collate, input representation) — nothing is staged on the host."""
 
-    def __init__(self, config, device, events_per_pass, seq_len=200, pool=4, seed=0):
+    def __init__(self, config, device, events_per_pass, seq_len=200, pool=4, seed=0, jitter=0):
         self.cfg, self.device = config, device
         self.B = config["loader"]["batch_size"]
         self.H, self.W = config["loader"]["resolution"]
         self.seq_len, self.t = seq_len, 0
         self.new_seq = True
+        self.max_grad = config["loader"]["max_num_grad_events"]
+        aug = config["loader"].get("augment") or []
         rng = np.random.default_rng(seed)
-        ng = min(events_per_pass, config["loader"]["max_num_grad_events"] or events_per_pass)
-        nd = events_per_pass - ng
+        gen = torch.Generator().manual_seed(seed)
         self.pool = []
-        for _ in range(pool):       # a small pool of pre-generated passes, cycled (host RNG is not the subject here)
-            ev, pm = synth.make_event_pass(rng, self.B, ng, self.H, self.W)
-            dev_, dpm = synth.make_event_pass(rng, self.B, nd, self.H, self.W)
-            self.pool.append(tuple(torch.tensor(a, device=device) for a in (ev, pm, dev_, dpm)))
+        for k in range(pool):       # a small pool of pre-generated raw passes, cycled (host RNG is not the subject here)
+            counts = [events_per_pass - int(rng.integers(0, jitter + 1)) for _ in range(self.B)]
+            offs = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+            n = int(offs[-1])
+            raw = {
+                "xs": rng.integers(0, self.W, n).astype(np.float32),
+                "ys": rng.integers(0, self.H, n).astype(np.float32),
+                "ts": np.concatenate([np.sort(rng.random(c)) + float(k) for c in counts] + [[]]).astype(np.float32),
+                "ps": rng.integers(0, 2, n).astype(np.float32),
+            }
+            flags = [sum(dl_base.AUG_BITS[m] for m in aug if rng.random() < 0.5) for _ in range(self.B)]
+            sampled = dl_base.draw_sampled_indices(counts, self.max_grad, gen).to(device)
+            self.pool.append(({k_: torch.tensor(v, device=device) for k_, v in raw.items()}, offs, flags, sampled))
 
     def next(self):
-        ev, pm, dev_, dpm = (a.clone() for a in self.pool[self.t % len(self.pool)])   # update() shifts ts in place
-        allev = torch.cat([ev, dev_], dim=1) if dev_.shape[1] else ev
-        bins = self.cfg["data"]["voxel"]
-        if bins is None:
-            net_input = encodings.event_list_to_channels(allev, (self.H, self.W))
-        else:
-            net_input = encodings.event_list_to_voxel(allev, bins, (self.H, self.W))
+        raw, offs, flags, sampled = self.pool[self.t % len(self.pool)]
+        batch = dl_base.collate_raw_events(raw["xs"], raw["ys"], raw["ts"], raw["ps"], offs, (self.H, self.W),
+                                           max_num_grad_events=self.max_grad, augmentation=flags,
+                                           sampled_indices=sampled, voxel=self.cfg["data"]["voxel"])
         self.new_seq = self.t % self.seq_len == 0
         self.t += 1
-        return {"net_input": net_input, "event_list": ev, "event_list_pol_mask": pm, "d_event_list": dev_,
-                "d_event_list_pol_mask": dpm}
+        return batch
 
 
 class Trainer:

@@ -1,0 +1,81 @@
+"""Loader restatement (oracle/loader.py, parity unpinned: see its header) against hand-computed cases, and the host
+mirror of the reference's static helpers (dataloader/base.py) against it.  CPU only."""
+import numpy as np
+import torch
+
+from oracle import loader
+from taming_event_flow_amd.dataloader.base import BaseDataLoader, draw_sampled_indices
+
+
+def test_formatting_and_mask_by_hand():
+    xs, ys, ts, ps = [3, 0, 7], [1, 2, 5], [10.0, 10.5, 12.0], [1, 0, 1]
+    x, y, t, p = loader.event_formatting(xs, ys, ts, ps)
+    assert t.tolist() == [0.0, 0.25, 1.0] and p.tolist() == [1.0, -1.0, 1.0] and t.dtype == np.float32
+    x2, y2, p2 = loader.augment_events(x, y, p, loader.AUG_HORIZONTAL | loader.AUG_POLARITY, (8, 10))
+    assert x2.tolist() == [6.0, 9.0, 2.0] and y2.tolist() == [1.0, 2.0, 5.0] and p2.tolist() == [-1.0, 1.0, -1.0]
+    x3, y3, _ = loader.augment_events(x, y, p, loader.AUG_VERTICAL, (8, 10))
+    assert x3.tolist() == [3.0, 0.0, 7.0] and y3.tolist() == [6.0, 5.0, 2.0]
+    ev = loader.create_list_encoding(x, y, t, p)
+    assert ev.shape == (4, 3) and ev[:, 1].tolist() == [0.25, 2.0, 0.0, -1.0]        # (ts, y, x, p)
+    m = loader.create_polarity_mask(p)
+    assert m.tolist() == [[1.0, 0.0, 1.0], [0.0, 1.0, 0.0]]
+
+
+def test_split_and_collate_by_hand():
+    ev = np.arange(4 * 6, dtype=np.float32).reshape(4, 6)
+    mk = np.stack([np.arange(6) % 2, 1 - np.arange(6) % 2]).astype(np.float32)
+    g, gm, d, dm = loader.split_event_list(ev, mk, 2, np.array([4, 1]))
+    assert g[0].tolist() == [4.0, 1.0] and d[0].tolist() == [0.0, 2.0, 3.0, 5.0]     # sampled order / stream order
+    assert gm[0].tolist() == [0.0, 1.0] and dm[1].tolist() == [1.0, 1.0, 0.0, 0.0]
+    g2, _, d2, _ = loader.split_event_list(ev, mk, 6, None)                           # not more than the cap: no split
+    assert g2.shape == (4, 6) and d2.shape == (4, 0)
+    g3, _, d3, _ = loader.split_event_list(ev, mk, None, None)
+    assert g3.shape == (4, 6) and d3.shape == (4, 0)
+    out = loader.custom_collate([{"event_list": g, "d_event_list": d, "net_input": np.zeros((2, 3, 3), np.float32)},
+                                 {"event_list": g2, "d_event_list": d2, "net_input": np.ones((2, 3, 3), np.float32)}])
+    assert out["event_list"].shape == (2, 6, 4) and out["d_event_list"].shape == (2, 4, 4)
+    assert out["event_list"][0, :, 0].tolist() == [4.0, 1.0, 0.0, 0.0, 0.0, 0.0]
+    assert out["d_event_list"][1].sum() == 0 and out["net_input"].shape == (2, 2, 3, 3)
+
+
+def test_few_events_become_empty():
+    xs = np.arange(10, dtype=np.float32)
+    it = loader.get_item(xs, xs, xs, np.ones(10), (16, 16), None, 0, None, None)      # h5.py:340-345: <= 10 -> none
+    assert it["event_list"].shape == (4, 0) and it["event_cnt"].sum() == 0 and it["event_mask"].sum() == 0
+    xs = np.arange(11, dtype=np.float32)
+    it = loader.get_item(xs, xs, xs, np.ones(11), (16, 16), None, 0, None, 3)
+    assert it["event_list"].shape == (4, 11) and it["event_cnt"][0].sum() == 11 and it["net_input"].shape == (3, 16, 16)
+    assert it["event_mask"].sum() == 11
+
+
+def test_host_mirror_matches_restatement():
+    rng = np.random.default_rng(3)
+    n = 40
+    xs, ys = rng.integers(0, 12, n).astype(np.float32), rng.integers(0, 9, n).astype(np.float32)
+    ts = np.sort(rng.random(n)).astype(np.float32)
+    ps = (rng.integers(0, 2, n) * 2 - 1).astype(np.float32)
+    ev = BaseDataLoader.create_list_encoding(*(torch.tensor(a) for a in (xs, ys, ts, ps)))
+    mk = BaseDataLoader.create_polarity_mask(torch.tensor(ps))
+    assert np.array_equal(ev.numpy(), loader.create_list_encoding(xs, ys, ts, ps))
+    assert np.array_equal(mk.numpy(), loader.create_polarity_mask(ps))
+    idx = rng.permutation(n)[:15]
+    got = BaseDataLoader.split_event_list(ev, mk, 15, torch.tensor(idx))
+    want = loader.split_event_list(ev.numpy(), mk.numpy(), 15, idx)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.numpy(), b)
+    g = BaseDataLoader.split_event_list(ev, mk, 15)                                   # own multinomial draw
+    assert g[0].shape == (4, 15) and g[2].shape == (4, n - 15)
+    both = torch.cat([g[0], g[2]], dim=1)
+    assert np.array_equal(np.sort(both[0].numpy()), ts)                               # a partition of the events
+    batch = [dict(zip(("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask"), got)),
+             dict(zip(("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask"),
+                      BaseDataLoader.split_event_list(ev[:, :9], mk[:, :9], 15)))]
+    for e in batch:
+        e["gt"] = None
+    out = BaseDataLoader.custom_collate(batch)
+    ref = loader.custom_collate([{k: v.numpy() for k, v in e.items() if v is not None} for e in batch])
+    assert out["gt"] is None
+    for k, v in ref.items():
+        assert np.array_equal(out[k].numpy(), v), k
+    s = draw_sampled_indices([n, 9, 100], 15, torch.Generator().manual_seed(0))
+    assert s.shape == (3, 15) and (s[1] == -1).all() and len(set(s[0].tolist())) == 15 and int(s[2].max()) < 100
