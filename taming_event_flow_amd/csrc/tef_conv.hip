@@ -48,7 +48,15 @@ struct Gather {
                          //  input gradient: mul = 1, div = stride, sgn = -1, only exact multiples contribute)
     int K;               // true reduction length (ci, ky, kx); k >= K reads as zero
     int npix;            // B * OH * OW; pixels >= npix read as zero
+    long npix_src;       // B * SH * SW: elements per channel-of-all-images of a source (bounds of the 16-byte gather)
 };
+
+#ifdef TEF_CONV_STAMP
+__device__ unsigned long long *g_stamps = nullptr;      // experiment hook: per-workgroup phase clocks
+#define STAMP(i) do { if (g_stamps && threadIdx.x == 0) g_stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 struct GemmArgs {
     const float *A;       // A_PLAIN: [rows][lda];  A_NCHW: g [B][rows][hwA] read as A[r][kk = (b, p)]
@@ -129,18 +137,25 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 //                    a row, or belong to strided / transposed-strided geometry fall back to 4 predicated loads.
 //   B, gather^T (wgrad): the tile row is a fixed (ci, ky, kx), the reduction walks over pixels; same 16-byte trick,
 //                    LDS row-major [TC][BK+4].
-template <int TR, int TC, int WR, int WC, int AM, int BM, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
+template <int NT, int TR, int TC, int WR, int WC, int AM, int BM, int EPI, bool QV, bool GATED>
+__global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
 {
-    static_assert((TR / WR) * (TC / WC) == 4, "4 waves per workgroup");
+    static_assert((TR / WR) * (TC / WC) == NT / 64, "one wave per WR x WC sub-tile");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
     static_assert(TC == 128 && BK == 32, "the quad staging below is written for 128 columns x 32 k");
     constexpr int MR = WR / 32, MC = WC / 32;          // MFMA tiles per wave
     constexpr int LDB = TC + 4;                        // k-major B rows (floats), 16-byte multiple
     constexpr int BFLOATS = (BM == B_GATHER) ? BK * LDB : TC * LDK;
-    __shared__ __attribute__((aligned(16))) float As[2][TR][LDK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BFLOATS];
+#ifdef TEF_CONV_SINGLE_BUF
+    constexpr int NBUF = 1;
+#else
+    constexpr int NBUF = 2;
+#endif
+    __shared__ __attribute__((aligned(16))) float As[NBUF][TR][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BFLOATS];
     __shared__ __attribute__((aligned(16))) int soff[BM == B_GATHER ? 9 : 1][BM == B_GATHER ? TC : 4];
 
+    STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / (TC / WC), wc = wave % (TC / WC);
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * TC;
@@ -153,19 +168,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     const int SHW = g.G.SH * g.G.SW;
     const int kk2 = g.G.ks * g.G.ks;
     const int Ct = g.G.C0 + g.G.C1;
+    const bool k3 = kk2 == 9;
 
     // ---- A staging: 4-float pieces (tile row = piece / PPR, k offset = 4 * (piece % PPR)) ----
-    constexpr int AP = (TR * PPR + 255) / 256;
+    constexpr int AP = (TR * PPR + NT - 1) / NT;
     float4 ra[AP];
     auto load_a = [&](int k0) {
+#ifdef TEF_CONV_ABL_NOLOAD
+        for (int p = 0; p < AP; ++p) ra[p] = make_float4(1.f, 2.f, 3.f, (float)k0);
+        return;
+#endif
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            int piece = tid + p * 256;
+            int piece = tid + p * NT;
             int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
-            bool ok = (TR * PPR % 256 == 0 || piece < TR * PPR) && (row0 + r) < g.rows;
+            bool ok = (TR * PPR % NT == 0 || piece < TR * PPR) && (row0 + r) < g.rows;
             if (AM == A_PLAIN) {
-                ra[p] = ok ? *reinterpret_cast<const float4 *>(g.A + (size_t)(row0 + r) * g.lda + k0 + kq)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                // unconditional: rows beyond g.rows (clamped to the last row) only feed output rows that are never stored
+                int rc = min(row0 + r, g.rows - 1);
+                ra[p] = *reinterpret_cast<const float4 *>(g.A + (size_t)rc * g.lda + k0 + kq);
             } else {            // A[r][kk], kk = (image, pixel) of an NCHW tensor with `rows` channels
                 int kk = k0 + kq;
                 int img = kk / g.hwA, px = kk - img * g.hwA;
@@ -186,21 +207,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
     auto store_a = [&](int buf) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            int piece = tid + p * 256;
-            if (TR * PPR % 256 == 0 || piece < TR * PPR)
+            int piece = tid + p * NT;
+            if (TR * PPR % NT == 0 || piece < TR * PPR)
                 *reinterpret_cast<float4 *>(&As[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = ra[p];
         }
     };
 
     // ---- B staging ----
-    constexpr int BP = 4;          // loads per thread per stage in both B modes (128 x 32 floats / 256 threads / 4)
+    constexpr int BP = 1024 / NT;  // 16-byte loads per thread per stage in both B modes (128 x 32 floats / NT / 4)
+    constexpr int KS = NT / 32;    // k slots of the gather
     float4 rb[BP];
-    // B_GATHER: thread = (quad of 4 pixels, k slot); k = k0 + kslot + 8 j
+    // B_GATHER: thread = (quad of 4 pixels, k slot); k = k0 + kslot + KS j
     const int quad = tid & 31, kslot = tid >> 5;
     int qb[4];                     // image index of the quad's pixels
     int ci0 = 0, r0 = 0;           // (ci, tap) of k = k0 + kslot
     if (BM == B_GATHER) {
-        for (int t = tid; t < TC * 9; t += 256) {
+        for (int t = tid; t < TC * 9; t += NT) {
             int r = t / TC, pix = t - r * TC;
             Pix q = decode_pixel(g.G, col0 + pix);
             int off = -1;
@@ -225,111 +247,153 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
         __syncthreads();
     }
     // B_GATHER_T: piece = (tile row = (ci, ky, kx), 4 consecutive pixels of the reduction)
-    const float *tsrc[BP], *tgate[BP];
-    int tky[BP], tkx[BP], tcs[BP];
+    const float *tsrc[BP], *tgate[BP];      // source tensor (and gate) of the tile row's channel, null beyond K
+    int tky[BP], tkx[BP], tcs[BP], tcl[BP];  // tap, channels of that source, channel index within it
     if (BM == B_GATHER_T) {
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
-            int k = col0 + ((tid + p * 256) >> LOGP);
+            int k = col0 + ((tid + p * NT) >> LOGP);
             int ci = k / kk2, r = k - ci * kk2;
             tky[p] = r / g.G.ks;
             tkx[p] = r - tky[p] * g.G.ks;
             bool second = ci >= g.G.C0;
             tcs[p] = second ? g.G.C1 : g.G.C0;
-            int cl = second ? ci - g.G.C0 : ci;
-            tsrc[p] = k < g.G.K ? (second ? g.G.src1 : g.G.src0) + (size_t)cl * SHW : nullptr;
-            tgate[p] = (k < g.G.K && second && g.G.gate1) ? g.G.gate1 + (size_t)cl * SHW : nullptr;
+            tcl[p] = second ? ci - g.G.C0 : ci;
+            tsrc[p] = k < g.G.K ? (second ? g.G.src1 : g.G.src0) : nullptr;
+            tgate[p] = (k < g.G.K && second && g.G.gate1) ? g.G.gate1 : nullptr;
         }
     }
 
+    // Loads only ISSUE here (values, gate values and validity bits stay in registers); masking and the gating product
+    // happen in store_b, after the MFMA block.  Every destination register has exactly one (predicated) load writing
+    // it — no if/else merges of loaded values, which would make the compiler wait for memory inside the load phase — so
+    // all gathers of a stage are in flight together.
+    //   QV (stride-1 geometry, rows a multiple of 4 pixels): the valid elements of a quad are contiguous in the source
+    //   row, so ONE 16-byte load anchored at element 0's (possibly out-of-row) position covers them; invalid elements
+    //   are masked at store.  At the two ends of a source tensor the anchor would fall 1 element outside the
+    //   allocation: the load is moved by one element and the value rotated back at store (shift flag).
+    float4 rg[BP];                 // gate values of the second source (ConvGRU reset gate), when present
+    unsigned bmask = 0;            // bit 4j+e: element e of load j valid;  bit 16+j: load j gated;  bits 20+2j: shift
+    constexpr bool has_gate = GATED;
+    // every load is unconditional (invalid lanes read element 0 of the tensor and are masked at store)
+    auto quad_load = [&](int j, const float *src, bool gated, long flat, long total, unsigned vm) {
+        unsigned sh = 0;
+        if (flat < 0) { flat += 1; sh = 1; }
+        else if (flat + 3 >= total) { flat -= 1; sh = 2; }
+        if (!vm) { flat = 0; sh = 0; }
+        f32x4_a4 t = *reinterpret_cast<const f32x4_a4 *>(src + flat);
+        rb[j] = make_float4(t.x, t.y, t.z, t.w);
+        if (has_gate) {
+            f32x4_a4 gt = *reinterpret_cast<const f32x4_a4 *>(g.G.gate1 + (gated ? flat : 0));
+            rg[j] = make_float4(gt.x, gt.y, gt.z, gt.w);
+            if (gated && vm) bmask |= 1u << (16 + j);
+        }
+        bmask |= (vm << (4 * j)) | (sh << (20 + 2 * j));
+    };
+    auto elem_load = [&](int j, int e, const float *src, bool gated, size_t o, bool ok) {
+        float *v = reinterpret_cast<float *>(&rb[j]), *gv = reinterpret_cast<float *>(&rg[j]);
+        o = ok ? o : 0;
+        v[e] = src[o];
+        if (has_gate) gv[e] = g.G.gate1[gated ? o : 0];
+        if (ok) bmask |= 1u << (4 * j + e);
+        if (ok && gated && has_gate) bmask |= 1u << (16 + j);
+    };
     auto load_b = [&](int k0) {
+#ifdef TEF_CONV_ABL_NOLOAD
+        for (int p = 0; p < BP; ++p) rb[p] = make_float4(1.f, 2.f, 3.f, (float)k0);
+        bmask = 0xffffu;
+        return;
+#endif
+        bmask = 0;
         if (BM == B_GATHER) {
             int ci = ci0, rr = r0;
 #pragma unroll
             for (int j = 0; j < BP; ++j) {
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (ci < Ct) {
-                    i32x4 so = *reinterpret_cast<const i32x4 *>(&soff[rr][4 * quad]);
-                    bool second = ci >= g.G.C0;
-                    const float *src = second ? g.G.src1 : g.G.src0;
-                    int cs = second ? g.G.C1 : g.G.C0, cl = second ? ci - g.G.C0 : ci;
-                    bool contiguous = (so.x >= 0) & (so.y == so.x + 1) & (so.z == so.x + 2) & (so.w == so.x + 3) &
-                                      (qb[0] == qb[3]);
-                    if (contiguous) {
-                        size_t o = ((size_t)qb[0] * cs + cl) * SHW + so.x;
-                        f32x4_a4 t = *reinterpret_cast<const f32x4_a4 *>(src + o);
-                        if (second && g.G.gate1) {
-                            f32x4_a4 gt = *reinterpret_cast<const f32x4_a4 *>(g.G.gate1 + o);
-                            t *= gt;
-                        }
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
-                        const int sov[4] = {so.x, so.y, so.z, so.w};
+                bool in_k = ci < Ct;
+                int cc = in_k ? ci : 0;
+                i32x4 so = *reinterpret_cast<const i32x4 *>(&soff[rr][4 * quad]);
+                bool second = cc >= g.G.C0;
+                const float *src = second ? g.G.src1 : g.G.src0;
+                int cs = second ? g.G.C1 : g.G.C0, cl = second ? cc - g.G.C0 : cc;
+                unsigned vm = (so.x >= 0 ? 1u : 0u) | (so.y >= 0 ? 2u : 0u) | (so.z >= 0 ? 4u : 0u) | (so.w >= 0 ? 8u : 0u);
+                if (!in_k) vm = 0;
+                if (QV) {
+                    int o0 = so.x >= 0 ? so.x : (so.y >= 0 ? so.y - 1 : (so.z >= 0 ? so.z - 2 : so.w - 3));
+                    quad_load(j, src, second, ((long)qb[0] * cs + cl) * SHW + o0, g.G.npix_src * cs, vm);
+                } else {
+                    const int sov[4] = {so.x, so.y, so.z, so.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (sov[e] < 0) continue;
-                            size_t o = ((size_t)qb[e] * cs + cl) * SHW + sov[e];
-                            float t = src[o];
-                            v[e] = (second && g.G.gate1) ? t * g.G.gate1[o] : t;
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        elem_load(j, e, src, second, ((size_t)qb[e] * cs + cl) * SHW + sov[e], (vm >> e) & 1u);
                 }
-                rb[j] = make_float4(v[0], v[1], v[2], v[3]);
-                // k += 8
-                if (kk2 == 9) { rr += 8; if (rr >= 9) { rr -= 9; ++ci; } }
-                else ci += 8;
+                // k += KS (branch-free: nothing but straight-line code between a load and its use)
+                ci += k3 ? KS / 9 : KS;
+                rr += k3 ? KS % 9 : 0;
+                int wrap = rr >= 9 ? 1 : 0;
+                rr -= 9 * wrap;
+                ci += wrap;
             }
             // k0 += BK (32) for the next stage
-            if (kk2 == 9) { ci0 += 3; r0 += 5; if (r0 >= 9) { r0 -= 9; ++ci0; } }
-            else ci0 += BK;
+            ci0 += k3 ? 3 : BK;
+            r0 += k3 ? 5 : 0;
+            int wrap0 = r0 >= 9 ? 1 : 0;
+            r0 -= 9 * wrap0;
+            ci0 += wrap0;
         } else {
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
-                int piece = tid + p * 256;
+                int piece = tid + p * NT;
                 int r = piece >> LOGP, kq = (piece & (PPR - 1)) * 4;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if ((col0 + r) < g.cols && tsrc[p]) {
-                    int m = k0 + kq;
-                    Pix q = decode_pixel(g.G, m);
-                    int ty = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
-                    int tx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
-                    bool fast = (g.G.mul == 1) & (m + 3 < g.G.npix) & (q.px + 3 < g.G.OW) & (ty >= 0) & (ty < g.G.SH) &
-                                (tx >= 0) & (tx + 3 < g.G.SW);
-                    if (fast) {
-                        size_t o = (size_t)q.b * tcs[p] * SHW + ty * g.G.SW + tx;
-                        f32x4_a4 t = *reinterpret_cast<const f32x4_a4 *>(tsrc[p] + o);
-                        if (tgate[p]) t *= *reinterpret_cast<const f32x4_a4 *>(tgate[p] + o);
-                        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-                    } else {
+                bool row_ok = (col0 + r) < g.cols && tsrc[p] != nullptr;
+                const float *src = tsrc[p] ? tsrc[p] : g.G.src0;
+                bool gated = tgate[p] != nullptr;
+                int m = k0 + kq;
+                Pix q = decode_pixel(g.G, m);
+                if (QV) {          // 4 pixels of one row: source (ty, tx .. tx + 3)
+                    int ty = q.py + g.G.sgn * (tky[p] - g.G.pad), tx = q.px + g.G.sgn * (tkx[p] - g.G.pad);
+                    unsigned vm = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (m + j < g.G.npix) {
-                                int yy = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
-                                int xx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
-                                if (yy >= 0 && xx >= 0 && yy < g.G.SH && xx < g.G.SW) {
-                                    size_t o = (size_t)q.b * tcs[p] * SHW + yy * g.G.SW + xx;
-                                    float t = tsrc[p][o];
-                                    v[j] = tgate[p] ? t * tgate[p][o] : t;
-                                }
-                            }
-                            if (++q.px == g.G.OW) { q.px = 0; if (++q.py == g.G.OH) { q.py = 0; ++q.b; } }
-                        }
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < g.G.npix && tx + e >= 0 && tx + e < g.G.SW) vm |= 1u << e;
+                    if (!row_ok || ty < 0 || ty >= g.G.SH) vm = 0;
+                    quad_load(p, src, gated, ((long)q.b * tcs[p] + tcl[p]) * SHW + ty * g.G.SW + tx, g.G.npix_src * tcs[p], vm);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        int yy = q.py * g.G.mul + g.G.sgn * (tky[p] - g.G.pad);
+                        int xx = q.px * g.G.mul + g.G.sgn * (tkx[p] - g.G.pad);
+                        bool ok = row_ok && (m + j < g.G.npix) && yy >= 0 && xx >= 0 && yy < g.G.SH && xx < g.G.SW;
+                        elem_load(p, j, src, gated, ((size_t)q.b * tcs[p] + tcl[p]) * SHW + yy * g.G.SW + xx, ok);
+                        if (++q.px == g.G.OW) { q.px = 0; if (++q.py == g.G.OH) { q.py = 0; ++q.b; } }
                     }
                 }
-                rb[p] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+    };
+    // the masked, gated value of load j as it goes to LDS
+    auto staged = [&](int j) {
+        float4 v = rb[j];
+        if (bmask & (1u << (16 + j))) { v.x *= rg[j].x; v.y *= rg[j].y; v.z *= rg[j].z; v.w *= rg[j].w; }
+        unsigned sh = (bmask >> (20 + 2 * j)) & 3u;
+        if (sh == 1) v = make_float4(0.f, v.x, v.y, v.z);
+        else if (sh == 2) v = make_float4(v.y, v.z, v.w, 0.f);
+        unsigned m = bmask >> (4 * j);
+        v.x = (m & 1u) ? v.x : 0.0f;
+        v.y = (m & 2u) ? v.y : 0.0f;
+        v.z = (m & 4u) ? v.z : 0.0f;
+        v.w = (m & 8u) ? v.w : 0.0f;
+        return v;
     };
     auto store_b = [&](int buf) {
         if (BM == B_GATHER) {
 #pragma unroll
             for (int j = 0; j < BP; ++j)
-                *reinterpret_cast<float4 *>(&Bs[buf][(kslot + 8 * j) * LDB + 4 * quad]) = rb[j];
+                *reinterpret_cast<float4 *>(&Bs[buf][(kslot + KS * j) * LDB + 4 * quad]) = staged(j);
         } else {
 #pragma unroll
             for (int p = 0; p < BP; ++p) {
-                int piece = tid + p * 256;
-                *reinterpret_cast<float4 *>(&Bs[buf][(piece >> LOGP) * LDK + (piece & (PPR - 1)) * 4]) = rb[p];
+                int piece = tid + p * NT;
+                *reinterpret_cast<float4 *>(&Bs[buf][(piece >> LOGP) * LDK + (piece & (PPR - 1)) * 4]) = staged(p);
             }
         }
     };
@@ -342,19 +406,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    load_a(k_begin);
-    load_b(k_begin);
-    store_a(0);
-    store_b(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = k_begin; k0 < k_end; k0 += BK) {
-        bool more = (k0 + BK) < k_end;
-        if (more) {                 // next stage in flight while this one is multiplied
-            load_a(k0 + BK);
-            load_b(k0 + BK);
-        }
-        // lane l feeds row/col (l & 31) and k = 4 * (l >> 5) + j of each 8-wide half stage
+    // one k-stage of MFMAs from LDS buffer `buf`: lane l feeds row/col (l & 31) and k = 4 * (l >> 5) + j of each
+    // 8-wide half stage
+    auto multiply = [&](int buf) {
 #pragma unroll
         for (int kh = 0; kh < BK; kh += 8) {
             float4 fa[MR], fb[MC];
@@ -374,19 +428,59 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < MC; ++j) {
+#ifdef TEF_CONV_ABL_NOMFMA
+                    acc[i][j][0] += fa[i].x * fb[j].x + fa[i].y * fb[j].y + fa[i].z * fb[j].z + fa[i].w * fb[j].w;
+                    continue;
+#endif
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) {
+    };
+    // The values in flight must not be touched before the MFMA block is issued: the compiler otherwise hoists the
+    // copies / selects of store_b up to the loads and waits for memory there.  The loop body is straight-line (last
+    // stage peeled), a scheduling barrier closes the MFMA block and the registers are re-defined by an empty asm.
+    auto pin = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < AP; ++p) asm volatile("" : "+v"(ra[p].x), "+v"(ra[p].y), "+v"(ra[p].z), "+v"(ra[p].w));
+#pragma unroll
+        for (int p = 0; p < BP; ++p) {
+            asm volatile("" : "+v"(rb[p].x), "+v"(rb[p].y), "+v"(rb[p].z), "+v"(rb[p].w));
+            if (GATED) asm volatile("" : "+v"(rg[p].x), "+v"(rg[p].y), "+v"(rg[p].z), "+v"(rg[p].w));
+        }
+        asm volatile("" : "+v"(bmask));
+    };
+
+    load_a(k_begin);
+    load_b(k_begin);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+    STAMP(1);
+    int buf = 0;
+    for (int k0 = k_begin + BK; k0 < k_end; k0 += BK) {
+        load_a(k0);                 // next stage in flight while this one is multiplied
+        load_b(k0);
+        __builtin_amdgcn_sched_barrier(0);      // every load is issued before the first MFMA
+        multiply(buf);
+        pin();
+        if (NBUF == 1) {
+            __syncthreads();        // everyone has read this stage
+            store_a(0);
+            store_b(0);
+            __syncthreads();
+        } else {
             store_a(buf ^ 1);
             store_b(buf ^ 1);
             __syncthreads();
             buf ^= 1;
         }
     }
+    multiply(buf);
+    STAMP(2);
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -419,6 +513,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g)
                 }
             }
         }
+    STAMP(3);
 }
 
 // split-K epilogue: out = act(bias[r] + sum_z slab[z][r][c]) scattered to the NCHW output(s)
@@ -522,21 +617,33 @@ __global__ __launch_bounds__(256) void gru_blend_bwd_kernel(const float *__restr
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+template <int AM, int BM, int EPI, bool QV, bool GATED>
+int launch_gemm_qv(const GemmArgs &g, int zsplits, hipStream_t st)
+{
+    // 8 waves per workgroup (2 x 4 wave grid): with the 75 KB of LDS of a double-buffered 128 x 128 x 32 stage two
+    // workgroups fit a CU, i.e. 4 waves per SIMD — the MFMA pipe stays fed while other waves gather and stage
+    if (g.rows > 64) {
+        dim3 grid((g.cols + 127) / 128, (g.rows + 127) / 128, zsplits);
+        hipLaunchKernelGGL((gemm_nt_kernel<512, 128, 128, 64, 32, AM, BM, EPI, QV, GATED>), grid, dim3(512), 0, st, g);
+    } else if (g.rows > 32) {
+        dim3 grid((g.cols + 127) / 128, (g.rows + 63) / 64, zsplits);
+        hipLaunchKernelGGL((gemm_nt_kernel<512, 64, 128, 32, 32, AM, BM, EPI, QV, GATED>), grid, dim3(512), 0, st, g);
+    } else {
+        dim3 grid((g.cols + 127) / 128, (g.rows + 31) / 32, zsplits);
+        hipLaunchKernelGGL((gemm_nt_kernel<256, 32, 128, 32, 32, AM, BM, EPI, QV, GATED>), grid, dim3(256), 0, st, g);
+    }
+    return tef::check_launch("gemm_nt_kernel");
+}
+
 template <int AM, int BM, int EPI>
 int launch_gemm(const GemmArgs &g, int zsplits, hipStream_t st)
 {
-    dim3 block(256);
-    if (g.rows > 64) {
-        dim3 grid((g.cols + 127) / 128, (g.rows + 127) / 128, zsplits);
-        hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64, 64, AM, BM, EPI>), grid, block, 0, st, g);
-    } else if (g.rows > 32) {
-        dim3 grid((g.cols + 127) / 128, (g.rows + 63) / 64, zsplits);
-        hipLaunchKernelGGL((gemm_nt_kernel<64, 128, 64, 32, AM, BM, EPI>), grid, block, 0, st, g);
-    } else {
-        dim3 grid((g.cols + 127) / 128, (g.rows + 31) / 32, zsplits);
-        hipLaunchKernelGGL((gemm_nt_kernel<32, 128, 32, 32, AM, BM, EPI>), grid, block, 0, st, g);
-    }
-    return tef::check_launch("gemm_nt_kernel");
+    // quad-vector gathers need stride-1 geometry and rows / images that are multiples of 4 pixels
+    const Gather &G = g.G;
+    bool qv = G.mul == 1 && G.div == 1 && (G.OW & 3) == 0 && ((G.OH * G.OW) & 3) == 0 && G.SH == G.OH && G.SW == G.OW;
+    if (G.gate1)
+        return qv ? launch_gemm_qv<AM, BM, EPI, true, true>(g, zsplits, st) : launch_gemm_qv<AM, BM, EPI, false, true>(g, zsplits, st);
+    return qv ? launch_gemm_qv<AM, BM, EPI, true, false>(g, zsplits, st) : launch_gemm_qv<AM, BM, EPI, false, false>(g, zsplits, st);
 }
 
 // GEMMs with few output tiles and a long reduction (deep levels: M = B*h*w = 512 at 8x8, K up to 9216) are split over
@@ -545,8 +652,11 @@ inline int k_splits(int rows, int cols, int K)
 {
     int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
     int tiles = ((cols + 127) / 128) * ((rows + tr - 1) / tr);
-    if (tiles >= 192 || K < 512) return 1;
-    int z = (384 + tiles - 1) / tiles;
+#ifndef TEF_CONV_WG_TARGET
+#define TEF_CONV_WG_TARGET 512          // two 512-thread workgroups per CU
+#endif
+    if (tiles >= TEF_CONV_WG_TARGET / 2 || K < 512) return 1;
+    int z = (TEF_CONV_WG_TARGET + tiles - 1) / tiles;
     int zmax = K / 128;
     if (z > zmax) z = zmax;
     if (z > 16) z = 16;
@@ -600,13 +710,20 @@ Gather forward_gather(const tef_conv_desc *d, const Geo &q, const float *x0, con
     G.src0 = x0; G.src1 = x1; G.gate1 = gate1;
     G.C0 = d->C0; G.C1 = d->C1; G.SH = d->H; G.SW = d->W; G.OH = q.Ho; G.OW = q.Wo;
     G.ks = d->ksize; G.pad = d->ksize / 2; G.mul = d->stride; G.div = 1; G.sgn = 1;
-    G.K = q.K; G.npix = q.M;
+    G.K = q.K; G.npix = q.M; G.npix_src = (long)d->B * d->H * d->W;
     return G;
 }
 
 }  // namespace
 
 extern "C" {
+
+#ifdef TEF_CONV_STAMP
+int tef_debug_set_stamps(unsigned long long *p)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 size_t tef_conv_workspace_bytes(const tef_conv_desc *d)
 {
@@ -716,7 +833,7 @@ int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, 
         G.src0 = gsrc; G.src1 = nullptr; G.gate1 = nullptr;
         G.C0 = N; G.C1 = 0; G.SH = q.Ho; G.SW = q.Wo; G.OH = d->H; G.OW = d->W;
         G.ks = d->ksize; G.pad = d->ksize / 2; G.mul = 1; G.div = d->stride; G.sgn = -1;
-        G.K = q.K2; G.npix = q.Min;
+        G.K = q.K2; G.npix = q.Min; G.npix_src = (long)d->B * q.Ho * q.Wo;
         g.G = G;
         g.cols = q.Min; g.K = q.K2p;
         g.C = dx0; g.C2 = dx1; g.split = d->C0; g.bias = nullptr; g.act = TEF_ACT_NONE; g.hw = d->H * d->W;
