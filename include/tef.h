@@ -196,6 +196,13 @@ int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, c
 int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
                       const float *w2, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with two accumulation targets: output channels [0, split_rows) add into dweight / dbias, channels
+ * [split_rows, N) into dweight2 / dbias2 — the gradients of two row-concatenated parameters (ConvGRU update | reset
+ * gates, submodules.py:122-123) go straight into their own .grad buffers, no temporary, no extra add. */
+int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                            const float *w2, const float *out, const float *dout, float *dx0, float *dx1,
+                            float *dweight, float *dweight2, float *dbias, float *dbias2, int split_rows,
+                            void *workspace, size_t workspace_bytes, void *stream);
 /* ConvGRU state update new_state = prev * (1 - update) + out_inputs * update (submodules.py:150) and its backward
  * (dh = direct path only; the paths through the gates go through tef_conv_backward). n = element count. */
 int tef_gru_blend(const float *h, const float *u, const float *o, size_t n, float *out, void *stream);

@@ -508,8 +508,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
                     else g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
                 } else if (EPI == EPI_SLAB) {
                     g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + c] = v;
-                } else {
-                    atomicAdd(g.C + (size_t)r * g.ldc + c, v);
+                } else {        // rows < split accumulate into C, the rest into C2 (row-concatenated parameters)
+                    atomicAdd(r < g.split ? g.C + (size_t)r * g.ldc + c : g.C2 + (size_t)(r - g.split) * g.ldc + c, v);
                 }
             }
         }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 // db[n] += sum over batch and pixels of g.   One block row per channel.
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ out,
                                                       int act, int B, int N, int HW, float *__restrict__ gbuf,
-                                                      float *__restrict__ dbias)
+                                                      float *__restrict__ dbias, float *__restrict__ dbias2, int split)
 {
     __shared__ float red[256];
     int n = blockIdx.y;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(dbias + n, red[0]);
+    if (threadIdx.x == 0) atomicAdd(n < split ? dbias + n : dbias2 + (n - split), red[0]);
 }
 
 // weight part [rows][Ct][ks][ks] -> rows [row0, row0 + rows) of
@@ -789,10 +789,21 @@ int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, 
                       const float *out, const float *dout, float *dx0, float *dx1, float *dweight, float *dbias,
                       void *workspace, size_t workspace_bytes, void *stream)
 {
+    return tef_conv_backward_split(d, x0, x1, gate1, w2, out, dout, dx0, dx1, dweight, nullptr, dbias, nullptr,
+                                   d ? d->N : 0, workspace, workspace_bytes, stream);
+}
+
+int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                            const float *w2, const float *out, const float *dout, float *dx0, float *dx1,
+                            float *dweight, float *dweight2, float *dbias, float *dbias2, int split_rows,
+                            void *workspace, size_t workspace_bytes, void *stream)
+{
     Geo q;
     if (!make_geo(d, &q)) return TEF_ERR_INVALID;
     if (!x0 || (d->C1 > 0 && !x1) || !dout || !workspace) return tef::fail("tef_conv_backward: null pointer"), TEF_ERR_INVALID;
     if (d->act != TEF_ACT_NONE && !out) return tef::fail("tef_conv_backward: activation needs the forward output"), TEF_ERR_INVALID;
+    if (split_rows < 0 || split_rows > d->N || (split_rows < d->N && ((dweight && !dweight2) || (dbias && !dbias2))))
+        return tef::fail("tef_conv_backward: rows beyond split_rows need dweight2 / dbias2"), TEF_ERR_INVALID;
     const bool need_dx = dx0 || dx1;
     if (need_dx && !w2) return tef::fail("tef_conv_backward: input gradient needs the packed weight w2"), TEF_ERR_INVALID;
     if (need_dx && ((d->C1 > 0) != (dx1 != nullptr) || !dx0))
@@ -807,7 +818,8 @@ int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, 
 
     if (d->act != TEF_ACT_NONE || dbias) {   // g = dY * act'(out) (+ bias gradient)
         dim3 grid((unsigned)std::min<size_t>(64, ((size_t)q.M + 255) / 256), N);
-        hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, out, d->act, d->B, N, HW, gbuf, dbias);
+        hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, out, d->act, d->B, N, HW, gbuf, dbias, dbias2,
+                           split_rows);
         if (int rc = tef::check_launch("act_bwd_kernel")) return rc;
         if (d->act != TEF_ACT_NONE) gsrc = gbuf;
     }
@@ -816,7 +828,7 @@ int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, 
         g.A = gsrc; g.rows = N; g.hwA = HW;
         g.G = forward_gather(d, q, x0, x1, gate1);
         g.cols = q.Kp; g.K = q.Mp;
-        g.C = dweight; g.ldc = q.K; g.valid_cols = q.K;
+        g.C = dweight; g.C2 = dweight2; g.split = split_rows; g.ldc = q.K; g.valid_cols = q.K;
         int tiles = ((q.Kp + 127) / 128) * ((N + 127) / 128);
         int want = std::max(1, 512 / std::max(1, tiles));
         int ks = round_up((q.Mp + want - 1) / want, BK);

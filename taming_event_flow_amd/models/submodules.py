@@ -30,6 +30,9 @@ class PackedWeights:
     def __init__(self):
         self.key = None
         self.wp = self.wt = None
+        # training loops that own pre-allocated .grad buffers (train.Trainer's flat bucket) switch this on: the weight /
+        # bias gradients are then accumulated by the kernel straight into .grad (no temporary, no autograd add)
+        self.direct_grads = False
 
     def get(self, weights, desc):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (desc.C0 + desc.C1, desc.N, desc.ksize)
@@ -82,6 +85,7 @@ class _ConvFn(torch.autograd.Function):
                                   out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr())
         _lib.check(rc, "tef_conv_forward")
         ctx.desc, ctx.nw, ctx.wt = d, nw, wt
+        ctx.packer, ctx.params = packer, (weights, biases)
         ctx.rows = [w.shape[0] for w in weights]
         ctx.wshape = tuple(weights[0].shape[1:])
         ctx.has = (x1 is not None, gate1 is not None, bias is not None)
@@ -102,14 +106,28 @@ class _ConvFn(torch.autograd.Function):
         dxg = torch.empty_like(x1) if (has_x1 and need_dx) else None
         need_w = any(need[7:7 + nw])
         need_b = has_bias and any(need[7 + nw:])
-        dw = torch.zeros((d.N,) + ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
-        db = torch.zeros((d.N,), dtype=torch.float32, device=dev) if need_b else None
         nbytes = lib.tef_conv_workspace_bytes(ctypes.byref(d))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        rc = lib.tef_conv_backward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(), _ptr(out),
-                                   dout.data_ptr(), _ptr(dx0), _ptr(dxg), _ptr(dw), _ptr(db), ws.data_ptr(), nbytes,
-                                   _lib.stream_ptr())
-        _lib.check(rc, "tef_conv_backward")
+        weights, biases = ctx.params
+        direct = (ctx.packer.direct_grads and nw <= 2 and need_w and all(need[7:7 + nw])
+                  and all(w.grad is not None and w.grad.is_contiguous() for w in weights)
+                  and (not has_bias or all(b.grad is not None and b.grad.is_contiguous() for b in biases)))
+        if direct:      # the kernel adds into the parameters' own .grad buffers
+            dws = [w.grad.data_ptr() for w in weights] + [None]
+            dbs = ([b.grad.data_ptr() for b in biases] + [None]) if has_bias else [None, None]
+            rc = lib.tef_conv_backward_split(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
+                                             _ptr(out), dout.data_ptr(), _ptr(dx0), _ptr(dxg), dws[0], dws[1], dbs[0],
+                                             dbs[1], ctx.rows[0] if nw == 2 else d.N, ws.data_ptr(), nbytes,
+                                             _lib.stream_ptr())
+            _lib.check(rc, "tef_conv_backward_split")
+            dw = db = None
+        else:
+            dw = torch.zeros((d.N,) + ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
+            db = torch.zeros((d.N,), dtype=torch.float32, device=dev) if need_b else None
+            rc = lib.tef_conv_backward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
+                                       _ptr(out), dout.data_ptr(), _ptr(dx0), _ptr(dxg), _ptr(dw), _ptr(db),
+                                       ws.data_ptr(), nbytes, _lib.stream_ptr())
+            _lib.check(rc, "tef_conv_backward")
         if not need[4]:
             dx0 = None
         dx1 = dgate = None
@@ -127,6 +145,18 @@ class _ConvFn(torch.autograd.Function):
         if not has_bias:
             gb = [None] * (len(need) - 7 - nw)
         return (None, None, None, None, dx0, dx1, dgate) + tuple(gw) + tuple(gb)
+
+
+def enable_direct_grads(module, on=True):
+    """Let every convolution of `module` accumulate its parameter gradients straight into the pre-allocated .grad
+    buffers (the caller owns them and runs loss.backward(); not for torch.autograd.grad on the parameters)."""
+    n = 0
+    for m in module.modules():
+        for v in vars(m).values():
+            if isinstance(v, PackedWeights):
+                v.direct_grads = on
+                n += 1
+    return n
 
 
 def conv2d(packer, x0, weights, biases, stride=1, act=None, x1=None, gate1=None):

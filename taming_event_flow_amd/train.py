@@ -12,6 +12,7 @@ import torch
 from . import parallel, synth
 from .dataloader import base as dl_base
 from .loss.flow import Iterative, Linear  # noqa: F401  (selected by name like the reference's eval(...))
+from .models import submodules
 from .models.model import RecEVFlowNet  # noqa: F401
 
 DEFAULT_CONFIG = {     # reference configs/train_flow.yml
@@ -77,6 +78,7 @@ class Trainer:
         self.model.train()
         self.loss_function = eval(config["loss"]["warping"])(config, device)
         self.bucket = parallel.FlatGradBucket(self.model.parameters())
+        submodules.enable_direct_grads(self.model)      # conv kernels add into the bucket's .grad views
         opt_kwargs = {"lr": config["optimizer"]["lr"]}
         if config["optimizer"].get("capturable"):
             opt_kwargs["capturable"] = True      # optimiser state stays on the device: the window can live in a hipGraph
