@@ -173,11 +173,14 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     // ---- A staging: 4-float pieces (tile row = piece / PPR, k offset = 4 * (piece % PPR)) ----
     constexpr int AP = (TR * PPR + NT - 1) / NT;
     float4 ra[AP];
+    unsigned amask = 0;            // A_NCHW: bit 4p+e = element e of piece p is inside the reduction range
     auto load_a = [&](int k0) {
 #ifdef TEF_CONV_ABL_NOLOAD
         for (int p = 0; p < AP; ++p) ra[p] = make_float4(1.f, 2.f, 3.f, (float)k0);
+        amask = 0xffffu;
         return;
 #endif
+        amask = 0;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             int piece = tid + p * NT;
@@ -188,18 +191,25 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
                 int rc = min(row0 + r, g.rows - 1);
                 ra[p] = *reinterpret_cast<const float4 *>(g.A + (size_t)rc * g.lda + k0 + kq);
             } else {            // A[r][kk], kk = (image, pixel) of an NCHW tensor with `rows` channels
+                // unconditional loads (out-of-range pieces read element 0 and are zeroed at store): no if/else merge of
+                // loaded values, nothing in the load phase waits on memory
                 int kk = k0 + kq;
                 int img = kk / g.hwA, px = kk - img * g.hwA;
-                if (ok && (g.hwA & 3) == 0 && kk + 3 < g.G.npix) {
-                    ra[p] = *reinterpret_cast<const float4 *>(g.A + ((size_t)img * g.rows + row0 + r) * g.hwA + px);
+                if (QV) {       // images are multiples of 4 pixels: the piece is inside one image, all in or all out
+                    bool in = ok && kk < g.G.npix;
+                    size_t o = in ? ((size_t)img * g.rows + row0 + r) * g.hwA + px : 0;
+                    ra[p] = *reinterpret_cast<const float4 *>(g.A + o);
+                    if (in) amask |= 0xfu << (4 * p);
                 } else {
-                    float v[4];
+                    float *v = reinterpret_cast<float *>(&ra[p]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        v[j] = (ok && kk + j < g.G.npix) ? g.A[((size_t)img * g.rows + row0 + r) * g.hwA + px] : 0.0f;
+                        bool in = ok && kk + j < g.G.npix;
+                        size_t o = in ? ((size_t)img * g.rows + row0 + r) * g.hwA + px : 0;
+                        v[j] = g.A[o];
+                        if (in) amask |= 1u << (4 * p + j);
                         if (++px == g.hwA) { px = 0; ++img; }
                     }
-                    ra[p] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -208,8 +218,16 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             int piece = tid + p * NT;
+            float4 v = ra[p];
+            if (AM == A_NCHW) {
+                unsigned m = amask >> (4 * p);
+                v.x = (m & 1u) ? v.x : 0.0f;
+                v.y = (m & 2u) ? v.y : 0.0f;
+                v.z = (m & 4u) ? v.z : 0.0f;
+                v.w = (m & 8u) ? v.w : 0.0f;
+            }
             if (TR * PPR % NT == 0 || piece < TR * PPR)
-                *reinterpret_cast<float4 *>(&As[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = ra[p];
+                *reinterpret_cast<float4 *>(&As[buf][piece >> LOGP][(piece & (PPR - 1)) * 4]) = v;
         }
     };
 
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < AP; ++p) asm volatile("" : "+v"(ra[p].x), "+v"(ra[p].y), "+v"(ra[p].z), "+v"(ra[p].w));
+        if (AM == A_NCHW) asm volatile("" : "+v"(amask));
 #pragma unroll
         for (int p = 0; p < BP; ++p) {
             asm volatile("" : "+v"(rb[p].x), "+v"(rb[p].y), "+v"(rb[p].z), "+v"(rb[p].w));
