@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--res", type=int, nargs=2, default=[128, 128])
     ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
     ap.add_argument("--warping", default="Iterative", choices=["Iterative", "Linear"])
-    ap.add_argument("--mode", default="loss", choices=["loss", "train"],
+    ap.add_argument("--mode", default="loss", choices=["loss", "train", "eval"],
                     help="loss: IWE + contrast-max loss fwd+bwd (BASELINE.json metric, configs[1]); "
                          "train: full training window, RecEVFlowNet + loss + DP all-reduce + Adam (configs[2]/[3])")
     ap.add_argument("--graph", action="store_true", help="train mode: replay the window from a captured hipGraph")
@@ -137,6 +137,8 @@ def main():
     lib = _lib.lib()
     if a.mode == "train":
         return bench_train(a, torch, dist, dev, rank, world, lib)
+    if a.mode == "eval":
+        return bench_eval(a, torch, dist, dev, rank, world, lib)
     H, W = a.res
     B, P, F = a.batch, a.passes, a.heads
     cfg = make_cfg(a)
@@ -368,6 +370,81 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
             "conv_gflop_per_pass_fwd": round(fl_pass / 1e9, 2),
             "roofline": roofline,
             "kernels_ms_per_window": {k: round(v[0] / a.steps, 4) for k, v in kern.items()},
+        }
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_eval(a, torch, dist, dev, rank, world, lib):
+    """DSEC-eval-shape inference (BASELINE.json configs[4], reference eval_flow.py:70-175): replicas only — every rank
+    runs its own sequence at batch 1 (eval_flow.py:30 hard-wires it), no collective in the data path.  One step = one
+    metric window: P x (device loader stage on raw events, RecEVFlowNet forward, x flow_scaling, validation update:
+    forward / backward event warping, forward-propagated and accumulated flow) + FWL + RSAT, then reset."""
+    import numpy as np
+
+    from taming_event_flow_amd.dataloader.base import collate_raw_events
+    from taming_event_flow_amd.loss import flow_val
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    H, W = (480, 640) if a.res == [128, 128] else a.res      # the default resolution of this mode is DSEC's
+    N = a.events if a.events != 10000 else 100000             # events per pass (DSEC-like rate), stated in the output
+    P = a.passes
+    cfg = {"loader": {"resolution": [H, W], "batch_size": 1}, "loss": {"round_ts": False, "flow_scaling": 128},
+           "vis": {"mask_output": True}, "metrics": {"name": ["FWL", "RSAT"]}, "data": {"passes_loss": P}}
+    torch.manual_seed(1234)
+    model = RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2).to(dev)
+    model.eval()
+    crit = flow_val.Iterative(cfg, dev)
+    rng = np.random.default_rng(200 + rank)
+    raws = []
+    for k in range(P):
+        raws.append({"xs": torch.tensor(rng.integers(0, W, N).astype(np.float32), device=dev),
+                     "ys": torch.tensor(rng.integers(0, H, N).astype(np.float32), device=dev),
+                     "ts": torch.tensor((np.sort(rng.random(N)) + k).astype(np.float32), device=dev),
+                     "ps": torch.tensor(rng.integers(0, 2, N).astype(np.float32), device=dev)})
+
+    def window():
+        model.reset_states()
+        crit.reset()
+        with torch.no_grad():
+            for r in raws:
+                b = collate_raw_events(r["xs"], r["ys"], r["ts"], r["ps"], [0, N], (H, W))
+                x = model(b["net_input"])
+                flows = [f * cfg["loss"]["flow_scaling"] for f in x["flow"]]
+                crit.update(flows, b["event_list"], b["event_list_pol_mask"], b["event_mask"])
+            return crit.fwl(), crit.rsat()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        window()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        fwl, rsat = window()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        fl = conv_flops_per_pass(1, H, W)
+        out = {
+            "metric": "events/sec through DSEC-eval-shape inference (RecEVFlowNet forward + FWL/RSAT validation), 480x640",
+            "value": round(N * P * a.steps * world / elapsed, 1), "unit": "events/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * elapsed / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"eval window: {P} x (loader stage, RecEVFlowNet fwd, validation update) + FWL + RSAT, "
+                                   f"{H}x{W}, B=1/GPU, N={N} events/pass (BASELINE.json configs[4])",
+                       "global_batch": world, "parallelism": f"{world} independent replicas (no collective)"},
+            "fwl": round(float(fwl.item()), 6), "rsat": round(float(rsat.item()), 6),
+            "conv_gflop_per_pass_fwd": round(fl / 1e9, 2),
         }
         print(json.dumps(out), flush=True)
     if dist:
