@@ -39,7 +39,19 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restri
     y[idx] = mul * v;
 }
 
-// exact adjoint in gather form: input pixel (iy, ix) collects from the outputs whose taps include it
+// exact adjoint in gather form: input pixel (iy, ix) collects from the outputs whose taps include it.  The 1-D weights
+// of the <= 3*s candidate output rows / columns are computed once per thread (same expressions as the forward, so the
+// pair is an exact adjoint), the double loop is then a plain weighted sum.
+constexpr int kMaxTaps = 24;      // 3 * scale, scale <= 8 (RecEVFlowNet: x2 decoders, x2/x4/x8 flow heads)
+
+__device__ __forceinline__ float tap_weight(int o, float inv, int n, int i)
+{
+    int i0, i1;
+    float l0, l1;
+    src_index(o, inv, n, i0, i1, l0, l1);
+    return (i0 == i ? l0 : 0.0f) + (i1 == i ? l1 : 0.0f);
+}
+
 __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
                                                            int sh, int sw, float mul, float *__restrict__ dx)
 {
@@ -52,22 +64,33 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restri
     const float *g = dy + (size_t)pl * Ho * Wo;
     int oy_lo = max(0, (iy - 1) * sh), oy_hi = min(Ho, (iy + 2) * sh);
     int ox_lo = max(0, (ix - 1) * sw), ox_hi = min(Wo, (ix + 2) * sw);
+    const float invh = 1.0f / (float)sh, invw = 1.0f / (float)sw;
     float acc = 0.0f;
-    for (int oy = oy_lo; oy < oy_hi; ++oy) {
-        int y0, y1;
-        float ly0, ly1;
-        src_index(oy, 1.0f / (float)sh, H, y0, y1, ly0, ly1);
-        float wy = (y0 == iy ? ly0 : 0.0f) + (y1 == iy ? ly1 : 0.0f);
-        if (wy == 0.0f) continue;
-        float row = 0.0f;
-        for (int ox = ox_lo; ox < ox_hi; ++ox) {
-            int x0, x1;
-            float lx0, lx1;
-            src_index(ox, 1.0f / (float)sw, W, x0, x1, lx0, lx1);
-            float wx = (x0 == ix ? lx0 : 0.0f) + (x1 == ix ? lx1 : 0.0f);
-            if (wx != 0.0f) row += wx * g[(size_t)oy * Wo + ox];
+    if (ox_hi - ox_lo <= kMaxTaps) {
+        float wx[kMaxTaps];
+#pragma unroll
+        for (int j = 0; j < kMaxTaps; ++j) wx[j] = (ox_lo + j < ox_hi) ? tap_weight(ox_lo + j, invw, W, ix) : 0.0f;
+        for (int oy = oy_lo; oy < oy_hi; ++oy) {
+            float wy = tap_weight(oy, invh, H, iy);
+            if (wy == 0.0f) continue;
+            const float *row = g + (size_t)oy * Wo + ox_lo;
+            float r = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxTaps; ++j)
+                if (wx[j] != 0.0f) r += wx[j] * row[j];
+            acc += wy * r;
         }
-        acc += wy * row;
+    } else {
+        for (int oy = oy_lo; oy < oy_hi; ++oy) {
+            float wy = tap_weight(oy, invh, H, iy);
+            if (wy == 0.0f) continue;
+            float r = 0.0f;
+            for (int ox = ox_lo; ox < ox_hi; ++ox) {
+                float w = tap_weight(ox, invw, W, ix);
+                if (w != 0.0f) r += w * g[(size_t)oy * Wo + ox];
+            }
+            acc += wy * r;
+        }
     }
     dx[idx] = mul * acc;
 }

@@ -183,3 +183,55 @@ def test_conv_against_torch_reference_large(dev):
     ref = [ref_out.detach(), x.grad, h.grad] + [p.grad for p in gru.parameters()]
     for a, b in zip(got, ref):
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-4
+
+
+@pytest.mark.parametrize("B,C0,C1,N,H,W,k,stride,act,gated", [
+    (3, 5, 0, 7, 5, 7, 3, 1, "relu", False),        # nothing a multiple of 4: scalar gathers everywhere
+    (2, 3, 4, 33, 9, 6, 3, 1, "tanh", True),        # concat + gate, ragged rows, 2 row tiles of 32
+    (2, 6, 0, 70, 11, 13, 3, 2, "sigmoid", False),  # stride 2 on odd sizes, 64-row tile
+    (1, 9, 0, 2, 6, 10, 1, 1, None, False),         # 1x1 prediction head shape
+    (2, 4, 4, 130, 8, 12, 3, 1, "relu", True),      # quad-vector gathers (W % 4 == 0), 128-row tile + remainder, gate
+    (1, 2, 0, 5, 4, 4, 3, 1, None, False),          # a single 16-pixel image: every quad touches the tensor's ends
+])
+def test_conv_ragged_geometries(dev, B, C0, C1, N, H, W, k, stride, act, gated):
+    """tef_conv_forward / backward against torch's CPU fp32 convolution on shapes that exercise every staging path."""
+    from taming_event_flow_amd.models import submodules as sm
+
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x0 = torch.randn(B, C0, H, W, generator=g)
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    gate = torch.rand(B, C1, H, W, generator=g) if gated else None
+    w = torch.randn(N, C0 + C1, k, k, generator=g) * 0.3
+    b = torch.randn(N, generator=g)
+    leaves = [t for t in (x0, x1, gate, w, b) if t is not None]
+
+    def ref():
+        ts = [t.clone().requires_grad_() for t in leaves]
+        it = iter(ts)
+        rx0 = next(it)
+        rx1 = next(it) if x1 is not None else None
+        rg = next(it) if gate is not None else None
+        rw, rb = next(it), next(it)
+        xin = rx0 if rx1 is None else torch.cat([rx0, rx1 * rg if rg is not None else rx1], dim=1)
+        y = torch.nn.functional.conv2d(xin, rw, rb, stride=stride, padding=k // 2)
+        if act is not None:
+            y = getattr(torch, act)(y)
+        return y, ts
+
+    y_ref, ts_ref = ref()
+    dout = torch.randn(y_ref.shape, generator=g)
+    g_ref = torch.autograd.grad(y_ref, ts_ref, dout)
+
+    ts = [t.to(dev).requires_grad_() for t in leaves]
+    it = iter(ts)
+    dx0 = next(it)
+    dx1 = next(it) if x1 is not None else None
+    dg = next(it) if gate is not None else None
+    dw, db = next(it), next(it)
+    y = sm.conv2d(sm.PackedWeights(), dx0, dw, db, stride=stride, act=act, x1=dx1, gate1=dg)
+    assert y.shape == y_ref.shape
+    assert rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy()) <= 1e-5
+    grads = torch.autograd.grad(y, ts, dout.to(dev))
+    for got, want, name in zip(grads, g_ref, ["x0", "x1", "gate", "w", "b"] if gated else
+                               (["x0", "x1", "w", "b"] if x1 is not None else ["x0", "w", "b"])):
+        assert rel_err(got.cpu().numpy(), want.numpy()) <= 2e-5, name
