@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of the HIP loss path against the CPU oracle (test infrastructure): random resolutions, batch,
+window length, heads, temporal scales, modes, ragged / empty passes, detached lists, float coordinates, flow kinds,
+smoothing weights, round_ts.  Prints every case whose error exceeds the 1e-4 bar and the worst case seen.
+
+    python tools/fuzz_loss.py [--cases 200] [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def sweep(cases, seed, verbose=True):
+    """-> (number of cases over the 1e-4 bar or raising, worst relative error)"""
+    import __graft_entry__ as g
+
+    g.build()
+    from oracle import oracle
+    from taming_event_flow_amd import synth
+    from test_loss_gpu import make_cfg, run_hip
+    from conftest import rel_err
+
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    worst, bad, t0 = (0.0, None), 0, time.time()
+    for c in range(cases):
+        kind = "Iterative" if rng.random() < 0.7 else "Linear"
+        S = int(rng.integers(1, 4))
+        P = int(rng.integers(2, 7)) * (1 << (S - 1))          # every scale divides the window
+        if kind == "Iterative" and P // (1 << (S - 1)) < 2:
+            P = 2 << (S - 1)
+        mode = "one" if rng.random() < 0.3 else "two"
+        B, F = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        H, W = int(rng.integers(6, 70)), int(rng.integers(6, 90))
+        if rng.random() < 0.1:
+            H, W = int(rng.integers(150, 260)), int(rng.integers(180, 330))      # several LDS row bands
+            B, F, P, S = 1, 1, min(P, 4), 1
+        nmax = int(rng.integers(1, 400))
+        ng = [int(rng.integers(0, nmax + 1)) if rng.random() < 0.5 else nmax for _ in range(P)]
+        if sum(ng) == 0:
+            ng[0] = 5
+        nd = [int(rng.integers(0, nmax // 2 + 1)) if rng.random() < 0.5 else 0 for _ in range(P)]
+        sigma = float(rng.choice([0.0, 0.5, 2.0, 6.0]))
+        fk = "smooth" if rng.random() < 0.7 else "iid"
+        win = synth.make_window(rng, B, H, W, P, F, ng, nd, sigma=sigma, kind=fk, ragged=rng.random() < 0.5,
+                                integer_coords=rng.random() < 0.7)
+        spat = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
+        temp = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
+        rts = rng.random() < 0.15 and min(ng) > 0          # round_ts on an empty list raises, as in the reference (:461)
+        meta = dict(H=H, W=W, B=B, P=P, S=S, mode=mode, spat=spat, temp=temp, round_ts=bool(rts))
+        try:
+            l, gr, _ = run_hip(kind, make_cfg(meta), win, dev)
+            ow = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=S, mode=mode, round_ts=bool(rts))
+            ol, od = ow.loss(kind, spat, temp)
+        except Exception as e:                                # noqa: BLE001
+            print("EXC", c, kind, meta, ng, nd, repr(e)[:200], flush=True)
+            bad += 1
+            continue
+        el = abs(l - ol) / max(abs(ol), 1e-12)
+        eg = rel_err(gr, od) if np.abs(od).max() > 0 else float(np.abs(gr).max())
+        e = max(el, eg)
+        if e > worst[0]:
+            worst = (e, (c, kind, meta, fk, sigma))
+        if e > 1e-4 or not np.isfinite(e):
+            bad += 1
+            print(f"FAIL case {c}: {kind} {meta} ng={ng} nd={nd} flows={fk}/{sigma} loss {l} vs {float(ol)} (rel {el:.2e}) "
+                  f"grad rel {eg:.2e}", flush=True)
+    if verbose:
+        print(f"{cases} cases in {time.time() - t0:.0f} s, {bad} over the 1e-4 bar; worst {worst[0]:.2e} at {worst[1]}")
+    return bad, worst[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    bad, _ = sweep(a.cases, a.seed)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
