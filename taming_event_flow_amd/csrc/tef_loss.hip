@@ -184,24 +184,26 @@ struct Quad2 { float2 v00, v01, v10, v11; };
 // two horizontally adjacent float2 pixels in one 16-byte load (global_load_dwordx4 only needs 4-byte alignment)
 typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 
-__device__ __forceinline__ void load_row(const float2 *__restrict__ map, int i0, int i1, float2 &v0, float2 &v1)
+// Branch-free: ONE unconditional 16-byte load whatever the validity of the two taps (an if/else between a vector path
+// and scalar paths makes the compiler merge just-loaded registers, i.e. wait for memory after every row — the gathers of
+// one chain step then queue up one behind the other instead of flying together).  i0 / i1: pixel indices of the left /
+// right tap, -1 when outside; when both are valid they are adjacent (i1 == i0 + 1).  hw = pixels of the map (>= 2).
+__device__ __forceinline__ void load_row(const float2 *__restrict__ map, int i0, int i1, int hw, float2 &v0, float2 &v1)
 {
-    const float2 z = make_float2(0.0f, 0.0f);
-    if (i0 >= 0 && i1 >= 0) {
-        f32x4_a8 p = *reinterpret_cast<const f32x4_a8 *>(map + i0);
-        v0 = make_float2(p.x, p.y);
-        v1 = make_float2(p.z, p.w);
-    } else {
-        v0 = i0 >= 0 ? map[i0] : z;
-        v1 = i1 >= 0 ? map[i1] : z;
-    }
+    const bool b0 = i0 >= 0, b1 = i1 >= 0;
+    int base = b0 ? (b1 ? i0 : i0 - 1) : (b1 ? i1 : 0);      // keep both loaded pixels inside the row / the map
+    base = min(max(base, 0), hw - 2);
+    f32x4_a8 p = *reinterpret_cast<const f32x4_a8 *>(map + base);
+    const float2 lo = make_float2(p.x, p.y), hi = make_float2(p.z, p.w), z = make_float2(0.0f, 0.0f);
+    v0 = b0 ? (i0 != base ? hi : lo) : z;
+    v1 = b1 ? (i1 != base ? hi : lo) : z;
 }
 
-__device__ __forceinline__ Quad2 load_quad(const float2 *__restrict__ map, const Taps &t)
+__device__ __forceinline__ Quad2 load_quad(const float2 *__restrict__ map, const Taps &t, int hw)
 {
     Quad2 q;
-    load_row(map, t.i00, t.i01, q.v00, q.v01);
-    load_row(map, t.i10, t.i11, q.v10, q.v11);
+    load_row(map, t.i00, t.i01, hw, q.v00, q.v01);
+    load_row(map, t.i10, t.i11, hw, q.v10, q.v11);
     return q;
 }
 
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
 
     // flow at the original location, shared by the first forward and the first backward step
     Taps tp = make_taps(y0, x0, H, W);
-    float2 f0 = quad_value(load_quad(flow_map(w, flows, t, i, b), tp), tp);
+    float2 f0 = quad_value(load_quad(flow_map(w, flows, t, i, b), tp, w.H * w.W), tp);
 
     // an event of pass t is only ever looked at (IWEs, gradient sweep, flow-gradient splat) at reference times within
     // delta_passes[0] of t; the chain still runs to both ends of the window because the border mask needs it
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         for (int k = t; k < P; ++k) {
             if (k > t) {
                 Taps q = make_taps(y, x, H, W);
-                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q), q);
+                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q, w.H * w.W), q);
                 dt = 1.0f;
             }
             y = y + dt * f.x;
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         for (int k = t; k >= 0; --k) {
             if (k < t) {
                 Taps q = make_taps(y, x, H, W);
-                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q), q);
+                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q, w.H * w.W), q);
                 dt = -1.0f;
             }
             y = y + dt * f.x;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
     float ts = E.ts[o], y0 = E.y[o], x0 = E.x[o];
     int t = E.bin[sl];
     Taps tp = make_taps(y0, x0, H, W);
-    float2 f = quad_value(load_quad(flow_map(w, flows, t, i, b), tp), tp);
+    float2 f = quad_value(load_quad(flow_map(w, flows, t, i, b), tp, w.H * w.W), tp);
     float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
     uint32_t bits = 0;
     for (int s = 0; s < w.S; ++s) {
@@ -615,33 +617,44 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
 #endif
     Splat sp = make_splat(p.x, p.y);
     float gy = 0.0f, gx = 0.0f;
-    bool vx0 = (sp.ix[0] >= 0) & (sp.ix[0] < w.W), vx1 = (sp.ix[1] >= 0) & (sp.ix[1] < w.W);
+    const bool vx0 = (sp.ix[0] >= 0) & (sp.ix[0] < w.W), vx1 = (sp.ix[1] >= 0) & (sp.ix[1] < w.W);
+    // One polarity plane per event in the common case (masks are (1,0) / (0,1)): its two rows are fetched by two
+    // unconditional 16-byte loads; an event carrying both polarities adds the second plane in a (rare) branch.
+    const bool hp = mp != 0.0f, both = hp & (mn != 0.0f);
+    const float2 *pl = hp ? pos : neg;
+    const float m1 = hp ? mp : mn;
+    float2 a0[2], a1[2];          // (A, R) at [row][left / right]
+    int i1s[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         int iy = sp.iy[r];
-        if (iy < 0 || iy >= w.H) continue;
-        int i0 = vx0 ? iy * w.W + sp.ix[0] : -1;
-        int i1 = (vx1 && sp.ix[1] == sp.ix[0] + 1) ? iy * w.W + sp.ix[1] : -1;   // adjacent unless y+1 rounded up
-        int i1s = (vx1 && i1 < 0) ? iy * w.W + sp.ix[1] : -1;
-        float2 ap[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)}, an[2] = {ap[0], ap[0]};
-        if (mp != 0.0f) {
-            load_row(pos, i0, i1, ap[0], ap[1]);
-            if (i1s >= 0) ap[1] = pos[i1s];
-        }
-        if (mn != 0.0f) {
-            load_row(neg, i0, i1, an[0], an[1]);
-            if (i1s >= 0) an[1] = neg[i1s];
-        }
+        bool vy = (iy >= 0) & (iy < w.H);
+        int i0 = (vy && vx0) ? iy * w.W + sp.ix[0] : -1;
+        int i1 = (vy && vx1 && sp.ix[1] == sp.ix[0] + 1) ? iy * w.W + sp.ix[1] : -1;   // adjacent unless x+1 rounded up
+        i1s[r] = (vy && vx1 && i1 < 0) ? iy * w.W + sp.ix[1] : -1;
+        load_row(pl, i0, i1, HW, a0[r], a1[r]);
+    }
 #pragma unroll
-        for (int cx = 0; cx < 2; ++cx) {
-            if (!(cx ? vx1 : vx0)) continue;
-            float dw = 0.0f;
-            if (mp != 0.0f) dw += mp * (2.0f * ap[cx].x * (tau - ap[cx].x) * ap[cx].y);
-            if (mn != 0.0f) dw += mn * (2.0f * an[cx].x * (tau - an[cx].x) * an[cx].y);
-            dw *= kimg;
-            gy += dw * (sp.sy[r] * sp.wx[cx]);
-            gx += dw * (sp.wy[r] * sp.sx[cx]);
+    for (int r = 0; r < 2; ++r) {
+        if (i1s[r] >= 0) a1[r] = pl[i1s[r]];            // fp32 corner case: floor(x + 1) == floor(x) + 2
+        float dw0 = m1 * (2.0f * a0[r].x * (tau - a0[r].x) * a0[r].y);
+        float dw1 = m1 * (2.0f * a1[r].x * (tau - a1[r].x) * a1[r].y);
+        if (both) {
+            int iy = sp.iy[r];
+            bool vy = (iy >= 0) & (iy < w.H);
+            float2 n0 = make_float2(0.f, 0.f), n1 = n0;
+            if (vy && vx0) n0 = neg[iy * w.W + sp.ix[0]];
+            if (vy && vx1) n1 = neg[iy * w.W + sp.ix[1]];
+            dw0 += mn * (2.0f * n0.x * (tau - n0.x) * n0.y);
+            dw1 += mn * (2.0f * n1.x * (tau - n1.x) * n1.y);
         }
+        // invalid corners read (A, R) = (0, 0): their dw is 0
+        dw0 *= kimg;
+        dw1 *= kimg;
+        gy += dw0 * (sp.sy[r] * sp.wx[0]);
+        gx += dw0 * (sp.wy[r] * sp.sx[0]);
+        gy += dw1 * (sp.sy[r] * sp.wx[1]);
+        gx += dw1 * (sp.wy[r] * sp.sx[1]);
     }
     return make_float2(gy, gx);
 }
@@ -736,13 +749,14 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
         if (ks > t) cur = tr[(size_t)ks * w.Mt];
         if (ks - 1 > t) nxt = tr[(size_t)(ks - 1) * w.Mt];
         for (int k = ks; k > t; --k) {
-            float2 nn = make_float2(0.0f, 0.0f);
-            if (k - 2 > t) nn = tr[(size_t)(k - 2) * w.Mt];
+            // every load of the step is unconditional (clamped plane / map, result masked): trajectory prefetch, the
+            // two flow rows and the two image rows are in flight together
+            float2 nn = tr[(size_t)max(k - 2, t + 1) * w.Mt];
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
 #ifndef TEF_ABL_NOFLOW
-            if (k - 1 > t) {
+            {
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
-                quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp), tp, jyy, jyx, jxy, jxx);
+                quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
             }
 #endif
             float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
@@ -773,13 +787,12 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
         if (ks <= t) cur = tr[(size_t)ks * w.Mt];
         if (ks + 1 <= t) nxt = tr[(size_t)(ks + 1) * w.Mt];
         for (int k = ks; k <= t; ++k) {
-            float2 nn = make_float2(0.0f, 0.0f);
-            if (k + 2 <= t) nn = tr[(size_t)(k + 2) * w.Mt];
+            float2 nn = tr[(size_t)min(k + 2, t) * w.Mt];
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
 #ifndef TEF_ABL_NOFLOW
-            if (k < t) {
+            {
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
-                quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp), tp, jyy, jyx, jxy, jxx);
+                quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
             }
 #endif
             float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
