@@ -123,6 +123,11 @@ def lib():
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `python taming_event_flow_amd/build.py`). There is no CPU fallback."
             )
+        # PyTorch-ROCm bundles its own HIP runtime: load it first so that the library binds to the runtime that owns
+        # the tensors' device context (loading libtef_hip.so before torch pulls in /opt/rocm's copy next to torch's, and
+        # launches then fail with "no ROCm-capable device is detected")
+        import torch  # noqa: F401
+
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
