@@ -405,6 +405,34 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
     *mo = pack_meta(bits, -1, 0, mp, mn);
 }
 
+// LDS image plane helpers of the two scatter kernels: [rows][W + kRowPad] doubles.
+// zero fill with 16-byte stores; write-out [rows][W] floats without a per-element division: when the workgroup covers
+// whole rows (blockDim % (W/2) == 0) a thread keeps its column pair and walks down the rows with 16-byte LDS reads.
+__device__ __forceinline__ void lds_plane_zero(double *img, int n)
+{
+    double2 *v = reinterpret_cast<double2 *>(img);
+    for (int p = threadIdx.x; p < (n >> 1); p += blockDim.x) v[p] = make_double2(0.0, 0.0);
+    if ((n & 1) && threadIdx.x == 0) img[n - 1] = 0.0;
+}
+
+__device__ __forceinline__ void lds_plane_store(const double *img, int rows, int W, int WP, float *__restrict__ o)
+{
+    const int half = W >> 1;
+    if (!(W & 1) && !(WP & 1) && half > 0 && (int)blockDim.x % half == 0) {
+        const int rstep = blockDim.x / half;
+        int r = threadIdx.x / half, c = (threadIdx.x - r * half) * 2;
+        for (; r < rows; r += rstep) {
+            double2 d = *reinterpret_cast<const double2 *>(img + r * WP + c);
+            *reinterpret_cast<float2 *>(o + (size_t)r * W + c) = make_float2((float)d.x, (float)d.y);
+        }
+    } else {
+        for (int p = threadIdx.x; p < rows * W; p += blockDim.x) {
+            int r = p / W;
+            o[p] = (float)img[r * WP + (p - r * W)];
+        }
+    }
+}
+
 // =============================================================================================
 // K2: image of warped events.  loss/flow.py:81-110 iwe_formatting = utils/iwe.py:63-136
 // get_interpolation + 4x interpolate (scatter_add_).  One workgroup owns ONE quantity
@@ -474,11 +502,10 @@ __device__ __forceinline__ void splat_run(const Win &w, const Img &im, const Eve
 // events of polarity c of pass t: classes are stored [pos-only | neg-only | both | padding]
 template <bool QT>
 __device__ __forceinline__ void splat_pass(const Win &w, const Img &im, const Events &g, const Events &d,
-                                           const Events &E, int b, int c, int t, int base, int slot0,
+                                           const int *cl, int b, int c, int base, int slot0,
                                            const float2 *__restrict__ pl, const uint32_t *__restrict__ mt,
                                            double *img, int r0, int r1)
 {
-    const int *cl = E.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3;
     int n0 = cl[0], n01 = cl[1], n012 = cl[2];
     if (c == 0) {
         splat_run<QT>(w, im, g, d, b, c, base + slot0, n0, pl, mt, img, r0, r1);
@@ -498,21 +525,19 @@ __device__ __forceinline__ void splat_body(const Win &w, const Events &g, const 
     int b = ib % w.B;
     int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
     int nlds = (r1 - r0) * WP;
-    for (int p = threadIdx.x; p < nlds; p += blockDim.x) img[p] = 0.0;
+    lds_plane_zero(img, nlds);
     __syncthreads();
     Img im = decode_image(w, j);
     const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
     const uint32_t *mt = meta + (size_t)ib * w.Mt;
-    for (int t = im.le; t < im.he; ++t) splat_pass<QT>(w, im, g, d, g, b, c, t, 0, w.off[t], pl, mt, img, r0, r1);
+    for (int t = im.le; t < im.he; ++t)
+        splat_pass<QT>(w, im, g, d, g.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3, b, c, 0, w.off[t], pl, mt, img, r0, r1);
     if (w.Md > 0)
         for (int t = im.le; t < im.he; ++t)
-            splat_pass<QT>(w, im, g, d, d, b, c, t, w.M, w.doff[t], pl, mt, img, r0, r1);
+            splat_pass<QT>(w, im, g, d, d.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3, b, c, w.M, w.doff[t], pl, mt, img, r0, r1);
     __syncthreads();
     float *o = out + (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
-    for (int p = threadIdx.x; p < (r1 - r0) * W; p += blockDim.x) {
-        int r = p / W;
-        o[p] = (float)img[r * WP + (p - r * W)];
-    }
+    lds_plane_store(img, r1 - r0, W, WP, o);
 }
 
 __global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, Events d,
@@ -883,7 +908,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
     int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
     const int WP = W + kRowPad;
     int nlds = (r1 - r0) * WP;
-    for (int p = threadIdx.x; p < nlds; p += blockDim.x) lds_img[p] = 0.0;
+    lds_plane_zero(lds_img, nlds);
     __syncthreads();
     const bool iter = (w.kind == TEF_KIND_ITERATIVE);
     const float *co = (comp ? cy : cx) + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
@@ -927,10 +952,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
     }
     __syncthreads();
     float *o = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2 + (comp ? 1 : 0)) * (size_t)(H * W) + (size_t)r0 * W;
-    for (int p = threadIdx.x; p < (r1 - r0) * W; p += blockDim.x) {
-        int r = p / W;
-        o[p] = (float)lds_img[r * WP + (p - r * W)];
-    }
+    lds_plane_store(lds_img, r1 - r0, W, WP, o);
 }
 
 // K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473),
