@@ -564,24 +564,44 @@ __global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, E
 //   ar   [(j*FB + ib)*2 + c][H*W] float2 = (A, R = 1/(C + 1e-9))  for the backward
 //   stats[(j*FB + ib)*2 + 0] = sum_px (A_pos^2 + A_neg^2) / n,   [+1] = n = #{C_pos + C_neg != 0} + 1e-9
 // =============================================================================================
+// Each image is cut into kStatParts parts (gridDim.y) so that the launch covers the chip; the parts' sums go to `part`
+// and K4 adds them in a fixed order.
+constexpr int kStatParts = 8;
+
 __global__ __launch_bounds__(256) void image_stats_kernel(Win w, const float *__restrict__ iwe_c,
                                                           const float *__restrict__ iwe_t, float2 *__restrict__ ar,
-                                                          float *__restrict__ stats)
+                                                          double *__restrict__ part)
 {
     __shared__ double ssum[256];
     __shared__ int scnt[256];
     const int HW = w.H * w.W;
     const size_t base = (size_t)blockIdx.x * 2 * HW;
+    const int per = (((HW + kStatParts - 1) / kStatParts) + 3) & ~3;          // multiple of 4 pixels
+    const int p0 = blockIdx.y * per, p1 = min(HW, p0 + per);
     float acc = 0.0f;
     int nnz = 0;
-    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-        float c0 = iwe_c[base + p], c1 = iwe_c[base + HW + p];
-        float t0 = iwe_t[base + p], t1 = iwe_t[base + HW + p];
+    auto pixel = [&](int p, float c0, float c1, float t0, float t1) {
+        float r0 = 1.0f / (c0 + kEps), r1 = 1.0f / (c1 + kEps);
         float a0 = t0 / (c0 + kEps), a1 = t1 / (c1 + kEps);
-        ar[base + p] = make_float2(a0, 1.0f / (c0 + kEps));
-        ar[base + HW + p] = make_float2(a1, 1.0f / (c1 + kEps));
+        ar[base + p] = make_float2(a0, r0);
+        ar[base + HW + p] = make_float2(a1, r1);
         acc += a0 * a0 + a1 * a1;
         nnz += ((c0 + c1) != 0.0f);
+    };
+    if ((HW & 3) == 0) {       // 16-byte loads: 4 pixels of the four planes per iteration
+        for (int p = p0 + 4 * threadIdx.x; p < p1; p += 4 * blockDim.x) {
+            float4 c0 = *reinterpret_cast<const float4 *>(iwe_c + base + p);
+            float4 c1 = *reinterpret_cast<const float4 *>(iwe_c + base + HW + p);
+            float4 t0 = *reinterpret_cast<const float4 *>(iwe_t + base + p);
+            float4 t1 = *reinterpret_cast<const float4 *>(iwe_t + base + HW + p);
+            pixel(p, c0.x, c1.x, t0.x, t1.x);
+            pixel(p + 1, c0.y, c1.y, t0.y, t1.y);
+            pixel(p + 2, c0.z, c1.z, t0.z, t1.z);
+            pixel(p + 3, c0.w, c1.w, t0.w, t1.w);
+        }
+    } else {
+        for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x)
+            pixel(p, iwe_c[base + p], iwe_c[base + HW + p], iwe_t[base + p], iwe_t[base + HW + p]);
     }
     ssum[threadIdx.x] = (double)acc;
     scnt[threadIdx.x] = nnz;
@@ -594,22 +614,31 @@ __global__ __launch_bounds__(256) void image_stats_kernel(Win w, const float *__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        float n = (float)scnt[0] + kEps;
-        stats[(size_t)blockIdx.x * 2] = (float)ssum[0] / n;
-        stats[(size_t)blockIdx.x * 2 + 1] = n;
+        part[((size_t)blockIdx.x * kStatParts + blockIdx.y) * 2] = ssum[0];
+        part[((size_t)blockIdx.x * kStatParts + blockIdx.y) * 2 + 1] = (double)scnt[0];
     }
 }
 
-// K4: loss = sum_images coef * (sum over samples of the per-sample term); fixed summation order.
-__global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const float *__restrict__ stats,
+// K4: per-image statistics from the parts, stats[q] = (sum A^2 / n, n = #active pixels + 1e-9), and
+// loss = sum_images coef * (sum over samples of the per-sample term); fixed summation order.
+__global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *__restrict__ part, float *__restrict__ stats,
                                                           float *__restrict__ loss_out)
 {
     __shared__ double ssum[256];
     const int FB = w.F * w.B;
     double acc = 0.0;
     for (int q = threadIdx.x; q < w.nimg * FB; q += blockDim.x) {
+        double s2 = 0.0, cnt = 0.0;
+        for (int k = 0; k < kStatParts; ++k) {
+            s2 += part[((size_t)q * kStatParts + k) * 2];
+            cnt += part[((size_t)q * kStatParts + k) * 2 + 1];
+        }
+        float n = (float)cnt + kEps;
+        float term = (float)s2 / n;
+        stats[(size_t)q * 2] = term;
+        stats[(size_t)q * 2 + 1] = n;
         Img im = decode_image(w, q / FB);
-        acc += (double)stats[(size_t)q * 2] * (double)im.coef;
+        acc += (double)term * (double)im.coef;
     }
     ssum[threadIdx.x] = acc;
     __syncthreads();
@@ -1051,7 +1080,7 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const float *__restrict_
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, iwe_c, iwe_t, ar, stats, cy, cx, total;
+    size_t traj, meta, iwe_c, iwe_t, ar, stats, parts, cy, cx, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1118,6 +1147,7 @@ Layout make_layout(const Win &w)
     L.iwe_t = o;  o += align_up(img * sizeof(float));
     L.ar = o;     o += align_up(img * sizeof(float2));
     L.stats = o;  o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
+    L.parts = o;  o += align_up((size_t)w.nimg * FB * kStatParts * 2 * sizeof(double));
     L.cy = o;     o += align_up(nc * sizeof(float));
     L.cx = o;     o += align_up(nc * sizeof(float));
     L.total = o;
@@ -1247,13 +1277,13 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     if (int rc = tef::check_launch("splat_kernel")) return rc;
     {
         tef::ProfScope ps(tef::PROF_STATS, st);
-        hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, w, iwe_c, iwe_t, ar,
-                           stats);
+        hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB), kStatParts), dim3(256), 0, st, w, iwe_c, iwe_t,
+                           ar, (double *)(ws + L.parts));
     }
     if (int rc = tef::check_launch("image_stats_kernel")) return rc;
     {
         tef::ProfScope ps(tef::PROF_REDUCE, st);
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, stats, loss_out);
+        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), stats, loss_out);
     }
     return tef::check_launch("loss_reduce_kernel");
 }
