@@ -193,16 +193,23 @@ int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, c
 /* Given dout = d loss / d out (and out itself when act != NONE):
  *   dx0 [B,C0,H,W], dx1 [B,C1,H,W] = gradient w.r.t. the concatenated conv input (dx1 is w.r.t. x1 * gate1; either may
  *   together be NULL to skip; needs the packed weight w2), overwritten;  dweight [N,C0+C1,k,k] and dbias [N] are ACCUMULATED into (+=), NULL to skip. */
+/* The same with the output channels delivered as two tensors, out [B,out_split,Ho,Wo] and out2 [B,N-out_split,Ho,Wo]:
+ * the update | reset gates of ConvGRU come out of one GEMM as the two tensors the cell uses (submodules.py:146-148). */
+int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                           const float *wp, const float *bias, float *out, float *out2, int out_split, void *workspace,
+                           size_t workspace_bytes, void *stream);
 int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
                       const float *w2, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream);
-/* The same with two accumulation targets: output channels [0, split_rows) add into dweight / dbias, channels
- * [split_rows, N) into dweight2 / dbias2 — the gradients of two row-concatenated parameters (ConvGRU update | reset
- * gates, submodules.py:122-123) go straight into their own .grad buffers, no temporary, no extra add. */
+/* The same for a convolution whose output channels are split: (out, dout) cover channels [0, io_split), (out2, dout2)
+ * the rest (io_split = N, out2 = dout2 = NULL for one tensor); and with two accumulation targets: output channels
+ * [0, split_rows) add into dweight / dbias, channels [split_rows, N) into dweight2 / dbias2 — the gradients of two
+ * row-concatenated parameters (ConvGRU update | reset gates, submodules.py:122-123) go straight into their own .grad
+ * buffers, no temporary, no extra add. */
 int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
-                            const float *w2, const float *out, const float *dout, float *dx0, float *dx1,
-                            float *dweight, float *dweight2, float *dbias, float *dbias2, int split_rows,
-                            void *workspace, size_t workspace_bytes, void *stream);
+                            const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
+                            int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
+                            float *dbias2, int split_rows, void *workspace, size_t workspace_bytes, void *stream);
 /* ConvGRU state update new_state = prev * (1 - update) + out_inputs * update (submodules.py:150) and its backward
  * (dh = direct path only; the paths through the gates go through tef_conv_backward). n = element count. */
 int tef_gru_blend(const float *h, const float *u, const float *o, size_t n, float *out, void *stream);

@@ -82,8 +82,11 @@ SIGNATURES = {
                                         _fp]),
     "tef_conv_backward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                          ctypes.c_size_t, _fp]),
-    "tef_conv_backward_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
-                                               _fp, _fp, ctypes.c_int, _fp, ctypes.c_size_t, _fp]),
+    "tef_conv_forward_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                              _fp, ctypes.c_size_t, _fp]),
+    "tef_conv_backward_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                               ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp,
+                                               ctypes.c_size_t, _fp]),
     "tef_gru_blend": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_size_t, _fp, _fp]),
     "tef_gru_blend_backward": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_val_event_step": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,

@@ -553,9 +553,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 
 // g = dout * act'(out) (out = post-activation: relu' = out > 0, tanh' = 1 - out^2, sigmoid' = out (1 - out)),
 // db[n] += sum over batch and pixels of g.   One block row per channel.
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ out,
-                                                      int act, int B, int N, int HW, float *__restrict__ gbuf,
-                                                      float *__restrict__ dbias, float *__restrict__ dbias2, int split)
+// dy / out may come as two tensors (channels [0, iosplit) and [iosplit, N): the split outputs of a fused conv).
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ dy2,
+                                                      const float *__restrict__ out, const float *__restrict__ out2,
+                                                      int iosplit, int act, int B, int N, int HW,
+                                                      float *__restrict__ gbuf, float *__restrict__ dbias,
+                                                      float *__restrict__ dbias2, int split)
 {
     __shared__ float red[256];
     int n = blockIdx.y;
@@ -564,14 +567,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
     for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
         int b = m / HW, p = m - b * HW;
         size_t o = ((size_t)b * N + n) * HW + p;
-        float gval = dy[o];
+        const bool second = n >= iosplit;
+        size_t oi = second ? ((size_t)b * (N - iosplit) + (n - iosplit)) * HW + p : ((size_t)b * iosplit + n) * HW + p;
+        float gval = second ? dy2[oi] : dy[oi];
         if (act != TEF_ACT_NONE) {
-            float y = out[o];
+            float y = second ? out2[oi] : out[oi];
             if (act == TEF_ACT_RELU) gval = y > 0.0f ? gval : 0.0f;
             else if (act == TEF_ACT_TANH) gval *= (1.0f - y * y);
             else gval *= y * (1.0f - y);
-            gbuf[o] = gval;
         }
+        if (act != TEF_ACT_NONE || iosplit < N) gbuf[o] = gval;
         local += gval;
     }
     if (!dbias) return;
@@ -778,9 +783,18 @@ int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, 
 int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
                      const float *bias, float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return tef_conv_forward_split(d, x0, x1, gate1, wp, bias, out, nullptr, d ? d->N : 0, workspace, workspace_bytes, stream);
+}
+
+int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                           const float *wp, const float *bias, float *out, float *out2, int out_split, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
     Geo q;
     if (!make_geo(d, &q)) return TEF_ERR_INVALID;
     if (!x0 || (d->C1 > 0 && !x1) || !wp || !out || !workspace) return tef::fail("tef_conv_forward: null pointer"), TEF_ERR_INVALID;
+    if (out_split < 1 || out_split > d->N || (out_split < d->N && !out2))
+        return tef::fail("tef_conv_forward: channels beyond out_split need out2"), TEF_ERR_INVALID;
     ConvLayout L = conv_layout(d, q);
     if (workspace_bytes < L.total) return tef::fail("tef_conv_forward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -789,7 +803,7 @@ int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, c
     g.A = wp; g.lda = q.Kp; g.rows = d->N;
     g.G = forward_gather(d, q, x0, x1, gate1);
     g.cols = q.M; g.K = q.Kp;
-    g.C = out; g.C2 = nullptr; g.split = d->N; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
+    g.C = out; g.C2 = out2; g.split = out_split; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
     int z = k_splits(d->N, q.M, q.Kp);
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
     if (z == 1) return launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st);
@@ -800,7 +814,7 @@ int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, c
     if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_SLAB>(g, z, st)) return rc;
     size_t n = (size_t)d->N * q.M;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
-                       d->act, q.Ho * q.Wo, d->N, out, (float *)nullptr);
+                       d->act, q.Ho * q.Wo, out_split, out, out2);
     return tef::check_launch("splitk_reduce_kernel");
 }
 
@@ -808,14 +822,14 @@ int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, 
                       const float *out, const float *dout, float *dx0, float *dx1, float *dweight, float *dbias,
                       void *workspace, size_t workspace_bytes, void *stream)
 {
-    return tef_conv_backward_split(d, x0, x1, gate1, w2, out, dout, dx0, dx1, dweight, nullptr, dbias, nullptr,
-                                   d ? d->N : 0, workspace, workspace_bytes, stream);
+    return tef_conv_backward_split(d, x0, x1, gate1, w2, out, nullptr, dout, nullptr, d ? d->N : 0, dx0, dx1, dweight, nullptr,
+                                   dbias, nullptr, d ? d->N : 0, workspace, workspace_bytes, stream);
 }
 
 int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
-                            const float *w2, const float *out, const float *dout, float *dx0, float *dx1,
-                            float *dweight, float *dweight2, float *dbias, float *dbias2, int split_rows,
-                            void *workspace, size_t workspace_bytes, void *stream)
+                            const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
+                            int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
+                            float *dbias2, int split_rows, void *workspace, size_t workspace_bytes, void *stream)
 {
     Geo q;
     if (!make_geo(d, &q)) return TEF_ERR_INVALID;
@@ -823,6 +837,8 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
     if (d->act != TEF_ACT_NONE && !out) return tef::fail("tef_conv_backward: activation needs the forward output"), TEF_ERR_INVALID;
     if (split_rows < 0 || split_rows > d->N || (split_rows < d->N && ((dweight && !dweight2) || (dbias && !dbias2))))
         return tef::fail("tef_conv_backward: rows beyond split_rows need dweight2 / dbias2"), TEF_ERR_INVALID;
+    if (io_split < 1 || io_split > d->N || (io_split < d->N && (!dout2 || (d->act != TEF_ACT_NONE && !out2))))
+        return tef::fail("tef_conv_backward: channels beyond io_split need dout2 / out2"), TEF_ERR_INVALID;
     const bool need_dx = dx0 || dx1;
     if (need_dx && !w2) return tef::fail("tef_conv_backward: input gradient needs the packed weight w2"), TEF_ERR_INVALID;
     if (need_dx && ((d->C1 > 0) != (dx1 != nullptr) || !dx0))
@@ -835,12 +851,12 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
     const int N = d->N, HW = q.Ho * q.Wo;
     const float *gsrc = dout;
 
-    if (d->act != TEF_ACT_NONE || dbias) {   // g = dY * act'(out) (+ bias gradient)
+    if (d->act != TEF_ACT_NONE || dbias || io_split < N) {   // g = dY * act'(out), gathered into one tensor (+ bias gradient)
         dim3 grid((unsigned)std::min<size_t>(64, ((size_t)q.M + 255) / 256), N);
-        hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, out, d->act, d->B, N, HW, gbuf, dbias, dbias2,
-                           split_rows);
+        hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, dout2, out, out2, io_split, d->act, d->B, N, HW, gbuf,
+                           dbias, dbias2, split_rows);
         if (int rc = tef::check_launch("act_bwd_kernel")) return rc;
-        if (d->act != TEF_ACT_NONE) gsrc = gbuf;
+        if (d->act != TEF_ACT_NONE || io_split < N) gsrc = gbuf;
     }
     if (dweight) {   // dW[n][k] += sum_m g[n][m] * x_gather[m][k]
         GemmArgs g{};

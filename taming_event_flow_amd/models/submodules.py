@@ -59,7 +59,7 @@ class _ConvFn(torch.autograd.Function):
     tef_conv_forward).  `nw` weight tensors are row-concatenated without materialising the concatenation."""
 
     @staticmethod
-    def forward(ctx, packer, stride, act, nw, x0, x1, gate1, *wb):
+    def forward(ctx, packer, stride, act, nw, out_split, x0, x1, gate1, *wb):
         lib = _lib.lib()
         _lib.require_device_tensor(x0, "conv input")
         weights, biases = wb[:nw], wb[nw:]
@@ -78,27 +78,39 @@ class _ConvFn(torch.autograd.Function):
             bias = biases[0] if len(biases) == 1 else torch.cat([b.detach() for b in biases])
         pad = k // 2
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        out = torch.empty((B, N, Ho, Wo), dtype=torch.float32, device=x0.device)
+        split = N if out_split is None else int(out_split)
+        out = torch.empty((B, split, Ho, Wo), dtype=torch.float32, device=x0.device)
+        out2 = torch.empty((B, N - split, Ho, Wo), dtype=torch.float32, device=x0.device) if split < N else None
         nbytes = lib.tef_conv_workspace_bytes(ctypes.byref(d))
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
-        rc = lib.tef_conv_forward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), wp.data_ptr(), _ptr(bias),
-                                  out.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr())
-        _lib.check(rc, "tef_conv_forward")
+        rc = lib.tef_conv_forward_split(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), wp.data_ptr(), _ptr(bias),
+                                        out.data_ptr(), _ptr(out2), split, ws.data_ptr(), nbytes, _lib.stream_ptr())
+        _lib.check(rc, "tef_conv_forward_split")
+        ctx.io_split = split
         ctx.desc, ctx.nw, ctx.wt = d, nw, wt
         ctx.packer, ctx.params = packer, (weights, biases)
         ctx.rows = [w.shape[0] for w in weights]
         ctx.wshape = tuple(weights[0].shape[1:])
         ctx.has = (x1 is not None, gate1 is not None, bias is not None)
-        ctx.save_for_backward(x0, x1, gate1, out if act is not None else None)
-        return out
+        ctx.save_for_backward(x0, x1, gate1, out if act is not None else None,
+                              out2 if (act is not None and out2 is not None) else None)
+        return out if out2 is None else (out, out2)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
         lib = _lib.lib()
-        x0, x1, gate1, out = ctx.saved_tensors
+        x0, x1, gate1, out, out2 = ctx.saved_tensors
         d, nw = ctx.desc, ctx.nw
         has_x1, has_gate, has_bias = ctx.has
-        need = ctx.needs_input_grad          # (packer, stride, act, nw, x0, x1, gate1, *weights, *biases)
+        need = (ctx.needs_input_grad[:4] + ctx.needs_input_grad[5:])   # drop out_split: (packer, stride, act, nw, x0, x1, gate1, *w, *b)
+        io_split = ctx.io_split
+        if io_split < d.N:        # an unused half of a split output arrives as None
+            Ho, Wo = (dout if dout is not None else dout2).shape[2:]
+            if dout is None:
+                dout = torch.zeros((d.B, io_split, Ho, Wo), dtype=torch.float32, device=dout2.device)
+            if dout2 is None:
+                dout2 = torch.zeros((d.B, d.N - io_split, Ho, Wo), dtype=torch.float32, device=dout.device)
+            dout2 = dout2.contiguous()
         dout = dout.contiguous()
         dev = dout.device
         need_dx = need[4] or (has_x1 and (need[5] or need[6]))      # the kernel produces dx0 and dx1 together
@@ -116,18 +128,19 @@ class _ConvFn(torch.autograd.Function):
             dws = [w.grad.data_ptr() for w in weights] + [None]
             dbs = ([b.grad.data_ptr() for b in biases] + [None]) if has_bias else [None, None]
             rc = lib.tef_conv_backward_split(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
-                                             _ptr(out), dout.data_ptr(), _ptr(dx0), _ptr(dxg), dws[0], dws[1], dbs[0],
-                                             dbs[1], ctx.rows[0] if nw == 2 else d.N, ws.data_ptr(), nbytes,
-                                             _lib.stream_ptr())
+                                             _ptr(out), _ptr(out2), dout.data_ptr(), _ptr(dout2), io_split, _ptr(dx0),
+                                             _ptr(dxg), dws[0], dws[1], dbs[0], dbs[1],
+                                             ctx.rows[0] if nw == 2 else d.N, ws.data_ptr(), nbytes, _lib.stream_ptr())
             _lib.check(rc, "tef_conv_backward_split")
             dw = db = None
         else:
             dw = torch.zeros((d.N,) + ctx.wshape, dtype=torch.float32, device=dev) if need_w else None
             db = torch.zeros((d.N,), dtype=torch.float32, device=dev) if need_b else None
-            rc = lib.tef_conv_backward(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
-                                       _ptr(out), dout.data_ptr(), _ptr(dx0), _ptr(dxg), _ptr(dw), _ptr(db),
-                                       ws.data_ptr(), nbytes, _lib.stream_ptr())
-            _lib.check(rc, "tef_conv_backward")
+            rc = lib.tef_conv_backward_split(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
+                                             _ptr(out), _ptr(out2), dout.data_ptr(), _ptr(dout2), io_split, _ptr(dx0),
+                                             _ptr(dxg), _ptr(dw), None, _ptr(db), None, d.N, ws.data_ptr(), nbytes,
+                                             _lib.stream_ptr())
+            _lib.check(rc, "tef_conv_backward_split")
         if not need[4]:
             dx0 = None
         dx1 = dgate = None
@@ -144,7 +157,7 @@ class _ConvFn(torch.autograd.Function):
             r0 += r
         if not has_bias:
             gb = [None] * (len(need) - 7 - nw)
-        return (None, None, None, None, dx0, dx1, dgate) + tuple(gw) + tuple(gb)
+        return (None, None, None, None, None, dx0, dx1, dgate) + tuple(gw) + tuple(gb)
 
 
 def enable_direct_grads(module, on=True):
@@ -159,11 +172,12 @@ def enable_direct_grads(module, on=True):
     return n
 
 
-def conv2d(packer, x0, weights, biases, stride=1, act=None, x1=None, gate1=None):
-    """weights / biases: a parameter or a tuple of parameters to be row-concatenated (same input, one GEMM)."""
+def conv2d(packer, x0, weights, biases, stride=1, act=None, x1=None, gate1=None, out_split=None):
+    """weights / biases: a parameter or a tuple of parameters to be row-concatenated (same input, one GEMM).
+    out_split: return the output channels as two tensors, [:out_split] and [out_split:]."""
     if not isinstance(weights, (tuple, list)):
         weights, biases = (weights,), (biases,)
-    return _ConvFn.apply(packer, stride, act, len(weights), x0, x1, gate1, *weights, *biases)
+    return _ConvFn.apply(packer, stride, act, len(weights), out_split, x0, x1, gate1, *weights, *biases)
 
 
 class _UpsampleFn(torch.autograd.Function):
@@ -291,9 +305,8 @@ class ConvGRU(nn.Module):
                                      dtype=input_.dtype, device=input_.device)
         C = self.hidden_size
         # update and reset gates share their input: one GEMM with 2C output channels
-        ur = conv2d(self._packed_ur, input_, (self.update_gate.weight, self.reset_gate.weight),
-                    (self.update_gate.bias, self.reset_gate.bias), 1, "sigmoid", x1=prev_state)
-        update, reset = ur[:, :C].contiguous(), ur[:, C:].contiguous()
+        update, reset = conv2d(self._packed_ur, input_, (self.update_gate.weight, self.reset_gate.weight),
+                               (self.update_gate.bias, self.reset_gate.bias), 1, "sigmoid", x1=prev_state, out_split=C)
         # tanh(out_gate(cat[input_, prev_state * reset])): the product is formed inside the im2col gather
         out_inputs = conv2d(self._packed_o, input_, self.out_gate.weight, self.out_gate.bias, 1, "tanh",
                             x1=prev_state, gate1=reset)
