@@ -39,11 +39,9 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restri
     y[idx] = mul * v;
 }
 
-// exact adjoint in gather form: input pixel (iy, ix) collects from the outputs whose taps include it.  The 1-D weights
-// of the <= 3*s candidate output rows / columns are computed once per thread (same expressions as the forward, so the
-// pair is an exact adjoint), the double loop is then a plain weighted sum.
-constexpr int kMaxTaps = 24;      // 3 * scale, scale <= 8 (RecEVFlowNet: x2 decoders, x2/x4/x8 flow heads)
-
+// Exact adjoint, separable: dX = Ry^T dY Rx with the forward's 1-D weights (same expressions as the forward, so the pair
+// is an exact adjoint).  One workgroup per (plane, input row): first the column sums over the <= 3*sh output rows that
+// touch the input row (T[ox], kept in LDS), then every input pixel of the row collects its <= 3*sw columns of T.
 __device__ __forceinline__ float tap_weight(int o, float inv, int n, int i)
 {
     int i0, i1;
@@ -52,47 +50,33 @@ __device__ __forceinline__ float tap_weight(int o, float inv, int n, int i)
     return (i0 == i ? l0 : 0.0f) + (i1 == i ? l1 : 0.0f);
 }
 
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
+__global__ __launch_bounds__(128) void upsample_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
                                                            int sh, int sw, float mul, float *__restrict__ dx)
 {
+    extern __shared__ float trow[];                 // [Wo]
     const int Ho = H * sh, Wo = W * sw;
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)planes * H * W) return;
-    int ix = (int)(idx % W);
-    size_t t = idx / W;
-    int iy = (int)(t % H), pl = (int)(t / H);
+    const int iy = blockIdx.x % H, pl = blockIdx.x / H;
     const float *g = dy + (size_t)pl * Ho * Wo;
-    int oy_lo = max(0, (iy - 1) * sh), oy_hi = min(Ho, (iy + 2) * sh);
-    int ox_lo = max(0, (ix - 1) * sw), ox_hi = min(Wo, (ix + 2) * sw);
     const float invh = 1.0f / (float)sh, invw = 1.0f / (float)sw;
-    float acc = 0.0f;
-    if (ox_hi - ox_lo <= kMaxTaps) {
-        float wx[kMaxTaps];
-#pragma unroll
-        for (int j = 0; j < kMaxTaps; ++j) wx[j] = (ox_lo + j < ox_hi) ? tap_weight(ox_lo + j, invw, W, ix) : 0.0f;
+    const int oy_lo = max(0, (iy - 1) * sh), oy_hi = min(Ho, (iy + 2) * sh);
+    for (int ox = threadIdx.x; ox < Wo; ox += blockDim.x) {
+        float acc = 0.0f;
         for (int oy = oy_lo; oy < oy_hi; ++oy) {
-            float wy = tap_weight(oy, invh, H, iy);
-            if (wy == 0.0f) continue;
-            const float *row = g + (size_t)oy * Wo + ox_lo;
-            float r = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMaxTaps; ++j)
-                if (wx[j] != 0.0f) r += wx[j] * row[j];
-            acc += wy * r;
+            float wy = tap_weight(oy, invh, H, iy);     // uniform across the workgroup
+            if (wy != 0.0f) acc += wy * g[(size_t)oy * Wo + ox];
         }
-    } else {
-        for (int oy = oy_lo; oy < oy_hi; ++oy) {
-            float wy = tap_weight(oy, invh, H, iy);
-            if (wy == 0.0f) continue;
-            float r = 0.0f;
-            for (int ox = ox_lo; ox < ox_hi; ++ox) {
-                float w = tap_weight(ox, invw, W, ix);
-                if (w != 0.0f) r += w * g[(size_t)oy * Wo + ox];
-            }
-            acc += wy * r;
-        }
+        trow[ox] = acc;
     }
-    dx[idx] = mul * acc;
+    __syncthreads();
+    for (int ix = threadIdx.x; ix < W; ix += blockDim.x) {
+        const int ox_lo = max(0, (ix - 1) * sw), ox_hi = min(Wo, (ix + 2) * sw);
+        float acc = 0.0f;
+        for (int ox = ox_lo; ox < ox_hi; ++ox) {
+            float wx = tap_weight(ox, invw, W, ix);
+            if (wx != 0.0f) acc += wx * trow[ox];
+        }
+        dx[((size_t)pl * H + iy) * W + ix] = mul * acc;
+    }
 }
 
 }  // namespace
@@ -115,9 +99,10 @@ int tef_upsample_bilinear_backward(const float *dy, int planes, int H, int W, in
 {
     if (!dy || !dx || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1)
         return tef::fail("tef_upsample_bilinear_backward: bad arguments"), TEF_ERR_INVALID;
-    size_t n = (size_t)planes * H * W;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, planes,
-                       H, W, scale_h, scale_w, mul, dx);
+    size_t lds = (size_t)W * scale_w * sizeof(float);
+    if (lds > 64 * 1024) return tef::fail("tef_upsample_bilinear_backward: output row too wide"), TEF_ERR_INVALID;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((size_t)planes * H)), dim3(128), lds, (hipStream_t)stream, dy,
+                       planes, H, W, scale_h, scale_w, mul, dx);
     return tef::check_launch("upsample_bwd_kernel");
 }
 
