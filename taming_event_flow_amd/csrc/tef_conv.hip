@@ -554,39 +554,60 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 // g = dout * act'(out) (out = post-activation: relu' = out > 0, tanh' = 1 - out^2, sigmoid' = out (1 - out)),
 // db[n] += sum over batch and pixels of g.   One block row per channel.
 // dy / out may come as two tensors (channels [0, iosplit) and [iosplit, N): the split outputs of a fused conv).
+__device__ __forceinline__ float act_grad_of(float gval, float y, int act)
+{
+    if (act == TEF_ACT_RELU) return y > 0.0f ? gval : 0.0f;
+    if (act == TEF_ACT_TANH) return gval * (1.0f - y * y);
+    if (act == TEF_ACT_SIGMOID) return gval * (y * (1.0f - y));
+    return gval;
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ dy2,
                                                       const float *__restrict__ out, const float *__restrict__ out2,
                                                       int iosplit, int act, int B, int N, int HW,
                                                       float *__restrict__ gbuf, float *__restrict__ dbias,
                                                       float *__restrict__ dbias2, int split)
 {
-    __shared__ float red[256];
-    int n = blockIdx.y;
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    const bool second = n >= iosplit;
+    const float *src = second ? dy2 : dy, *ysrc = second ? out2 : out;
+    const int cs = second ? N - iosplit : iosplit, cl = second ? n - iosplit : n;      // channels / index in its tensor
+    const bool store = act != TEF_ACT_NONE || iosplit < N;
     float local = 0.0f;
-    int M = B * HW;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
-        int b = m / HW, p = m - b * HW;
-        size_t o = ((size_t)b * N + n) * HW + p;
-        const bool second = n >= iosplit;
-        size_t oi = second ? ((size_t)b * (N - iosplit) + (n - iosplit)) * HW + p : ((size_t)b * iosplit + n) * HW + p;
-        float gval = second ? dy2[oi] : dy[oi];
-        if (act != TEF_ACT_NONE) {
-            float y = second ? out2[oi] : out[oi];
-            if (act == TEF_ACT_RELU) gval = y > 0.0f ? gval : 0.0f;
-            else if (act == TEF_ACT_TANH) gval *= (1.0f - y * y);
-            else gval *= y * (1.0f - y);
+    if ((HW & 3) == 0) {       // 4 pixels of one image per 16-byte access
+        const int Q = (B * HW) >> 2;
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+            int m = q << 2, b = m / HW, p = m - b * HW;
+            size_t oi = ((size_t)b * cs + cl) * HW + p, o = ((size_t)b * N + n) * HW + p;
+            float4 gv = *reinterpret_cast<const float4 *>(src + oi);
+            if (act != TEF_ACT_NONE) {
+                float4 y = *reinterpret_cast<const float4 *>(ysrc + oi);
+                gv = make_float4(act_grad_of(gv.x, y.x, act), act_grad_of(gv.y, y.y, act), act_grad_of(gv.z, y.z, act),
+                                 act_grad_of(gv.w, y.w, act));
+            }
+            if (store) *reinterpret_cast<float4 *>(gbuf + o) = gv;
+            local += (gv.x + gv.y) + (gv.z + gv.w);
         }
-        if (act != TEF_ACT_NONE || iosplit < N) gbuf[o] = gval;
-        local += gval;
+    } else {
+        const int M = B * HW;
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+            int b = m / HW, p = m - b * HW;
+            size_t oi = ((size_t)b * cs + cl) * HW + p, o = ((size_t)b * N + n) * HW + p;
+            float gval = src[oi];
+            if (act != TEF_ACT_NONE) gval = act_grad_of(gval, ysrc[oi], act);
+            if (store) gbuf[o] = gval;
+            local += gval;
+        }
     }
     if (!dbias) return;
-    red[threadIdx.x] = local;
+    for (int s = 32; s > 0; s >>= 1) local += __shfl_down(local, s, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = local;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = (red[0] + red[1]) + (red[2] + red[3]);
+        atomicAdd(n < split ? dbias + n : dbias2 + (n - split), t);
     }
-    if (threadIdx.x == 0) atomicAdd(n < split ? dbias + n : dbias2 + (n - split), red[0]);
 }
 
 // weight part [rows][Ct][ks][ks] -> rows [row0, row0 + rows) of
@@ -852,7 +873,7 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
     const float *gsrc = dout;
 
     if (d->act != TEF_ACT_NONE || dbias || io_split < N) {   // g = dY * act'(out), gathered into one tensor (+ bias gradient)
-        dim3 grid((unsigned)std::min<size_t>(64, ((size_t)q.M + 255) / 256), N);
+        dim3 grid((unsigned)std::min<size_t>(32, ((size_t)q.M / 4 + 255) / 256 + 1), N);
         hipLaunchKernelGGL(act_bwd_kernel, grid, dim3(256), 0, st, dout, dout2, out, out2, io_split, d->act, d->B, N, HW, gbuf,
                            dbias, dbias2, split_rows);
         if (int rc = tef::check_launch("act_bwd_kernel")) return rc;
