@@ -535,16 +535,37 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     STAMP(3);
 }
 
-// split-K epilogue: out = act(bias[r] + sum_z slab[z][r][c]) scattered to the NCHW output(s)
+// split-K epilogue: out = act(bias[r] + sum_z slab[z][r][c]) scattered to the NCHW output(s); 4 columns (pixels of one
+// image) per thread when the geometry allows 16-byte accesses
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int z, int rows, int cols,
                                                             const float *__restrict__ bias, int act, int hw, int split,
                                                             float *__restrict__ out, float *__restrict__ out2)
 {
+    const size_t plane = (size_t)rows * cols;
+    if (((cols | hw) & 3) == 0) {
+        const int c4 = cols >> 2;
+        size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (idx >= (size_t)rows * c4) return;
+        int r = (int)(idx / c4), c = (int)(idx - (size_t)r * c4) << 2;
+        float b0 = bias ? bias[r] : 0.0f;
+        float4 v = make_float4(b0, b0, b0, b0);
+        const float *sp = slab + (size_t)r * cols + c;
+        for (int k = 0; k < z; ++k) {
+            float4 t = *reinterpret_cast<const float4 *>(sp + (size_t)k * plane);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        v = make_float4(apply_act(v.x, act), apply_act(v.y, act), apply_act(v.z, act), apply_act(v.w, act));
+        int img = c / hw, px = c - img * hw;
+        float *o = r < split ? out + ((size_t)img * split + r) * hw + px
+                             : out2 + ((size_t)img * (rows - split) + (r - split)) * hw + px;
+        *reinterpret_cast<float4 *>(o) = v;
+        return;
+    }
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)rows * cols) return;
+    if (idx >= plane) return;
     int r = (int)(idx / cols), c = (int)(idx - (size_t)r * cols);
     float v = bias ? bias[r] : 0.0f;
-    for (int k = 0; k < z; ++k) v += slab[((size_t)k * rows + r) * cols + c];
+    for (int k = 0; k < z; ++k) v += slab[(size_t)k * plane + (size_t)r * cols + c];
     v = apply_act(v, act);
     int img = c / hw, px = c - img * hw;
     if (r < split) out[((size_t)img * split + r) * hw + px] = v;
