@@ -631,6 +631,118 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// ---- 1x1 convolutions onto a handful of channels (the flow prediction heads, Cin -> 2, tanh) --------------------
+// Streaming kernels instead of GEMM tiles: a 2-row output would leave 126 of the 128 tile rows empty.
+constexpr int kPwMaxN = 4;
+
+// out[b][n][p] = act(bias[n] + sum_ci W[n][ci] x[b][ci][p]);  wp [N][Kp] (k = ci).
+// Workgroup = 32 pixels x 8 channel groups (the groups' partial sums meet in LDS), so that small feature maps with
+// many channels still fill the chip.
+__global__ __launch_bounds__(256) void pw_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wp,
+                                                     const float *__restrict__ bias, int B, int C, int N, int HW, int Kp,
+                                                     int act, float *__restrict__ out)
+{
+    __shared__ float part[8][kPwMaxN][32];
+    const int px = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int m = blockIdx.x * 32 + px;
+    const bool ok = m < B * HW;
+    const int b = ok ? m / HW : 0, p = ok ? m - b * HW : 0;
+    float acc[kPwMaxN];
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) acc[n] = 0.0f;
+    const float *xp = x + (size_t)b * C * HW + p;
+    for (int ci = grp; ci < C; ci += 8) {
+        float v = ok ? xp[(size_t)ci * HW] : 0.0f;
+#pragma unroll
+        for (int n = 0; n < kPwMaxN; ++n)
+            if (n < N) acc[n] += wp[n * Kp + ci] * v;
+    }
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) part[grp][n][px] = acc[n];
+    __syncthreads();
+    if (grp < N && ok) {            // wave `grp` finishes output channel n = grp
+        const int n = grp;
+        float v = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += part[k][n][px];
+        out[((size_t)b * N + n) * HW + p] = apply_act(v, act);
+    }
+}
+
+__device__ __forceinline__ float pw_g(const float *__restrict__ dy, const float *__restrict__ out, size_t o, int act)
+{
+    float g = dy[o];
+    if (act == TEF_ACT_NONE) return g;
+    float y = out[o];
+    if (act == TEF_ACT_RELU) return y > 0.0f ? g : 0.0f;
+    if (act == TEF_ACT_TANH) return g * (1.0f - y * y);
+    return g * (y * (1.0f - y));
+}
+
+// dx[b][ci][p] = sum_n W[n][ci] g[b][n][p],  g = dY * act'(out);  w2 [C][K2p] (k' = n).  grid (pixels / 256, channel
+// groups of 16)
+__global__ __launch_bounds__(256) void pw_dx_kernel(const float *__restrict__ dy, const float *__restrict__ out,
+                                                    const float *__restrict__ w2, int B, int C, int N, int HW, int K2p,
+                                                    int act, float *__restrict__ dx)
+{
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= B * HW) return;
+    int b = m / HW, p = m - b * HW;
+    float g[kPwMaxN];
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) g[n] = n < N ? pw_g(dy, out, ((size_t)b * N + n) * HW + p, act) : 0.0f;
+    float *dp = dx + (size_t)b * C * HW + p;
+    const int c0 = blockIdx.y * 16, c1 = min(C, c0 + 16);
+    for (int ci = c0; ci < c1; ++ci) {
+        float v = 0.0f;
+#pragma unroll
+        for (int n = 0; n < kPwMaxN; ++n)
+            if (n < N) v += w2[ci * K2p + n] * g[n];
+        dp[(size_t)ci * HW] = v;
+    }
+}
+
+// dW[n][ci] += sum_{b,p} g[b][n][p] x[b][ci][p];  grid (input channel, pixel part); channel 0 also adds db[n] += sum g
+__global__ __launch_bounds__(256) void pw_dw_kernel(const float *__restrict__ dy, const float *__restrict__ out,
+                                                    const float *__restrict__ x, int B, int C, int N, int HW, int act,
+                                                    float *__restrict__ dw, float *__restrict__ db)
+{
+    __shared__ float red[4][2 * kPwMaxN];
+    const int ci = blockIdx.x;
+    float sw[kPwMaxN], sb[kPwMaxN];
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) sw[n] = sb[n] = 0.0f;
+    for (int m = blockIdx.y * blockDim.x + threadIdx.x; m < B * HW; m += gridDim.y * blockDim.x) {
+        int b = m / HW, p = m - b * HW;
+        float v = x[((size_t)b * C + ci) * HW + p];
+#pragma unroll
+        for (int n = 0; n < kPwMaxN; ++n)
+            if (n < N) {
+                float g = pw_g(dy, out, ((size_t)b * N + n) * HW + p, act);
+                sw[n] += g * v;
+                sb[n] += g;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) {
+        for (int s = 32; s > 0; s >>= 1) {
+            sw[n] += __shfl_down(sw[n], s, 64);
+            sb[n] += __shfl_down(sb[n], s, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            red[threadIdx.x >> 6][n] = sw[n];
+            red[threadIdx.x >> 6][kPwMaxN + n] = sb[n];
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < N) {
+        int n = threadIdx.x;
+        if (dw) atomicAdd(dw + (size_t)n * C + ci, (red[0][n] + red[1][n]) + (red[2][n] + red[3][n]));
+        if (db && ci == 0)
+            atomicAdd(db + n, (red[0][kPwMaxN + n] + red[1][kPwMaxN + n]) + (red[2][kPwMaxN + n] + red[3][kPwMaxN + n]));
+    }
+}
+
 // weight part [rows][Ct][ks][ks] -> rows [row0, row0 + rows) of
 //   wp [N][Kp]      k  = (ci, ky, kx)   forward A operand
 //   w2 [Ct][K2p]    k' = (n, ky, kx)    input-gradient A operand
@@ -753,6 +865,12 @@ bool make_geo(const tef_conv_desc *d, Geo *q)
     return true;
 }
 
+// flow prediction heads: 1x1, stride 1, one source, at most kPwMaxN output channels
+inline bool pointwise_small(const tef_conv_desc *d)
+{
+    return d->ksize == 1 && d->stride == 1 && d->C1 == 0 && d->N <= kPwMaxN;
+}
+
 struct ConvLayout {
     size_t gbuf, slab, total;
 };
@@ -841,6 +959,12 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     if (workspace_bytes < L.total) return tef::fail("tef_conv_forward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
+    if (pointwise_small(d) && out_split == d->N) {
+        tef::ProfScope ps(tef::PROF_CONV_FWD, st);
+        hipLaunchKernelGGL(pw_fwd_kernel, dim3((unsigned)((q.M + 31) / 32)), dim3(256), 0, st, x0, wp, bias, d->B, d->C0, d->N,
+                           q.Ho * q.Wo, q.Kp, d->act, out);
+        return tef::check_launch("pw_fwd_kernel");
+    }
     GemmArgs g{};
     g.A = wp; g.lda = q.Kp; g.rows = d->N;
     g.G = forward_gather(d, q, x0, x1, gate1);
@@ -892,6 +1016,22 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
     float *gbuf = (float *)(ws + L.gbuf), *slab = (float *)(ws + L.slab);
     const int N = d->N, HW = q.Ho * q.Wo;
     const float *gsrc = dout;
+    if (pointwise_small(d) && io_split == N && split_rows == N) {
+        if (dweight || dbias) {
+            tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
+            int parts = std::max(1, std::min((q.M + 1023) / 1024, (1024 + d->C0 - 1) / d->C0));
+            hipLaunchKernelGGL(pw_dw_kernel, dim3((unsigned)d->C0, (unsigned)parts), dim3(256), 0, st, dout, out, x0, d->B, d->C0,
+                               N, HW, d->act, dweight, dbias);
+            if (int rc = tef::check_launch("pw_dw_kernel")) return rc;
+        }
+        if (need_dx) {
+            tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
+            hipLaunchKernelGGL(pw_dx_kernel, dim3((unsigned)((q.M + 255) / 256), (unsigned)((d->C0 + 15) / 16)), dim3(256), 0, st,
+                               dout, out, w2, d->B, d->C0, N, HW, q.K2p, d->act, dx0);
+            if (int rc = tef::check_launch("pw_dx_kernel")) return rc;
+        }
+        return 0;
+    }
 
     if (d->act != TEF_ACT_NONE || dbias || io_split < N) {   // g = dY * act'(out), gathered into one tensor (+ bias gradient)
         dim3 grid((unsigned)std::min<size_t>(32, ((size_t)q.M / 4 + 255) / 256 + 1), N);
