@@ -125,18 +125,22 @@ __device__ __forceinline__ float gather_value(const Gather &G, const Pix &q, int
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// TR x TC workgroup tile, WR x WC wave tile (multiples of 32), 256 threads.
+// TR x TC workgroup tile, WR x WC wave tile (multiples of 32), NT = 256 or 512 threads (4 or 8 waves).
+// QV: quad-vector gathers (stride-1 geometry, rows / images multiples of 4 pixels); GATED: the second source is multiplied
+// by gate1.  Both are template parameters so that the staging code is straight-line.
 //
 // Operand staging (the part that decides the speed of an implicit GEMM):
 //   A, plain:        float4 along k, LDS row-major [TR][BK+4], fragments by ds_read_b128.
-//   A, NCHW (wgrad): g[n][(b, p)], float4 along the pixels when an image is a multiple of 4 pixels.
-//   B, gather:       a thread owns a QUAD of 4 consecutive output pixels and one k per load: for stride-1 convolutions
-//                    the 4 source elements are contiguous, so the im2col gather is ONE 16-byte load (wave-coalesced
-//                    along the pixels), staged k-major [BK][TC+4] with one ds_write_b128.  The 9 tap offsets of every
-//                    pixel live in an LDS table; (ci, tap) advance incrementally.  Quads that touch the padding, cross
-//                    a row, or belong to strided / transposed-strided geometry fall back to 4 predicated loads.
+//   A, NCHW (wgrad): g[n][(b, p)], float4 along the pixels (QV) or 4 scalar loads.
+//   B, gather:       a thread owns a QUAD of 4 consecutive output pixels and one k per load: with QV the valid source
+//                    elements are contiguous, so the im2col gather is ONE 16-byte load (wave-coalesced along the
+//                    pixels) anchored at element 0's position, staged k-major [BK][TC+4] with one ds_write_b128.  The 9
+//                    tap offsets of every pixel live in an LDS table; (ci, tap) advance incrementally.  Other geometry
+//                    (strides, ragged rows) uses 4 scalar loads per quad.
 //   B, gather^T (wgrad): the tile row is a fixed (ci, ky, kx), the reduction walks over pixels; same 16-byte trick,
 //                    LDS row-major [TC][BK+4].
+//   Every load is unconditional (invalid lanes read element 0); validity, gating and the end-of-tensor shifts are bit
+//   flags applied when the registers go to LDS, after the MFMA block of the stage.
 template <int NT, int TR, int TC, int WR, int WC, int AM, int BM, int EPI, bool QV, bool GATED>
 __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
 {
@@ -146,11 +150,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     constexpr int MR = WR / 32, MC = WC / 32;          // MFMA tiles per wave
     constexpr int LDB = TC + 4;                        // k-major B rows (floats), 16-byte multiple
     constexpr int BFLOATS = (BM == B_GATHER) ? BK * LDB : TC * LDK;
-#ifdef TEF_CONV_SINGLE_BUF
-    constexpr int NBUF = 1;
-#else
-    constexpr int NBUF = 2;
-#endif
+    constexpr int NBUF = 2;          // LDS stages (a single-buffered variant with two barriers per stage was slower)
     __shared__ __attribute__((aligned(16))) float As[NBUF][TR][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BFLOATS];
     __shared__ __attribute__((aligned(16))) int soff[BM == B_GATHER ? 9 : 1][BM == B_GATHER ? TC : 4];
@@ -486,17 +486,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
         __builtin_amdgcn_sched_barrier(0);      // every load is issued before the first MFMA
         multiply(buf);
         pin();
-        if (NBUF == 1) {
-            __syncthreads();        // everyone has read this stage
-            store_a(0);
-            store_b(0);
-            __syncthreads();
-        } else {
-            store_a(buf ^ 1);
-            store_b(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-        }
+        store_a(buf ^ 1);
+        store_b(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
     multiply(buf);
     STAMP(2);
