@@ -303,6 +303,8 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
     cfg["data"]["passes_loss"] = a.passes
     cfg["loss"]["warping"] = a.warping
     torch.manual_seed(1234)                      # identical initial weights on every rank
+    if a.graph and world > 1:
+        a.graph = False                          # the DP window (RCCL all-reduce + flag exchange) is replayed eagerly
     if a.graph:
         cfg["optimizer"]["capturable"] = True
     tr = train.Trainer(cfg, dev)
