@@ -528,6 +528,224 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     STAMP(3);
 }
 
+// =====================================================================================================================
+// 3x3 stride-1 convolution with the input patch staged in LDS ("halo" kernel) — forward and input gradient of the
+// layers whose rows are 16 / 32 / 64 / 128 pixels wide.  The implicit-GEMM kernel above gathers every im2col element from
+// L2 (each input element 9 times); here a workgroup's 128 output pixels are R = 128 / W whole image rows, the 8 input
+// channels of a k-chunk are loaded ONCE as an (R + 2) x (W + 2) patch (zero halo) and the nine taps are read from it.
+//   k order inside a chunk: (tap, channel) = 9 x 8 = 72;  A = weights repacked [row][chunk][tap][8] (input gradient:
+//   taps flipped at pack time, so the kernel always reads source pixel (y + ky - 1, x + kx - 1)).
+//   A is staged in 3 sub-stages of 24 k (3 taps), double-buffered; the patch is double-buffered per chunk.
+// Waves: (TR / WR) x 4, every wave a WR x 32 tile (MC = 1).  Epilogues as above (EPI_FWD / EPI_SLAB).
+// =====================================================================================================================
+constexpr int HC = 8;            // channels per k-chunk
+constexpr int HK = 9 * HC;       // k per chunk
+constexpr int HS = 3 * HC;       // k per A sub-stage (3 taps)
+constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
+
+template <int NT, int TR, int WR, int LOGW, int EPI, bool GATED>
+__global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
+{
+    constexpr int W = 1 << LOGW, R = 128 >> LOGW, PR = R + 2, PP = W + 8, PLANE = PR * PP;
+    constexpr int MR = WR / 32;
+    static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
+    __shared__ __attribute__((aligned(16))) float As[2][TR][HLDA];
+    __shared__ __attribute__((aligned(16))) float Ps[2][HC][PLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
+    const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
+    const int HWi = g.G.SH * W;                           // pixels per image (a multiple of 128)
+    const int img = col0 / HWi, y0 = (col0 - img * HWi) >> LOGW;
+    const int Ct = g.G.C0 + g.G.C1;
+    const int nch = g.lda / HK;
+    int c_begin = 0, c_end = nch;
+    if (EPI == EPI_SLAB) {
+        c_begin = blockIdx.z * g.ksplit;
+        c_end = min(nch, c_begin + g.ksplit);
+        if (c_begin >= c_end) return;
+    }
+
+    // zero the halo columns of both patch buffers once (data columns are 4 .. 4 + W - 1)
+    for (int t = tid; t < 2 * HC * PR; t += NT) {
+        float *row = &Ps[0][0][0] + (size_t)t * PP;
+        row[3] = 0.0f;
+        row[4 + W] = 0.0f;
+    }
+
+    // ---- A sub-tile staging: TR rows x 6 float4 ----
+    constexpr int AP = (TR * 6 + NT - 1) / NT;
+    float4 ra[AP];
+    auto load_a = [&](int chunk, int sub) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int piece = min(tid + p * NT, TR * 6 - 1);
+            int r = piece / 6, q4 = piece - r * 6;
+            int rc = min(row0 + r, g.rows - 1);
+            ra[p] = *reinterpret_cast<const float4 *>(g.A + (size_t)rc * g.lda + (size_t)chunk * HK + sub * HS + q4 * 4);
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int piece = tid + p * NT;
+            if (TR * 6 % NT == 0 || piece < TR * 6) {
+                int r = piece / 6, q4 = piece - r * 6;
+                *reinterpret_cast<float4 *>(&As[buf][r][q4 * 4]) = ra[p];
+            }
+        }
+    };
+
+    // ---- patch staging: 8 channels x PR rows x W / 4 float4 ----
+    constexpr int Q = W / 4, PIECES = HC * PR * Q, PPT = (PIECES + NT - 1) / NT;
+    float4 rp[PPT], rq[PPT];
+    int pofs[PPT], pcl[PPT];         // offset inside an image plane (-1: row outside the image / no piece), local channel
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {
+        int piece = tid + p * NT;
+        bool has = PIECES % NT == 0 || piece < PIECES;
+        int pc = has ? piece : 0;
+        int cl = pc / (PR * Q), rem = pc - cl * (PR * Q), prow = rem / Q, q4 = rem - prow * Q;
+        int y = y0 - 1 + prow;
+        pcl[p] = cl | (prow << 8) | (q4 << 16);
+        pofs[p] = (has && y >= 0 && y < g.G.SH) ? y * W + q4 * 4 : -1;
+    }
+    unsigned pmask = 0;              // bit p: piece p holds data; bit 8 + p: gated
+    auto load_p = [&](int chunk) {
+        pmask = 0;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            int ci = chunk * HC + (pcl[p] & 0xff);
+            bool ok = pofs[p] >= 0 && ci < Ct;
+            bool second = ok && ci >= g.G.C0;          // padded channels (ci >= Ct) read element 0 of src0
+            const float *src = second ? g.G.src1 : g.G.src0;
+            int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
+            size_t o = ok ? ((size_t)img * cs + clc) * HWi + pofs[p] : 0;
+            rp[p] = *reinterpret_cast<const float4 *>(src + o);
+            if (GATED) {
+                rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + ((ok && second) ? o : 0));
+                if (ok && second) pmask |= 1u << (8 + p);
+            }
+            if (ok) pmask |= 1u << p;
+        }
+    };
+    auto store_p = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            int piece = tid + p * NT;
+            if (PIECES % NT == 0 || piece < PIECES) {
+                float4 v = rp[p];
+                if (GATED && (pmask & (1u << (8 + p)))) { v.x *= rq[p].x; v.y *= rq[p].y; v.z *= rq[p].z; v.w *= rq[p].w; }
+                if (!(pmask & (1u << p))) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int cl = pcl[p] & 0xff, prow = (pcl[p] >> 8) & 0xff, q4 = pcl[p] >> 16;
+                *reinterpret_cast<float4 *>(&Ps[buf][cl][prow * PP + 4 + q4 * 4]) = v;
+            }
+        }
+    };
+    auto pin = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < AP; ++p) asm volatile("" : "+v"(ra[p].x), "+v"(ra[p].y), "+v"(ra[p].z), "+v"(ra[p].w));
+    };
+    auto pin_p = [&]() {
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            asm volatile("" : "+v"(rp[p].x), "+v"(rp[p].y), "+v"(rp[p].z), "+v"(rp[p].w));
+            if (GATED) asm volatile("" : "+v"(rq[p].x), "+v"(rq[p].y), "+v"(rq[p].z), "+v"(rq[p].w));
+        }
+        asm volatile("" : "+v"(pmask));
+    };
+
+    f32x16 acc[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+
+    // lane's pixel inside the tile and its patch base (tap (ky, kx) adds ky * PP + kx; channel j adds j * PLANE)
+    const int pl = wc * 32 + (lane & 31);
+    const int pbase = (4 * h) * PLANE + (pl >> LOGW) * PP + (pl & (W - 1)) + 3;
+    auto multiply = [&](int abuf, int pbuf, int sub) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int tap = sub * 3 + t, ky = tap / 3, kx = tap - ky * 3;
+            float4 fa[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                fa[i] = *reinterpret_cast<const float4 *>(&As[abuf][wr * WR + i * 32 + (lane & 31)][t * HC + 4 * h]);
+            const float *bp = &Ps[pbuf][0][0] + pbase + ky * PP + kx;
+            float4 fb = make_float4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    load_p(c_begin);
+    load_a(c_begin, 0);
+    store_p(0);
+    store_a(0);
+    __syncthreads();
+    int abuf = 0, pbuf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int cn = min(c + 1, c_end - 1);       // the last chunk re-loads itself (stored, never read)
+        // sub-stage 0
+        load_a(c, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(abuf, pbuf, 0);
+        pin();
+        store_a(abuf ^ 1);
+        __syncthreads();
+        abuf ^= 1;
+        // sub-stage 1: also start the next chunk's patch
+        load_a(c, 2);
+        load_p(cn);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(abuf, pbuf, 1);
+        pin();
+        store_a(abuf ^ 1);
+        __syncthreads();
+        abuf ^= 1;
+        // sub-stage 2
+        load_a(cn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(abuf, pbuf, 2);
+        pin();
+        pin_p();
+        store_a(abuf ^ 1);
+        store_p(pbuf ^ 1);
+        __syncthreads();
+        abuf ^= 1;
+        pbuf ^= 1;
+    }
+
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int cc = col0 + pl;
+    const int px = cc - img * HWi;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+        if (cc >= g.cols) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int r = row0 + wr * WR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (r >= g.rows) continue;
+            float v = acc[i][e];
+            if (EPI == EPI_FWD) {
+                if (g.bias) v += g.bias[r];
+                v = apply_act(v, g.act);
+                if (r < g.split) g.C[((size_t)img * g.split + r) * g.hw + px] = v;
+                else g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
+            } else {
+                g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + cc] = v;
+            }
+        }
+    }
+}
+
 // split-K epilogue: out = act(bias[r] + sum_z slab[z][r][c]) scattered to the NCHW output(s); 4 columns (pixels of one
 // image) per thread when the geometry allows 16-byte accesses
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int z, int rows, int cols,
@@ -763,6 +981,30 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
     }
 }
 
+// Halo-kernel operands of a 3x3 weight part [rows][Ct][3][3] (k-chunks of 8 channels, (tap, channel) inside a chunk):
+//   wh  [N][nch][9][8]     forward:        wh[n][chunk][tap][c]   = W[n][8 chunk + c][tap]
+//   w2h [Ct][nch2][9][8]   input gradient: w2h[ci][chunk][tap][c] = W[8 chunk + c][ci][8 - tap]   (taps flipped)
+// zero beyond Ct / N.  As pack_weight_kernel, a row part fills its own rows of wh and its own columns of w2h.
+__global__ __launch_bounds__(256) void pack_halo_kernel(const float *__restrict__ w, int rows, int row0, int N, int Ct,
+                                                        int nch, int nch2, float *__restrict__ wh, float *__restrict__ w2h)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lda = nch * HK, lda2 = nch2 * HK;
+    if (idx < (size_t)rows * lda) {
+        int n = (int)(idx / lda), k = (int)(idx - (size_t)n * lda);
+        int chunk = k / HK, r = k - chunk * HK, tap = r / HC, c = r - tap * HC, ci = chunk * HC + c;
+        wh[(size_t)(row0 + n) * lda + k] = ci < Ct ? w[((size_t)n * Ct + ci) * 9 + tap] : 0.0f;
+    }
+    int n_lo = row0, n_hi = (row0 + rows == N) ? nch2 * HC : row0 + rows;      // the last part also writes the padding
+    int span = (n_hi - n_lo) * 9;
+    if (idx < (size_t)Ct * span) {
+        int ci = (int)(idx / span), r = (int)(idx - (size_t)ci * span);
+        int n = n_lo + r / 9, tap = r - (r / 9) * 9;
+        float v = n < N ? w[((size_t)(n - row0) * Ct + ci) * 9 + (8 - tap)] : 0.0f;
+        w2h[(size_t)ci * lda2 + (size_t)(n / HC) * HK + tap * HC + (n % HC)] = v;
+    }
+}
+
 // ConvGRU state update (models/submodules.py:150) and its backward.
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ h, const float *__restrict__ u,
                                                         const float *__restrict__ o, size_t n, float *__restrict__ out)
@@ -864,6 +1106,43 @@ inline bool pointwise_small(const tef_conv_desc *d)
     return d->ksize == 1 && d->stride == 1 && d->C1 == 0 && d->N <= kPwMaxN;
 }
 
+// The halo kernel covers 3x3 stride-1 layers whose rows are 16 / 32 / 64 / 128 pixels and whose images are multiples
+// of 128 pixels (a workgroup's 128 pixels are whole rows of one image).
+inline int halo_logw(const tef_conv_desc *d)
+{
+    if (d->ksize != 3 || d->stride != 1 || (d->H * d->W) % 128) return 0;
+    return d->W == 16 ? 4 : d->W == 32 ? 5 : d->W == 64 ? 6 : d->W == 128 ? 7 : 0;
+}
+
+template <int LOGW, int EPI, bool GATED>
+int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
+{
+    dim3 grid((g.cols + 127) / 128, 1, z);
+    if (g.rows > 64) {
+        grid.y = (g.rows + 127) / 128;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, EPI, GATED>), grid, dim3(512), 0, st, g);
+    } else if (g.rows > 32) {
+        grid.y = (g.rows + 63) / 64;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, EPI, GATED>), grid, dim3(512), 0, st, g);
+    } else {
+        grid.y = (g.rows + 31) / 32;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, EPI, GATED>), grid, dim3(256), 0, st, g);
+    }
+    return tef::check_launch("conv3x3_halo_kernel");
+}
+
+template <int EPI>
+int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
+{
+    const bool gated = g.G.gate1 != nullptr;
+    switch (logw) {
+    case 4: return gated ? launch_halo_w<4, EPI, true>(g, z, st) : launch_halo_w<4, EPI, false>(g, z, st);
+    case 5: return gated ? launch_halo_w<5, EPI, true>(g, z, st) : launch_halo_w<5, EPI, false>(g, z, st);
+    case 6: return gated ? launch_halo_w<6, EPI, true>(g, z, st) : launch_halo_w<6, EPI, false>(g, z, st);
+    default: return gated ? launch_halo_w<7, EPI, true>(g, z, st) : launch_halo_w<7, EPI, false>(g, z, st);
+    }
+}
+
 struct ConvLayout {
     size_t gbuf, slab, total;
 };
@@ -874,8 +1153,10 @@ ConvLayout conv_layout(const tef_conv_desc *d, const Geo &q)
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n * sizeof(float) + 255) & ~(size_t)255; return r; };
     L.gbuf = take((size_t)d->N * q.M);
-    size_t s_fwd = (size_t)k_splits(d->N, q.M, q.Kp) * d->N * q.M;
-    size_t s_bwd = (size_t)k_splits(q.Ct, q.Min, q.K2p) * q.Ct * q.Min;
+    // split factors of both kernels (implicit GEMM / halo: their padded reduction lengths differ slightly)
+    int kh1 = ((q.Ct + HC - 1) / HC) * HK, kh2 = ((d->N + HC - 1) / HC) * HK;
+    size_t s_fwd = (size_t)std::max(k_splits(d->N, q.M, q.Kp), k_splits(d->N, q.M, kh1)) * d->N * q.M;
+    size_t s_bwd = (size_t)std::max(k_splits(q.Ct, q.Min, q.K2p), k_splits(q.Ct, q.Min, kh2)) * q.Ct * q.Min;
     L.slab = take(std::max(s_fwd, s_bwd));
     L.total = o;
     return L;
@@ -914,6 +1195,10 @@ size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, 
     Geo q;
     if (!make_geo(d, &q)) return 0;
     size_t np_ = (size_t)d->N * q.Kp, n2 = (size_t)q.Ct * q.K2p;
+    if (d->ksize == 3) {           // + the halo-kernel layouts
+        np_ += (size_t)d->N * ((q.Ct + HC - 1) / HC) * HK;
+        n2 += (size_t)q.Ct * ((d->N + HC - 1) / HC) * HK;
+    }
     if (wp_floats) *wp_floats = np_;
     if (w2_floats) *w2_floats = n2;
     return np_ + n2;
@@ -930,7 +1215,16 @@ int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, 
     size_t n = std::max((size_t)rows * q.Kp, (size_t)q.Ct * (c_hi - c_lo));
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight,
                        rows, row0, d->N, q.Ct, q.kk, q.Kp, q.K2p, wp, w2);
-    return tef::check_launch("pack_weight_kernel");
+    if (int rc = tef::check_launch("pack_weight_kernel")) return rc;
+    if (d->ksize == 3) {
+        int nch = (q.Ct + HC - 1) / HC, nch2 = (d->N + HC - 1) / HC;
+        int n_hi = (row0 + rows == d->N) ? nch2 * HC : row0 + rows;
+        size_t nh = std::max((size_t)rows * nch * HK, (size_t)q.Ct * (n_hi - row0) * 9);
+        hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, rows,
+                           row0, d->N, q.Ct, nch, nch2, wp + (size_t)d->N * q.Kp, w2 + (size_t)q.Ct * q.K2p);
+        if (int rc = tef::check_launch("pack_halo_kernel")) return rc;
+    }
+    return 0;
 }
 
 int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
@@ -963,8 +1257,25 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     g.G = forward_gather(d, q, x0, x1, gate1);
     g.cols = q.M; g.K = q.Kp;
     g.C = out; g.C2 = out2; g.split = out_split; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
-    int z = k_splits(d->N, q.M, q.Kp);
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
+#ifndef TEF_CONV_NO_HALO
+    if (int logw = halo_logw(d)) {
+        int nch = (q.Ct + HC - 1) / HC;
+        g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
+        int z = std::min(k_splits(d->N, q.M, nch * HK), nch);
+        if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
+        float *slab = (float *)(ws + L.slab);
+        g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
+        g.ksplit = (nch + z - 1) / z;
+        z = (nch + g.ksplit - 1) / g.ksplit;
+        if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
+        size_t n = (size_t)d->N * q.M;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
+                           d->act, q.Ho * q.Wo, out_split, out, out2);
+        return tef::check_launch("splitk_reduce_kernel");
+    }
+#endif
+    int z = k_splits(d->N, q.M, q.Kp);
     if (z == 1) return launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st);
     float *slab = (float *)(ws + L.slab);
     g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
@@ -1059,8 +1370,24 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         g.G = G;
         g.cols = q.Min; g.K = q.K2p;
         g.C = dx0; g.C2 = dx1; g.split = d->C0; g.bias = nullptr; g.act = TEF_ACT_NONE; g.hw = d->H * d->W;
-        int z = k_splits(q.Ct, q.Min, q.K2p);
         tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
+#ifndef TEF_CONV_NO_HALO
+        if (int logw = halo_logw(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
+            int nch2 = (N + HC - 1) / HC;
+            g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
+            int z = std::min(k_splits(q.Ct, q.Min, nch2 * HK), nch2);
+            if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
+            g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
+            g.ksplit = (nch2 + z - 1) / z;
+            z = (nch2 + g.ksplit - 1) / g.ksplit;
+            if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
+            size_t n = (size_t)q.Ct * q.Min;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min,
+                               (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1);
+            return tef::check_launch("splitk_reduce_kernel");
+        }
+#endif
+        int z = k_splits(q.Ct, q.Min, q.K2p);
         if (z == 1) {
             if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st)) return rc;
         } else {
