@@ -1108,6 +1108,20 @@ inline bool pointwise_small(const tef_conv_desc *d)
 
 // The halo kernel covers 3x3 stride-1 layers whose rows are 16 / 32 / 64 / 128 pixels and whose images are multiples
 // of 128 pixels (a workgroup's 128 pixels are whole rows of one image).
+#ifndef TEF_HALO_WG_TARGET
+#define TEF_HALO_WG_TARGET 512
+#endif
+// split factor of the halo kernel over its `nch` k-chunks
+inline int halo_splits(int rows, int cols, int nch)
+{
+    int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
+    int tiles = ((cols + 127) / 128) * ((rows + tr - 1) / tr);
+    if (tiles >= TEF_HALO_WG_TARGET / 2 || nch < 8) return 1;
+    int z = (TEF_HALO_WG_TARGET + tiles - 1) / tiles;
+    z = std::min(z, std::min(nch / 2, 16));
+    return z < 1 ? 1 : z;
+}
+
 inline int halo_logw(const tef_conv_desc *d)
 {
     if (d->ksize != 3 || d->stride != 1 || (d->H * d->W) % 128) return 0;
@@ -1155,8 +1169,8 @@ ConvLayout conv_layout(const tef_conv_desc *d, const Geo &q)
     L.gbuf = take((size_t)d->N * q.M);
     // split factors of both kernels (implicit GEMM / halo: their padded reduction lengths differ slightly)
     int kh1 = ((q.Ct + HC - 1) / HC) * HK, kh2 = ((d->N + HC - 1) / HC) * HK;
-    size_t s_fwd = (size_t)std::max(k_splits(d->N, q.M, q.Kp), k_splits(d->N, q.M, kh1)) * d->N * q.M;
-    size_t s_bwd = (size_t)std::max(k_splits(q.Ct, q.Min, q.K2p), k_splits(q.Ct, q.Min, kh2)) * q.Ct * q.Min;
+    size_t s_fwd = (size_t)std::max(k_splits(d->N, q.M, q.Kp), halo_splits(d->N, q.M, kh1 / HK)) * d->N * q.M;
+    size_t s_bwd = (size_t)std::max(k_splits(q.Ct, q.Min, q.K2p), halo_splits(q.Ct, q.Min, kh2 / HK)) * q.Ct * q.Min;
     L.slab = take(std::max(s_fwd, s_bwd));
     L.total = o;
     return L;
@@ -1262,7 +1276,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     if (int logw = halo_logw(d)) {
         int nch = (q.Ct + HC - 1) / HC;
         g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
-        int z = std::min(k_splits(d->N, q.M, nch * HK), nch);
+        int z = halo_splits(d->N, q.M, nch);
         if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
@@ -1375,7 +1389,7 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         if (int logw = halo_logw(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
-            int z = std::min(k_splits(q.Ct, q.Min, nch2 * HK), nch2);
+            int z = halo_splits(q.Ct, q.Min, nch2);
             if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
             g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
             g.ksplit = (nch2 + z - 1) / z;
