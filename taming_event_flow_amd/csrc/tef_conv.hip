@@ -543,10 +543,12 @@ constexpr int HK = 9 * HC;       // k per chunk
 constexpr int HS = 3 * HC;       // k per A sub-stage (3 taps)
 constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
 
-template <int NT, int TR, int WR, int LOGW, int EPI, bool GATED>
+// IPT > 1: images smaller than a tile (8 x 8 pixels at the deepest level) — the tile holds IPT whole images, each with
+// its own zero halo rows in the patch.
+template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 {
-    constexpr int W = 1 << LOGW, R = 128 >> LOGW, PR = R + 2, PP = W + 8, PLANE = PR * PP;
+    constexpr int W = 1 << LOGW, R = 128 >> LOGW, RI = R / IPT, PR = IPT * (RI + 2), PP = W + 8, PLANE = PR * PP;
     constexpr int MR = WR / 32;
     static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
     __shared__ __attribute__((aligned(16))) float As[2][TR][HLDA];
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
-    const int HWi = g.G.SH * W;                           // pixels per image (a multiple of 128)
-    const int img = col0 / HWi, y0 = (col0 - img * HWi) >> LOGW;
+    const int HWi = g.G.SH * W;                           // pixels per image (a multiple of 128, or 128 / IPT)
+    const int img = col0 / HWi, y0 = (col0 - img * HWi) >> LOGW;      // first image / image row of the tile
     const int Ct = g.G.C0 + g.G.C1;
     const int nch = g.lda / HK;
     int c_begin = 0, c_end = nch;
@@ -606,9 +608,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
         bool has = PIECES % NT == 0 || piece < PIECES;
         int pc = has ? piece : 0;
         int cl = pc / (PR * Q), rem = pc - cl * (PR * Q), prow = rem / Q, q4 = rem - prow * Q;
-        int y = y0 - 1 + prow;
+        int sub = prow / (RI + 2), y = y0 - 1 + (prow - sub * (RI + 2));      // image of the tile, row inside it
         pcl[p] = cl | (prow << 8) | (q4 << 16);
-        pofs[p] = (has && y >= 0 && y < g.G.SH) ? y * W + q4 * 4 : -1;
+        pofs[p] = (has && y >= 0 && y < g.G.SH && (long)(img + sub) * HWi < (long)g.cols) ? sub * HWi + y * W + q4 * 4 : -1;
     }
     unsigned pmask = 0;              // bit p: piece p holds data; bit 8 + p: gated
     auto load_p = [&](int chunk) {
@@ -620,7 +622,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             bool second = ok && ci >= g.G.C0;          // padded channels (ci >= Ct) read element 0 of src0
             const float *src = second ? g.G.src1 : g.G.src0;
             int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
-            size_t o = ok ? ((size_t)img * cs + clc) * HWi + pofs[p] : 0;
+            // pofs = (image of the tile) * HWi + offset inside the plane: move the image part to the channel stride
+            int sub = IPT > 1 ? pofs[p] / HWi : 0;
+            size_t o = ok ? ((size_t)(img + sub) * cs + clc) * HWi + (pofs[p] - sub * HWi) : 0;
             rp[p] = *reinterpret_cast<const float4 *>(src + o);
             if (GATED) {
                 rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + ((ok && second) ? o : 0));
@@ -664,7 +668,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 
     // lane's pixel inside the tile and its patch base (tap (ky, kx) adds ky * PP + kx; channel j adds j * PLANE)
     const int pl = wc * 32 + (lane & 31);
-    const int pbase = (4 * h) * PLANE + (pl >> LOGW) * PP + (pl & (W - 1)) + 3;
+    const int prow_l = IPT > 1 ? ((pl >> LOGW) / RI) * (RI + 2) + (pl >> LOGW) % RI : (pl >> LOGW);
+    const int pbase = (4 * h) * PLANE + prow_l * PP + (pl & (W - 1)) + 3;
     auto multiply = [&](int abuf, int pbuf, int sub) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -725,7 +730,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int cc = col0 + pl;
-    const int px = cc - img * HWi;
+    const int img_l = IPT > 1 ? cc / HWi : img;
+    const int px = cc - img_l * HWi;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
         if (cc >= g.cols) continue;
@@ -737,8 +743,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             if (EPI == EPI_FWD) {
                 if (g.bias) v += g.bias[r];
                 v = apply_act(v, g.act);
-                if (r < g.split) g.C[((size_t)img * g.split + r) * g.hw + px] = v;
-                else g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
+                if (r < g.split) g.C[((size_t)img_l * g.split + r) * g.hw + px] = v;
+                else g.C2[((size_t)img_l * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
             } else {
                 g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + cc] = v;
             }
@@ -1122,25 +1128,29 @@ inline int halo_splits(int rows, int cols, int nch)
     return z < 1 ? 1 : z;
 }
 
+// (also 8 x 8 images: two whole images per tile; returned as 3)
 inline int halo_logw(const tef_conv_desc *d)
 {
-    if (d->ksize != 3 || d->stride != 1 || (d->H * d->W) % 128) return 0;
+    if (d->ksize != 3 || d->stride != 1) return 0;
+    if (d->W == 8 && d->H == 8 && (d->B & 1) == 0) return 3;
+    if ((d->H * d->W) % 128) return 0;
     return d->W == 16 ? 4 : d->W == 32 ? 5 : d->W == 64 ? 6 : d->W == 128 ? 7 : 0;
 }
 
 template <int LOGW, int EPI, bool GATED>
 int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
+    constexpr int IPT = LOGW == 3 ? 2 : 1;
     dim3 grid((g.cols + 127) / 128, 1, z);
     if (g.rows > 64) {
         grid.y = (g.rows + 127) / 128;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, EPI, GATED>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED>), grid, dim3(512), 0, st, g);
     } else if (g.rows > 32) {
         grid.y = (g.rows + 63) / 64;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, EPI, GATED>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED>), grid, dim3(512), 0, st, g);
     } else {
         grid.y = (g.rows + 31) / 32;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, EPI, GATED>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, IPT, EPI, GATED>), grid, dim3(256), 0, st, g);
     }
     return tef::check_launch("conv3x3_halo_kernel");
 }
@@ -1150,6 +1160,7 @@ int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
 {
     const bool gated = g.G.gate1 != nullptr;
     switch (logw) {
+    case 3: return gated ? launch_halo_w<3, EPI, true>(g, z, st) : launch_halo_w<3, EPI, false>(g, z, st);
     case 4: return gated ? launch_halo_w<4, EPI, true>(g, z, st) : launch_halo_w<4, EPI, false>(g, z, st);
     case 5: return gated ? launch_halo_w<5, EPI, true>(g, z, st) : launch_halo_w<5, EPI, false>(g, z, st);
     case 6: return gated ? launch_halo_w<6, EPI, true>(g, z, st) : launch_halo_w<6, EPI, false>(g, z, st);
