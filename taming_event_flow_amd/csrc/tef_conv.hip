@@ -752,6 +752,204 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     }
 }
 
+// =====================================================================================================================
+// Weight gradient of the same layers with the input patch in LDS:  dW[n][(ci, tap)] += sum_pixels g[n][m] x[ci][m + tap].
+// rows = output channels (A = g, NCHW, k = pixels, read as in the implicit GEMM), columns = (ci, tap) in the weight's own
+// order, reduction over pixels in stages of 32.  The 128 columns of a tile touch at most 16 input channels: their
+// (rows + 2) x (32 + 2) patch of the stage's pixels is loaded once and every lane reads its own (channel, tap) window
+// from it — 9x fewer input loads than the transposed im2col gather, which is what the narrow layers are bound by.
+// =====================================================================================================================
+constexpr int WGC = 16;          // input channels a 128-column tile can touch
+
+template <int NT, int TR, int WR, int LOGW, bool GATED>
+__global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
+{
+    constexpr int W = 1 << LOGW, CW = W < 32 ? W : 32, RB = 32 / CW, PR = RB + 2, PP = CW + 8, PLANE = PR * PP + 1;
+    constexpr int MR = WR / 32;
+    static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
+    __shared__ __attribute__((aligned(16))) float As[2][TR][LDK];
+    __shared__ __attribute__((aligned(16))) float Ps[2][WGC * PLANE + 3];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
+    const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
+    const int H = g.G.SH, HWi = H * W;
+    const int Ct = g.G.C0 + g.G.C1;
+    const int c_lo = col0 / 9;
+    const int nst = g.K / 32;                                  // pixel stages in total (g.K = padded pixel count)
+    int s_begin = blockIdx.z * g.ksplit, s_end = min(nst, s_begin + g.ksplit);
+    if (s_begin >= s_end) return;
+
+    // ---- A staging: TR rows x 8 float4 of g[n][m0 .. m0 + 31] ----
+    constexpr int AP = (TR * 8 + NT - 1) / NT;
+    float4 ra[AP];
+    unsigned amask = 0;
+    auto load_a = [&](int st) {
+        amask = 0;
+        const int m0 = st * 32;
+        const int img = m0 / HWi, po = m0 - img * HWi;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int piece = tid + p * NT;
+            int r = piece >> 3, q4 = piece & 7;
+            bool ok = (TR * 8 % NT == 0 || piece < TR * 8) && (row0 + r) < g.rows && m0 < g.G.npix;
+            size_t o = ok ? ((size_t)img * g.rows + row0 + r) * HWi + po + q4 * 4 : 0;
+            ra[p] = *reinterpret_cast<const float4 *>(g.A + o);
+            if (ok) amask |= 1u << p;
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            int piece = tid + p * NT;
+            if (TR * 8 % NT == 0 || piece < TR * 8) {
+                float4 v = (amask & (1u << p)) ? ra[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(&As[buf][piece >> 3][(piece & 7) * 4]) = v;
+            }
+        }
+    };
+
+    // ---- patch staging: 16 channels x PR rows x (CW / 4 float4 + 2 halo scalars) ----
+    constexpr int Q = CW / 4, PIECES = WGC * PR * Q, PPT = (PIECES + NT - 1) / NT;
+    constexpr int HPIECES = WGC * PR * 2;
+    static_assert(HPIECES <= NT, "one halo element per thread");
+    float4 rp[PPT], rq[PPT];
+    float rh = 0.0f, rhq = 1.0f;
+    unsigned pmask = 0;              // bit p: piece p holds data; bit 8 + p: gated; bit 16: halo valid; bit 17: halo gated
+    auto load_p = [&](int st) {
+        pmask = 0;
+        const int m0 = st * 32;
+        const int img = m0 / HWi, po = m0 - img * HWi;
+        const int y0 = po >> LOGW, x0 = po & (W - 1);
+        const bool live = m0 < g.G.npix;
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            int piece = tid + p * NT;
+            bool has = PIECES % NT == 0 || piece < PIECES;
+            int pc = has ? piece : 0;
+            int cl = pc / (PR * Q), rem = pc - cl * (PR * Q), prow = rem / Q, q4 = rem - prow * Q;
+            int ci = c_lo + cl, y = y0 - 1 + prow;
+            bool ok = has && live && ci < Ct && y >= 0 && y < H;
+            bool second = ok && ci >= g.G.C0;
+            const float *src = second ? g.G.src1 : g.G.src0;
+            int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
+            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * W + x0 + q4 * 4 : 0;
+            rp[p] = *reinterpret_cast<const float4 *>(src + o);
+            if (GATED) {
+                rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + (second ? o : 0));
+                if (second) pmask |= 1u << (8 + p);
+            }
+            if (ok) pmask |= 1u << p;
+        }
+        {   // halo columns x0 - 1 and x0 + CW (inside the row only when the row is wider than the stage)
+            int pc = tid < HPIECES ? tid : 0;
+            int cl = pc / (PR * 2), rem = pc - cl * (PR * 2), prow = rem >> 1, side = rem & 1;
+            int ci = c_lo + cl, y = y0 - 1 + prow, x = side ? x0 + CW : x0 - 1;
+            bool ok = tid < HPIECES && live && ci < Ct && y >= 0 && y < H && x >= 0 && x < W;
+            bool second = ok && ci >= g.G.C0;
+            const float *src = second ? g.G.src1 : g.G.src0;
+            int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
+            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * W + x : 0;
+            rh = src[o];
+            if (GATED) {
+                rhq = g.G.gate1[second ? o : 0];
+                if (second) pmask |= 1u << 17;
+            }
+            if (ok) pmask |= 1u << 16;
+        }
+    };
+    auto store_p = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            int piece = tid + p * NT;
+            if (PIECES % NT == 0 || piece < PIECES) {
+                float4 v = rp[p];
+                if (GATED && (pmask & (1u << (8 + p)))) { v.x *= rq[p].x; v.y *= rq[p].y; v.z *= rq[p].z; v.w *= rq[p].w; }
+                if (!(pmask & (1u << p))) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                int cl = piece / (PR * Q), rem = piece - cl * (PR * Q), prow = rem / Q, q4 = rem - prow * Q;
+                float *dst = &Ps[buf][cl * PLANE + prow * PP + 4 + q4 * 4];      // PLANE is odd: scalar stores
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        }
+        if (tid < HPIECES) {
+            int cl = tid / (PR * 2), rem = tid - cl * (PR * 2), prow = rem >> 1, side = rem & 1;
+            float v = rh;
+            if (GATED && (pmask & (1u << 17))) v *= rhq;
+            if (!(pmask & (1u << 16))) v = 0.0f;
+            Ps[buf][cl * PLANE + prow * PP + (side ? 4 + CW : 3)] = v;
+        }
+    };
+    auto pin = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < AP; ++p) asm volatile("" : "+v"(ra[p].x), "+v"(ra[p].y), "+v"(ra[p].z), "+v"(ra[p].w));
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            asm volatile("" : "+v"(rp[p].x), "+v"(rp[p].y), "+v"(rp[p].z), "+v"(rp[p].w));
+            if (GATED) asm volatile("" : "+v"(rq[p].x), "+v"(rq[p].y), "+v"(rq[p].z), "+v"(rq[p].w));
+        }
+        asm volatile("" : "+v"(rh), "+v"(rhq), "+v"(pmask), "+v"(amask));
+    };
+
+    f32x16 acc[MR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+
+    // lane's column = (input channel, tap): its window base in the patch (pixel (ry, rx) of the stage adds ry * PP + rx)
+    const int col = col0 + wc * 32 + (lane & 31);
+    const int cil = min(col / 9 - c_lo, WGC - 1), tap = col % 9, ky = tap / 3, kx = tap - ky * 3;
+    const int pbase = cil * PLANE + ky * PP + kx + 3 + 4 * h;
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            float4 fa[MR];
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+                fa[i] = *reinterpret_cast<const float4 *>(&As[buf][wr * WR + i * 32 + (lane & 31)][kh * 8 + 4 * h]);
+            const float *bp = &Ps[buf][pbase + ((kh * 8) / CW) * PP + (kh * 8) % CW];
+            float4 fb = make_float4(bp[0], bp[1], bp[2], bp[3]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
+            }
+        }
+    };
+
+    load_a(s_begin);
+    load_p(s_begin);
+    store_a(0);
+    store_p(0);
+    __syncthreads();
+    int buf = 0;
+    for (int st = s_begin + 1; st < s_end; ++st) {
+        load_a(st);
+        load_p(st);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(buf);
+        pin();
+        store_a(buf ^ 1);
+        store_p(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    multiply(buf);
+
+    if (col >= g.valid_cols) return;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int r = row0 + wr * WR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (r >= g.rows) continue;
+            atomicAdd(r < g.split ? g.C + (size_t)r * g.ldc + col : g.C2 + (size_t)(r - g.split) * g.ldc + col, acc[i][e]);
+        }
+}
+
 // split-K epilogue: out = act(bias[r] + sum_z slab[z][r][c]) scattered to the NCHW output(s); 4 columns (pixels of one
 // image) per thread when the geometry allows 16-byte accesses
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int z, int rows, int cols,
@@ -1168,6 +1366,35 @@ int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
     }
 }
 
+template <int LOGW, bool GATED>
+int launch_wgrad_halo_w(const GemmArgs &g, int z, hipStream_t st)
+{
+    dim3 grid((g.cols + 127) / 128, 1, z);
+    if (g.rows > 64) {
+        grid.y = (g.rows + 127) / 128;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 128, 64, LOGW, GATED>), grid, dim3(512), 0, st, g);
+    } else if (g.rows > 32) {
+        grid.y = (g.rows + 63) / 64;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 64, 32, LOGW, GATED>), grid, dim3(512), 0, st, g);
+    } else {
+        grid.y = (g.rows + 31) / 32;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<256, 32, 32, LOGW, GATED>), grid, dim3(256), 0, st, g);
+    }
+    return tef::check_launch("wgrad3x3_halo_kernel");
+}
+
+inline int launch_wgrad_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
+{
+    const bool gated = g.G.gate1 != nullptr;
+    switch (logw) {
+    case 3: return gated ? launch_wgrad_halo_w<3, true>(g, z, st) : launch_wgrad_halo_w<3, false>(g, z, st);
+    case 4: return gated ? launch_wgrad_halo_w<4, true>(g, z, st) : launch_wgrad_halo_w<4, false>(g, z, st);
+    case 5: return gated ? launch_wgrad_halo_w<5, true>(g, z, st) : launch_wgrad_halo_w<5, false>(g, z, st);
+    case 6: return gated ? launch_wgrad_halo_w<6, true>(g, z, st) : launch_wgrad_halo_w<6, false>(g, z, st);
+    default: return gated ? launch_wgrad_halo_w<7, true>(g, z, st) : launch_wgrad_halo_w<7, false>(g, z, st);
+    }
+}
+
 struct ConvLayout {
     size_t gbuf, slab, total;
 };
@@ -1382,6 +1609,13 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         g.ksplit = ks;
         int z = (q.Mp + ks - 1) / ks;
         tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
+#ifndef TEF_CONV_NO_WGRAD_HALO
+        if (int logw = halo_logw(d)) {      // reduction in 32-pixel stages; ksplit counts stages
+            g.cols = q.K; g.valid_cols = q.K;
+            g.ksplit = ks / 32;
+            if (int rc = launch_wgrad_halo(g, logw, z, st)) return rc;
+        } else
+#endif
         if (int rc = launch_gemm<A_NCHW, B_GATHER_T, EPI_ATOMIC>(g, z, st)) return rc;
     }
     if (need_dx) {   // dx[ci][m'] = sum_{n,ky,kx} W[n][ci][ky][kx] * g[n][(m' + pad - k) / stride]
