@@ -29,7 +29,13 @@ def one_case(sm, dev, rng, g):
     C1 = int(rng.integers(1, 40)) if rng.random() < 0.4 else 0
     gated = C1 > 0 and rng.random() < 0.6
     N = int(rng.choice([1, 2, 3, 7, 31, 32, 33, 64, 65, 100, 128, 130]))
-    if rng.random() < 0.5:      # quad-vector geometry: rows a multiple of 4
+    u = rng.random()
+    if u < 0.3:        # halo-kernel geometry: 3x3 stride 1, rows of 16 / 32 / 64 pixels in whole 128-pixel tiles, or 8x8
+        W = int(rng.choice([8, 16, 32, 64]))
+        H = 8 if W == 8 else (128 // W) * int(rng.integers(1, 4))
+        if W == 8:
+            B = 2 * int(rng.integers(1, 3))
+    elif u < 0.65:     # quad-vector geometry: rows a multiple of 4
         H, W = int(rng.integers(1, 12)), 4 * int(rng.integers(1, 10))
     else:
         H, W = int(rng.integers(1, 30)), int(rng.integers(1, 30))
@@ -41,7 +47,7 @@ def one_case(sm, dev, rng, g):
     w = torch.randn(N, C0 + C1, k, k, generator=g) * 0.3
     b = torch.randn(N, generator=g)
     leaves = [t for t in (x0, x1, gate, w, b) if t is not None]
-    ts = [t.clone().requires_grad_() for t in leaves]
+    ts = [t.double().requires_grad_() for t in leaves]        # reference in float64: errors are measured against exact
     it = iter(ts)
     rx0 = next(it)
     rx1 = next(it) if x1 is not None else None
@@ -55,7 +61,7 @@ def one_case(sm, dev, rng, g):
     dout = torch.randn(y_ref.shape, generator=g)
     if act == "relu":        # a pre-activation within rounding of 0 may land on either side of the kink: keep it out
         dout = dout * (pre.abs() > 1e-4)
-    g_ref = torch.autograd.grad(y_ref, ts, dout)
+    g_ref = torch.autograd.grad(y_ref, ts, dout.double())
     ds = [t.to(dev).requires_grad_() for t in leaves]
     it = iter(ds)
     dx0 = next(it)
