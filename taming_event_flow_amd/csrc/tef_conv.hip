@@ -545,9 +545,12 @@ constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
 
 // IPT > 1: images smaller than a tile (8 x 8 pixels at the deepest level) — the tile holds IPT whole images, each with
 // its own zero halo rows in the patch.
-template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED>
+// GEN: images of any size (width a multiple of 4): the 128 pixels are a W x R rectangle of the image (W = tile width),
+// the halo columns hold real neighbours and are loaded with the patch, edge tiles are masked.
+template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED, bool GEN>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 {
+    static_assert(!GEN || IPT == 1, "general tiles hold one image");
     constexpr int W = 1 << LOGW, R = 128 >> LOGW, RI = R / IPT, PR = IPT * (RI + 2), PP = W + 8, PLANE = PR * PP;
     constexpr int MR = WR / 32;
     static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
@@ -557,8 +560,19 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
-    const int HWi = g.G.SH * W;                           // pixels per image (a multiple of 128, or 128 / IPT)
-    const int img = col0 / HWi, y0 = (col0 - img * HWi) >> LOGW;      // first image / image row of the tile
+    const int WI = GEN ? g.G.SW : W;                      // image width
+    const int HWi = g.G.SH * WI;                          // pixels per image (!GEN: a multiple of 128, or 128 / IPT)
+    int img, y0, x0 = 0;                                  // image, first row and first column of the tile
+    if (GEN) {
+        const int ntx = (WI + W - 1) / W, nty = (g.G.SH + R - 1) / R;
+        img = blockIdx.x / (ntx * nty);
+        int rem = blockIdx.x - img * ntx * nty, ty = rem / ntx;
+        y0 = ty * R;
+        x0 = (rem - ty * ntx) * W;
+    } else {
+        img = col0 / HWi;
+        y0 = (col0 - img * HWi) >> LOGW;
+    }
     const int Ct = g.G.C0 + g.G.C1;
     const int nch = g.lda / HK;
     int c_begin = 0, c_end = nch;
@@ -568,8 +582,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
         if (c_begin >= c_end) return;
     }
 
-    // zero the halo columns of both patch buffers once (data columns are 4 .. 4 + W - 1)
-    for (int t = tid; t < 2 * HC * PR; t += NT) {
+    // zero the halo columns of both patch buffers once (data columns are 4 .. 4 + W - 1); GEN rewrites them per chunk
+    for (int t = tid; t < (GEN ? 0 : 2 * HC * PR); t += NT) {
         float *row = &Ps[0][0][0] + (size_t)t * PP;
         row[3] = 0.0f;
         row[4 + W] = 0.0f;
@@ -610,11 +624,31 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
         int cl = pc / (PR * Q), rem = pc - cl * (PR * Q), prow = rem / Q, q4 = rem - prow * Q;
         int sub = prow / (RI + 2), y = y0 - 1 + (prow - sub * (RI + 2));      // image of the tile, row inside it
         pcl[p] = cl | (prow << 8) | (q4 << 16);
-        pofs[p] = (has && y >= 0 && y < g.G.SH && (long)(img + sub) * HWi < (long)g.cols) ? sub * HWi + y * W + q4 * 4 : -1;
+        if (GEN) pofs[p] = (has && y >= 0 && y < g.G.SH && x0 + q4 * 4 < WI) ? y * WI + x0 + q4 * 4 : -1;
+        else pofs[p] = (has && y >= 0 && y < g.G.SH && (long)(img + sub) * HWi < (long)g.cols) ? sub * HWi + y * W + q4 * 4 : -1;
     }
-    unsigned pmask = 0;              // bit p: piece p holds data; bit 8 + p: gated
+    unsigned pmask = 0;              // bit p: piece p holds data; bit 8 + p: gated; bits 16 / 17: halo element valid / gated
+    float rh = 0.0f, rhq = 1.0f;     // GEN: this thread's halo-column element (x0 - 1 or x0 + W of one patch row)
+    constexpr int HPIECES = HC * PR * 2;
+    static_assert(!GEN || HPIECES <= NT, "one halo element per thread");
     auto load_p = [&](int chunk) {
         pmask = 0;
+        if (GEN) {
+            int pc = tid < HPIECES ? tid : 0;
+            int cl = pc / (PR * 2), rem = pc - cl * (PR * 2), prow = rem >> 1, side = rem & 1;
+            int ci = chunk * HC + cl, y = y0 - 1 + prow, x = side ? x0 + W : x0 - 1;
+            bool ok = tid < HPIECES && ci < Ct && y >= 0 && y < g.G.SH && x >= 0 && x < WI;
+            bool second = ok && ci >= g.G.C0;
+            const float *src = second ? g.G.src1 : g.G.src0;
+            int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
+            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * WI + x : 0;
+            rh = src[o];
+            if (GATED) {
+                rhq = g.G.gate1[second ? o : 0];
+                if (second) pmask |= 1u << 17;
+            }
+            if (ok) pmask |= 1u << 16;
+        }
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
             int ci = chunk * HC + (pcl[p] & 0xff);
@@ -645,6 +679,13 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
                 *reinterpret_cast<float4 *>(&Ps[buf][cl][prow * PP + 4 + q4 * 4]) = v;
             }
         }
+        if (GEN && tid < HPIECES) {
+            int cl = tid / (PR * 2), rem = tid - cl * (PR * 2), prow = rem >> 1, side = rem & 1;
+            float v = rh;
+            if (GATED && (pmask & (1u << 17))) v *= rhq;
+            if (!(pmask & (1u << 16))) v = 0.0f;
+            Ps[buf][cl][prow * PP + (side ? 4 + W : 3)] = v;
+        }
     };
     auto pin = [&]() {
         __builtin_amdgcn_sched_barrier(0);
@@ -658,6 +699,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             if (GATED) asm volatile("" : "+v"(rq[p].x), "+v"(rq[p].y), "+v"(rq[p].z), "+v"(rq[p].w));
         }
         asm volatile("" : "+v"(pmask));
+        if (GEN) asm volatile("" : "+v"(rh), "+v"(rhq));
     };
 
     f32x16 acc[MR];
@@ -729,12 +771,19 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     }
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int cc = col0 + pl;
-    const int img_l = IPT > 1 ? cc / HWi : img;
-    const int px = cc - img_l * HWi;
+    int cc = col0 + pl;
+    int img_l = IPT > 1 ? cc / HWi : img;
+    int px = cc - img_l * HWi;
+    bool pix_ok = cc < g.cols;
+    if (GEN) {        // the lane's pixel inside the image; the column index becomes the true pixel index
+        int y = y0 + (pl >> LOGW), x = x0 + (pl & (W - 1));
+        pix_ok = y < g.G.SH && x < WI;
+        px = y * WI + x;
+        cc = img * HWi + px;
+    }
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-        if (cc >= g.cols) continue;
+        if (!pix_ok) continue;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             int r = row0 + wr * WR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1335,35 +1384,66 @@ inline int halo_logw(const tef_conv_desc *d)
     return d->W == 16 ? 4 : d->W == 32 ? 5 : d->W == 64 ? 6 : d->W == 128 ? 7 : 0;
 }
 
-template <int LOGW, int EPI, bool GATED>
+// Any other 3x3 stride-1 layer whose rows are a multiple of 4 pixels runs on W x (128 / W) rectangles: returns
+// log2(tile width), the widest of 128 / 64 / 32 / 16 that wastes the least of the image's columns and rows.
+inline int halo_gen_logw(const tef_conv_desc *d)
+{
+    if (d->ksize != 3 || d->stride != 1 || (d->W & 3) || d->W < 16 || d->H * d->W < 128) return 0;
+    int best = 0;
+    double best_eff = 0.0;
+    for (int lw = 7; lw >= 4; --lw) {
+        int tw = 1 << lw, th = 128 >> lw;
+        double eff = (double)d->W / (((d->W + tw - 1) / tw) * tw) * (double)d->H / (((d->H + th - 1) / th) * th);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = lw; }
+    }
+    return best_eff >= 0.6 ? best : 0;
+}
+
+template <int LOGW, int EPI, bool GATED, bool GEN>
 int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
-    constexpr int IPT = LOGW == 3 ? 2 : 1;
-    dim3 grid((g.cols + 127) / 128, 1, z);
+    constexpr int IPT = (LOGW == 3 && !GEN) ? 2 : 1;
+    unsigned tiles = (g.cols + 127) / 128;
+    if (GEN) tiles = (unsigned)((g.G.SW + (1 << LOGW) - 1) >> LOGW) * ((g.G.SH + (128 >> LOGW) - 1) / (128 >> LOGW)) *
+                     (g.G.npix / (g.G.SH * g.G.SW));
+    dim3 grid(tiles, 1, z);
     if (g.rows > 64) {
         grid.y = (g.rows + 127) / 128;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
     } else if (g.rows > 32) {
         grid.y = (g.rows + 63) / 64;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
     } else {
         grid.y = (g.rows + 31) / 32;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, IPT, EPI, GATED>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(256), 0, st, g);
     }
     return tef::check_launch("conv3x3_halo_kernel");
 }
 
+// logw: 3..7 whole-row tiles (halo_logw), 100 + 4..7 general rectangles (halo_gen_logw)
 template <int EPI>
 int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
 {
     const bool gated = g.G.gate1 != nullptr;
     switch (logw) {
-    case 3: return gated ? launch_halo_w<3, EPI, true>(g, z, st) : launch_halo_w<3, EPI, false>(g, z, st);
-    case 4: return gated ? launch_halo_w<4, EPI, true>(g, z, st) : launch_halo_w<4, EPI, false>(g, z, st);
-    case 5: return gated ? launch_halo_w<5, EPI, true>(g, z, st) : launch_halo_w<5, EPI, false>(g, z, st);
-    case 6: return gated ? launch_halo_w<6, EPI, true>(g, z, st) : launch_halo_w<6, EPI, false>(g, z, st);
-    default: return gated ? launch_halo_w<7, EPI, true>(g, z, st) : launch_halo_w<7, EPI, false>(g, z, st);
+    case 3: return gated ? launch_halo_w<3, EPI, true, false>(g, z, st) : launch_halo_w<3, EPI, false, false>(g, z, st);
+    case 4: return gated ? launch_halo_w<4, EPI, true, false>(g, z, st) : launch_halo_w<4, EPI, false, false>(g, z, st);
+    case 5: return gated ? launch_halo_w<5, EPI, true, false>(g, z, st) : launch_halo_w<5, EPI, false, false>(g, z, st);
+    case 6: return gated ? launch_halo_w<6, EPI, true, false>(g, z, st) : launch_halo_w<6, EPI, false, false>(g, z, st);
+    case 7: return gated ? launch_halo_w<7, EPI, true, false>(g, z, st) : launch_halo_w<7, EPI, false, false>(g, z, st);
+    case 104: return gated ? launch_halo_w<4, EPI, true, true>(g, z, st) : launch_halo_w<4, EPI, false, true>(g, z, st);
+    case 105: return gated ? launch_halo_w<5, EPI, true, true>(g, z, st) : launch_halo_w<5, EPI, false, true>(g, z, st);
+    case 106: return gated ? launch_halo_w<6, EPI, true, true>(g, z, st) : launch_halo_w<6, EPI, false, true>(g, z, st);
+    default: return gated ? launch_halo_w<7, EPI, true, true>(g, z, st) : launch_halo_w<7, EPI, false, true>(g, z, st);
     }
+}
+
+// the halo forward / input-gradient kernel to use for this layer: 0 = none (implicit GEMM)
+inline int halo_mode(const tef_conv_desc *d)
+{
+    if (int lw = halo_logw(d)) return lw;
+    if (int lw = halo_gen_logw(d)) return 100 + lw;
+    return 0;
 }
 
 template <int LOGW, bool GATED>
@@ -1511,7 +1591,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     g.C = out; g.C2 = out2; g.split = out_split; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
 #ifndef TEF_CONV_NO_HALO
-    if (int logw = halo_logw(d)) {
+    if (int logw = halo_mode(d)) {
         int nch = (q.Ct + HC - 1) / HC;
         g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
         int z = halo_splits(d->N, q.M, nch);
@@ -1631,7 +1711,7 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         g.C = dx0; g.C2 = dx1; g.split = d->C0; g.bias = nullptr; g.act = TEF_ACT_NONE; g.hw = d->H * d->W;
         tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
 #ifndef TEF_CONV_NO_HALO
-        if (int logw = halo_logw(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
+        if (int logw = halo_mode(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
             int z = halo_splits(q.Ct, q.Min, nch2);

@@ -35,7 +35,9 @@ def one_case(sm, dev, rng, g):
         H = 8 if W == 8 else (128 // W) * int(rng.integers(1, 4))
         if W == 8:
             B = 2 * int(rng.integers(1, 3))
-    elif u < 0.65:     # quad-vector geometry: rows a multiple of 4
+    elif u < 0.45:     # general halo rectangles: rows a multiple of 4 pixels, any height, ragged tile edges
+        H, W = int(rng.integers(3, 40)), 4 * int(rng.integers(4, 24))
+    elif u < 0.7:      # quad-vector geometry: rows a multiple of 4
         H, W = int(rng.integers(1, 12)), 4 * int(rng.integers(1, 10))
     else:
         H, W = int(rng.integers(1, 30)), int(rng.integers(1, 30))
