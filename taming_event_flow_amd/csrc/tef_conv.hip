@@ -547,11 +547,15 @@ constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
 // its own zero halo rows in the patch.
 // GEN: images of any size (width a multiple of 4): the 128 pixels are a W x R rectangle of the image (W = tile width),
 // the halo columns hold real neighbours and are loaded with the patch, edge tiles are masked.
-template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED, bool GEN>
+// S = 2: the stride-2 encoder heads (forward only): the tile's R x W outputs read a (2R + 1) x (2W + 1) input patch with
+// stride-2 windows (padding 1: only the left / top halo exists, and it is zero).
+template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED, bool GEN, int S = 1>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 {
     static_assert(!GEN || IPT == 1, "general tiles hold one image");
-    constexpr int W = 1 << LOGW, R = 128 >> LOGW, RI = R / IPT, PR = IPT * (RI + 2), PP = W + 8, PLANE = PR * PP;
+    static_assert(S == 1 || (!GEN && IPT == 1), "stride-2 tiles are whole output rows of one image");
+    constexpr int W = 1 << LOGW, R = 128 >> LOGW, RI = R / IPT, PR = S == 1 ? IPT * (RI + 2) : 2 * R + 1,
+                  PP = S * W + 8, PLANE = PR * PP;
     constexpr int MR = WR / 32;
     static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
     __shared__ __attribute__((aligned(16))) float As[2][TR][HLDA];
@@ -560,8 +564,9 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
-    const int WI = GEN ? g.G.SW : W;                      // image width
-    const int HWi = g.G.SH * WI;                          // pixels per image (!GEN: a multiple of 128, or 128 / IPT)
+    const int WI = GEN ? g.G.SW : S * W;                  // (input) image width
+    const int HWi = g.G.SH * WI;                          // pixels per input image (!GEN: a multiple of 128, or 128 / IPT)
+    const int HWo = S == 1 ? HWi : g.G.OH * W;            // pixels per output image
     int img, y0, x0 = 0;                                  // image, first row and first column of the tile
     if (GEN) {
         const int ntx = (WI + W - 1) / W, nty = (g.G.SH + R - 1) / R;
@@ -570,8 +575,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
         y0 = ty * R;
         x0 = (rem - ty * ntx) * W;
     } else {
-        img = col0 / HWi;
-        y0 = (col0 - img * HWi) >> LOGW;
+        img = col0 / HWo;
+        y0 = (col0 - img * HWo) >> LOGW;
     }
     const int Ct = g.G.C0 + g.G.C1;
     const int nch = g.lda / HK;
@@ -586,7 +591,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     for (int t = tid; t < (GEN ? 0 : 2 * HC * PR); t += NT) {
         float *row = &Ps[0][0][0] + (size_t)t * PP;
         row[3] = 0.0f;
-        row[4 + W] = 0.0f;
+        row[4 + S * W] = 0.0f;
     }
 
     // ---- A sub-tile staging: TR rows x 6 float4 ----
@@ -612,8 +617,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
         }
     };
 
-    // ---- patch staging: 8 channels x PR rows x W / 4 float4 ----
-    constexpr int Q = W / 4, PIECES = HC * PR * Q, PPT = (PIECES + NT - 1) / NT;
+    // ---- patch staging: 8 channels x PR rows x S W / 4 float4 ----
+    constexpr int Q = S * W / 4, PIECES = HC * PR * Q, PPT = (PIECES + NT - 1) / NT;
     float4 rp[PPT], rq[PPT];
     int pofs[PPT], pcl[PPT];         // offset inside an image plane (-1: row outside the image / no piece), local channel
 #pragma unroll
@@ -622,10 +627,11 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
         bool has = PIECES % NT == 0 || piece < PIECES;
         int pc = has ? piece : 0;
         int cl = pc / (PR * Q), rem = pc - cl * (PR * Q), prow = rem / Q, q4 = rem - prow * Q;
-        int sub = prow / (RI + 2), y = y0 - 1 + (prow - sub * (RI + 2));      // image of the tile, row inside it
+        int sub = S == 1 ? prow / (RI + 2) : 0;                                  // image of the tile, row inside it
+        int y = S == 1 ? y0 - 1 + (prow - sub * (RI + 2)) : 2 * y0 - 1 + prow;
         pcl[p] = cl | (prow << 8) | (q4 << 16);
         if (GEN) pofs[p] = (has && y >= 0 && y < g.G.SH && x0 + q4 * 4 < WI) ? y * WI + x0 + q4 * 4 : -1;
-        else pofs[p] = (has && y >= 0 && y < g.G.SH && (long)(img + sub) * HWi < (long)g.cols) ? sub * HWi + y * W + q4 * 4 : -1;
+        else pofs[p] = (has && y >= 0 && y < g.G.SH && (long)(img + sub) * HWo < (long)g.cols) ? sub * HWi + y * WI + q4 * 4 : -1;
     }
     unsigned pmask = 0;              // bit p: piece p holds data; bit 8 + p: gated; bits 16 / 17: halo element valid / gated
     float rh = 0.0f, rhq = 1.0f;     // GEN: this thread's halo-column element (x0 - 1 or x0 + W of one patch row)
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     // lane's pixel inside the tile and its patch base (tap (ky, kx) adds ky * PP + kx; channel j adds j * PLANE)
     const int pl = wc * 32 + (lane & 31);
     const int prow_l = IPT > 1 ? ((pl >> LOGW) / RI) * (RI + 2) + (pl >> LOGW) % RI : (pl >> LOGW);
-    const int pbase = (4 * h) * PLANE + prow_l * PP + (pl & (W - 1)) + 3;
+    const int pbase = (4 * h) * PLANE + S * prow_l * PP + S * (pl & (W - 1)) + 3;
     auto multiply = [&](int abuf, int pbuf, int sub) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -772,8 +778,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     int cc = col0 + pl;
-    int img_l = IPT > 1 ? cc / HWi : img;
-    int px = cc - img_l * HWi;
+    int img_l = IPT > 1 ? cc / HWo : img;
+    int px = cc - img_l * HWo;
     bool pix_ok = cc < g.cols;
     if (GEN) {        // the lane's pixel inside the image; the column index becomes the true pixel index
         int y = y0 + (pl >> LOGW), x = x0 + (pl & (W - 1));
@@ -1438,6 +1444,43 @@ int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
     }
 }
 
+// stride-2 heads (forward): even input sizes, output rows of 16 / 32 / 64 / 128 pixels in whole 128-pixel tiles
+inline int halo_s2_logw(const tef_conv_desc *d)
+{
+    if (d->ksize != 3 || d->stride != 2 || (d->H & 1) || (d->W & 1) || d->C1 != 0) return 0;
+    int Wo = d->W / 2, Ho = d->H / 2;
+    if ((Ho * Wo) % 128) return 0;
+    return Wo == 16 ? 4 : Wo == 32 ? 5 : Wo == 64 ? 6 : Wo == 128 ? 7 : 0;
+}
+
+template <int LOGW, int EPI>
+int launch_halo_s2_w(const GemmArgs &g, int z, hipStream_t st)
+{
+    dim3 grid((g.cols + 127) / 128, 1, z);
+    if (g.rows > 64) {
+        grid.y = (g.rows + 127) / 128;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, 1, EPI, false, false, 2>), grid, dim3(512), 0, st, g);
+    } else if (g.rows > 32) {
+        grid.y = (g.rows + 63) / 64;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, 1, EPI, false, false, 2>), grid, dim3(512), 0, st, g);
+    } else {
+        grid.y = (g.rows + 31) / 32;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, 1, EPI, false, false, 2>), grid, dim3(256), 0, st, g);
+    }
+    return tef::check_launch("conv3x3_halo_kernel (stride 2)");
+}
+
+template <int EPI>
+int launch_halo_s2(const GemmArgs &g, int logw, int z, hipStream_t st)
+{
+    switch (logw) {
+    case 4: return launch_halo_s2_w<4, EPI>(g, z, st);
+    case 5: return launch_halo_s2_w<5, EPI>(g, z, st);
+    case 6: return launch_halo_s2_w<6, EPI>(g, z, st);
+    default: return launch_halo_s2_w<7, EPI>(g, z, st);
+    }
+}
+
 // the halo forward / input-gradient kernel to use for this layer: 0 = none (implicit GEMM)
 inline int halo_mode(const tef_conv_desc *d)
 {
@@ -1591,6 +1634,21 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     g.C = out; g.C2 = out2; g.split = out_split; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
 #ifndef TEF_CONV_NO_HALO
+    if (int logw = halo_s2_logw(d)) {
+        int nch = (q.Ct + HC - 1) / HC;
+        g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
+        int z = halo_splits(d->N, q.M, nch);
+        if (z <= 1) return launch_halo_s2<EPI_FWD>(g, logw, 1, st);
+        float *slab = (float *)(ws + L.slab);
+        g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
+        g.ksplit = (nch + z - 1) / z;
+        z = (nch + g.ksplit - 1) / g.ksplit;
+        if (int rc = launch_halo_s2<EPI_SLAB>(g, logw, z, st)) return rc;
+        size_t n = (size_t)d->N * q.M;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
+                           d->act, q.Ho * q.Wo, out_split, out, out2);
+        return tef::check_launch("splitk_reduce_kernel");
+    }
     if (int logw = halo_mode(d)) {
         int nch = (q.Ct + HC - 1) / HC;
         g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;

@@ -41,6 +41,10 @@ def one_case(sm, dev, rng, g):
         H, W = int(rng.integers(1, 12)), 4 * int(rng.integers(1, 10))
     else:
         H, W = int(rng.integers(1, 30)), int(rng.integers(1, 30))
+    if k == 3 and stride == 2 and rng.random() < 0.6:      # stride-2 halo geometry: output rows of 16 / 32 / 64 pixels
+        Wo = int(rng.choice([16, 32, 64]))
+        H, W = 2 * (128 // Wo) * int(rng.integers(1, 3)), 2 * Wo
+        C1, gated = 0, False
     act = [None, "relu", "tanh", "sigmoid"][int(rng.integers(0, 4))]
     desc = dict(B=B, C0=C0, C1=C1, N=N, H=H, W=W, k=k, stride=stride, act=act, gated=gated)
     x0 = torch.randn(B, C0, H, W, generator=g)
