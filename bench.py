@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--event-every", type=int, default=4,
+                    help="per-kernel HIP events are recorded on every K-th timed step (each pair costs a few us of stream time)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: repeat the window this long")
     return ap.parse_args()
 
@@ -193,9 +195,12 @@ def main():
     for k in range(a.warmup):
         step(k)
     barrier()
-    lib.tef_profile_enable(0 if a.no_kernel_events else 1)       # HIP events around every kernel, on the launch stream
+    # per-kernel HIP events (start / stop of each launch, on the launch stream) on every `event_every`-th timed step
+    lib.tef_profile_enable(0 if a.no_kernel_events else 1)
     t0 = time.perf_counter()
     for k in range(a.steps):
+        if not a.no_kernel_events:
+            lib.tef_profile_pause(0 if k % max(1, a.event_every) == 0 else 1)
         last, last_grads = step(k)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (diagnostic: host- vs device-bound)
     barrier()
@@ -249,6 +254,7 @@ def main():
             "loss": round(loss_val, 6),
             "ms_update_per_window": round(1e3 * t_update, 3),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
+            "kernel_events_every": None if a.no_kernel_events else max(1, a.event_every),
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -45,6 +45,7 @@ const char *tef_last_error(void);
  * tef_profile_enable(1) resets the accumulators; tef_profile_collect() synchronises the recorded events and
  * accumulates per-slot totals; slots are named (tef_profile_name) after the kernels in DESIGN.md. */
 int tef_profile_enable(int on);
+int tef_profile_pause(int paused);      /* stop / resume recording without clearing what was recorded (sampled timing) */
 int tef_profile_collect(void);
 int tef_profile_slots(void);
 const char *tef_profile_name(int slot);

@@ -49,6 +49,7 @@ SIGNATURES = {
     "tef_version": (ctypes.c_int, []),
     "tef_last_error": (ctypes.c_char_p, []),
     "tef_profile_enable": (ctypes.c_int, [ctypes.c_int]),
+    "tef_profile_pause": (ctypes.c_int, [ctypes.c_int]),
     "tef_profile_collect": (ctypes.c_int, []),
     "tef_profile_slots": (ctypes.c_int, []),
     "tef_profile_name": (ctypes.c_char_p, [ctypes.c_int]),

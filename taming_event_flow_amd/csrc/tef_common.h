@@ -20,6 +20,9 @@ enum ProfSlot {
     PROF_PACK = 0, PROF_WARP, PROF_SPLAT, PROF_STATS, PROF_REDUCE, PROF_CHAIN_BWD, PROF_DFLOW,
     PROF_SMOOTH_FWD, PROF_SMOOTH_BWD, PROF_ENCODE, PROF_CONV_FWD, PROF_CONV_DGRAD, PROF_CONV_WGRAD, PROF_NSLOTS
 };
+// A (start, stop) event pair to hand to hipExtLaunchKernelGGL: the timestamps then come from the kernel's own dispatch
+// signal and no marker packets enter the stream.  Both are null while profiling is off (= a plain launch).
+void prof_events(int slot, hipEvent_t *start, hipEvent_t *stop);
 void prof_begin(int slot, hipStream_t st);
 void prof_end(int slot, hipStream_t st);
 struct ProfScope {

@@ -56,6 +56,15 @@ int check_launch(const char *kernel)
     return TEF_ERR_LAUNCH;
 }
 
+void prof_events(int slot, hipEvent_t *start, hipEvent_t *stop)
+{
+    *start = *stop = nullptr;
+    if (!g_prof_on) return;
+    *start = get_event();
+    *stop = get_event();
+    g_pending.push_back(Pending{slot, *start, *stop});
+}
+
 void prof_begin(int slot, hipStream_t st)
 {
     if (!g_prof_on) return;
@@ -82,6 +91,12 @@ int tef_profile_enable(int on)
     for (int i = 0; i < tef::PROF_NSLOTS; ++i) { g_ms[i] = 0.0; g_calls[i] = 0; }
     for (auto &p : g_pending) { g_pool.push_back(p.a); g_pool.push_back(p.b); }
     g_pending.clear();
+    return 0;
+}
+
+int tef_profile_pause(int paused)
+{
+    g_prof_on = paused == 0;
     return 0;
 }
 

@@ -29,6 +29,7 @@
 // (coordinate normalisation + un-normalisation of grid_sample, floor(y + 1) corners, true division
 // for the timestamp normalisation); compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1162,6 +1163,14 @@ inline Events to_events(const tef_events *e)
     return r;
 }
 
+// launch with the kernel's own start / stop timestamps when per-kernel timing is on (tef_profile_enable)
+#define TEF_LAUNCH_TIMED(slot, kernel, grid, block, lds, st, ...)                                   \
+    do {                                                                                            \
+        hipEvent_t ev_a_, ev_b_;                                                                    \
+        tef::prof_events(slot, &ev_a_, &ev_b_);                                                     \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev_a_, ev_b_, 0, __VA_ARGS__);          \
+    } while (0)
+
 inline void band_geometry(const Win &w, int *rows_per_band, int *nbands, size_t *lds)
 {
     int rows = (int)(kLdsBudget / ((size_t)(w.W + kRowPad) * sizeof(double)));
@@ -1259,32 +1268,23 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     if (w.Mt > 0) {
         int chunks = (w.Mt + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
-        tef::ProfScope ps(tef::PROF_WARP, st);
         if (w.kind == TEF_KIND_ITERATIVE)
-            hipLaunchKernelGGL(iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_WARP, iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, chunks);
         else
-            hipLaunchKernelGGL(linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_WARP, linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, chunks);
     }
     if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
     size_t lds;
     band_geometry(w, &rows, &nbands, &lds);
-    {
-        tef::ProfScope ps(tef::PROF_SPLAT, st);
-        hipLaunchKernelGGL(splat_kernel, dim3(xcd_grid(w.nimg * FB, 4 * nbands)), dim3(kSplatThreads), lds, st, w, g, d,
-                           traj, meta, iwe_c, iwe_t, rows, nbands);
-    }
+    TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_kernel, dim3(xcd_grid(w.nimg * FB, 4 * nbands)), dim3(kSplatThreads), lds, st, w,
+                     g, d, traj, meta, iwe_c, iwe_t, rows, nbands);
     if (int rc = tef::check_launch("splat_kernel")) return rc;
-    {
-        tef::ProfScope ps(tef::PROF_STATS, st);
-        hipLaunchKernelGGL(image_stats_kernel, dim3((unsigned)(w.nimg * FB), kStatParts), dim3(256), 0, st, w, iwe_c, iwe_t,
-                           ar, (double *)(ws + L.parts));
-    }
+    TEF_LAUNCH_TIMED(tef::PROF_STATS, image_stats_kernel, dim3((unsigned)(w.nimg * FB), kStatParts), dim3(256), 0, st, w,
+                     iwe_c, iwe_t, ar, (double *)(ws + L.parts));
     if (int rc = tef::check_launch("image_stats_kernel")) return rc;
-    {
-        tef::ProfScope ps(tef::PROF_REDUCE, st);
-        hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), stats, loss_out);
-    }
+    TEF_LAUNCH_TIMED(tef::PROF_REDUCE, loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), stats,
+                     loss_out);
     return tef::check_launch("loss_reduce_kernel");
 }
 
@@ -1311,23 +1311,19 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     if (w.M > 0) {
         int chunks = (w.M + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
-        tef::ProfScope ps(tef::PROF_CHAIN_BWD, st);
         if (w.kind == TEF_KIND_ITERATIVE)
-            hipLaunchKernelGGL(iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar, stats, grad_out,
-                               cy, cx, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+                             stats, grad_out, cy, cx, chunks);
         else
-            hipLaunchKernelGGL(linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats, grad_out, cy, cx,
-                               chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
+                             grad_out, cy, cx, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
     int rows, nbands;
     size_t lds;
     band_geometry(w, &rows, &nbands, &lds);
-    {
-        tef::ProfScope ps(tef::PROF_DFLOW, st);
-        hipLaunchKernelGGL(dflow_splat_kernel, dim3(xcd_grid(w.P * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w, g,
-                           traj, cy, cx, dflows, rows, nbands);
-    }
+    TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(xcd_grid(w.P * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w,
+                     g, traj, cy, cx, dflows, rows, nbands);
     return tef::check_launch("dflow_splat_kernel");
 }
 
