@@ -1328,7 +1328,7 @@ inline int k_splits(int rows, int cols, int K)
 #define TEF_CONV_WG_TARGET 512          // two 512-thread workgroups per CU
 #endif
     if (tiles >= TEF_CONV_WG_TARGET / 2 || K < 512) return 1;
-    int z = (TEF_CONV_WG_TARGET + tiles - 1) / tiles;
+    int z = TEF_CONV_WG_TARGET / tiles;      // at or just below two full rounds of the chip, never just past them
     int zmax = K / 128;
     if (z > zmax) z = zmax;
     if (z > 16) z = 16;
@@ -1370,17 +1370,6 @@ inline bool pointwise_small(const tef_conv_desc *d)
 #ifndef TEF_HALO_WG_TARGET
 #define TEF_HALO_WG_TARGET 512
 #endif
-// split factor of the halo kernel over its `nch` k-chunks
-inline int halo_splits(int rows, int cols, int nch)
-{
-    int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
-    int tiles = ((cols + 127) / 128) * ((rows + tr - 1) / tr);
-    if (tiles >= TEF_HALO_WG_TARGET / 2 || nch < 8) return 1;
-    int z = (TEF_HALO_WG_TARGET + tiles - 1) / tiles;
-    z = std::min(z, std::min(nch / 2, 16));
-    return z < 1 ? 1 : z;
-}
-
 // (also 8 x 8 images: two whole images per tile; returned as 3)
 inline int halo_logw(const tef_conv_desc *d)
 {
@@ -1391,13 +1380,14 @@ inline int halo_logw(const tef_conv_desc *d)
 }
 
 // Any other 3x3 stride-1 layer whose rows are a multiple of 4 pixels runs on W x (128 / W) rectangles: returns
-// log2(tile width), the widest of 128 / 64 / 32 / 16 that wastes the least of the image's columns and rows.
+// log2(tile width), the widest of 128 / 64 / 32 / 16 / 8 that wastes the least of the image's columns and rows
+// (30 x 40 at the deepest level of a 480 x 640 input: 8 x 16 tiles cover 94 %, 16 x 8 tiles 78 %).
 inline int halo_gen_logw(const tef_conv_desc *d)
 {
-    if (d->ksize != 3 || d->stride != 1 || (d->W & 3) || d->W < 16 || d->H * d->W < 128) return 0;
+    if (d->ksize != 3 || d->stride != 1 || (d->W & 3) || d->W < 8 || d->H * d->W < 128) return 0;
     int best = 0;
     double best_eff = 0.0;
-    for (int lw = 7; lw >= 4; --lw) {
+    for (int lw = 7; lw >= 3; --lw) {
         int tw = 1 << lw, th = 128 >> lw;
         double eff = (double)d->W / (((d->W + tw - 1) / tw) * tw) * (double)d->H / (((d->H + th - 1) / th) * th);
         if (eff > best_eff + 1e-9) { best_eff = eff; best = lw; }
@@ -1419,6 +1409,9 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
     } else if (g.rows > 32) {
         grid.y = (g.rows + 63) / 64;
         hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
+    } else if constexpr (GEN && LOGW == 3) {     // 8 x 16 rectangles: the 288 halo elements need more than 256 threads
+        grid.y = (g.rows + 63) / 64;
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
     } else {
         grid.y = (g.rows + 31) / 32;
         hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(256), 0, st, g);
@@ -1426,7 +1419,7 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
     return tef::check_launch("conv3x3_halo_kernel");
 }
 
-// logw: 3..7 whole-row tiles (halo_logw), 100 + 4..7 general rectangles (halo_gen_logw)
+// logw: 3..7 whole-row tiles (halo_logw), 100 + 3..7 general rectangles (halo_gen_logw)
 template <int EPI>
 int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
 {
@@ -1437,6 +1430,7 @@ int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
     case 5: return gated ? launch_halo_w<5, EPI, true, false>(g, z, st) : launch_halo_w<5, EPI, false, false>(g, z, st);
     case 6: return gated ? launch_halo_w<6, EPI, true, false>(g, z, st) : launch_halo_w<6, EPI, false, false>(g, z, st);
     case 7: return gated ? launch_halo_w<7, EPI, true, false>(g, z, st) : launch_halo_w<7, EPI, false, false>(g, z, st);
+    case 103: return gated ? launch_halo_w<3, EPI, true, true>(g, z, st) : launch_halo_w<3, EPI, false, true>(g, z, st);
     case 104: return gated ? launch_halo_w<4, EPI, true, true>(g, z, st) : launch_halo_w<4, EPI, false, true>(g, z, st);
     case 105: return gated ? launch_halo_w<5, EPI, true, true>(g, z, st) : launch_halo_w<5, EPI, false, true>(g, z, st);
     case 106: return gated ? launch_halo_w<6, EPI, true, true>(g, z, st) : launch_halo_w<6, EPI, false, true>(g, z, st);
@@ -1489,6 +1483,45 @@ inline int halo_mode(const tef_conv_desc *d)
     return 0;
 }
 
+// Split factor of the halo kernel over its `nch` k-chunks.  A CU finishes its workgroups at a nearly fixed rate, so a
+// launch runs as long as its fullest CU: `tiles` workgroups use tiles / (256 * ceil(tiles / 256)) of the chip (300 tiles
+// -> 59 %; measured 73 vs 97 TFLOP/s with three slices, tools/zsweep.sh).  Layers with few tiles are split up to the
+// workgroup target (never past it); larger ones take the smallest factor that fills the last round of 256 to >= 85 %.
+inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
+{
+    int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
+    int ctiles = (cols + 127) / 128;
+    if (int m = halo_mode(d); m > 100) {      // general rectangles: edge tiles are partly empty
+        int lw = m - 100;
+        ctiles = ((d->W + (1 << lw) - 1) >> lw) * ((d->H + (128 >> lw) - 1) / (128 >> lw)) * d->B;
+    }
+    int tiles = ctiles * ((rows + tr - 1) / tr);
+#ifdef TEF_HALO_SPLIT_ENV
+    if (const char *e = getenv("TEF_HALO_Z")) {         // experiment hook: force the split factor
+        int z = atoi(e);
+        if (z > 0 && nch >= 8) return std::max(1, std::min(z, std::min(nch / 2, 16)));
+    }
+#endif
+    if (nch < 8 || tiles >= 1024) return 1;
+    const int zmax = std::min(nch / 2, 16);
+    if (tiles < TEF_HALO_WG_TARGET / 4) {           // stay at or just below two full rounds (80 tiles: 480, not 560)
+        int z = TEF_HALO_WG_TARGET / tiles;
+        return std::max(1, std::min(z, zmax));
+    }
+    auto fill = [](int wg) { return (double)wg / (256.0 * ((wg + 255) / 256)); };
+    if (tiles >= 256 && fill(tiles) >= 0.85) return 1;
+    int best = 1;
+    double best_fill = tiles >= 256 ? fill(tiles) : 0.0;
+    for (int z = 2; z <= std::min(zmax, 8); ++z) {
+        int wg = tiles * z;
+        if (wg < 400) continue;
+        double f = fill(wg);
+        if (f >= 0.85) return z;
+        if (f > best_fill + 1e-9) { best_fill = f; best = z; }
+    }
+    return best;
+}
+
 template <int LOGW, bool GATED>
 int launch_wgrad_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
@@ -1530,8 +1563,8 @@ ConvLayout conv_layout(const tef_conv_desc *d, const Geo &q)
     L.gbuf = take((size_t)d->N * q.M);
     // split factors of both kernels (implicit GEMM / halo: their padded reduction lengths differ slightly)
     int kh1 = ((q.Ct + HC - 1) / HC) * HK, kh2 = ((d->N + HC - 1) / HC) * HK;
-    size_t s_fwd = (size_t)std::max(k_splits(d->N, q.M, q.Kp), halo_splits(d->N, q.M, kh1 / HK)) * d->N * q.M;
-    size_t s_bwd = (size_t)std::max(k_splits(q.Ct, q.Min, q.K2p), halo_splits(q.Ct, q.Min, kh2 / HK)) * q.Ct * q.Min;
+    size_t s_fwd = (size_t)std::max(k_splits(d->N, q.M, q.Kp), halo_splits(d, d->N, q.M, kh1 / HK)) * d->N * q.M;
+    size_t s_bwd = (size_t)std::max(k_splits(q.Ct, q.Min, q.K2p), halo_splits(d, q.Ct, q.Min, kh2 / HK)) * q.Ct * q.Min;
     L.slab = take(std::max(s_fwd, s_bwd));
     L.total = o;
     return L;
@@ -1637,7 +1670,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     if (int logw = halo_s2_logw(d)) {
         int nch = (q.Ct + HC - 1) / HC;
         g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
-        int z = halo_splits(d->N, q.M, nch);
+        int z = halo_splits(d, d->N, q.M, nch);
         if (z <= 1) return launch_halo_s2<EPI_FWD>(g, logw, 1, st);
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
@@ -1652,7 +1685,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     if (int logw = halo_mode(d)) {
         int nch = (q.Ct + HC - 1) / HC;
         g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
-        int z = halo_splits(d->N, q.M, nch);
+        int z = halo_splits(d, d->N, q.M, nch);
         if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
@@ -1772,7 +1805,7 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         if (int logw = halo_mode(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
-            int z = halo_splits(q.Ct, q.Min, nch2);
+            int z = halo_splits(d, q.Ct, q.Min, nch2);
             if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
             g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
             g.ksplit = (nch2 + z - 1) / z;

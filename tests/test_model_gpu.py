@@ -192,6 +192,9 @@ def test_conv_against_torch_reference_large(dev):
     (1, 9, 0, 2, 6, 10, 1, 1, None, False),         # 1x1 prediction head shape
     (2, 4, 4, 130, 8, 12, 3, 1, "relu", True),      # quad-vector gathers (W % 4 == 0), 128-row tile + remainder, gate
     (1, 2, 0, 5, 4, 4, 3, 1, None, False),          # a single 16-pixel image: every quad touches the tensor's ends
+    (1, 12, 0, 20, 30, 40, 3, 1, "relu", False),    # 8 x 16 halo rectangles (deepest eval level), <= 32 output rows
+    (2, 5, 6, 70, 33, 24, 3, 1, "tanh", True),      # 8 x 16 rectangles, ragged bottom edge, concat + gate
+    (1, 64, 8, 40, 30, 40, 3, 1, "relu", True),     # 8 x 16 rectangles with the reduction split over slabs
 ])
 def test_conv_ragged_geometries(dev, B, C0, C1, N, H, W, k, stride, act, gated):
     """tef_conv_forward / backward against torch's CPU fp32 convolution on shapes that exercise every staging path."""
