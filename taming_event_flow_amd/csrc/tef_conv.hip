@@ -1367,9 +1367,6 @@ inline bool pointwise_small(const tef_conv_desc *d)
 
 // The halo kernel covers 3x3 stride-1 layers whose rows are 16 / 32 / 64 / 128 pixels and whose images are multiples
 // of 128 pixels (a workgroup's 128 pixels are whole rows of one image).
-#ifndef TEF_HALO_WG_TARGET
-#define TEF_HALO_WG_TARGET 512
-#endif
 // (also 8 x 8 images: two whole images per tile; returned as 3)
 inline int halo_logw(const tef_conv_desc *d)
 {
@@ -1483,10 +1480,11 @@ inline int halo_mode(const tef_conv_desc *d)
     return 0;
 }
 
-// Split factor of the halo kernel over its `nch` k-chunks.  A CU finishes its workgroups at a nearly fixed rate, so a
-// launch runs as long as its fullest CU: `tiles` workgroups use tiles / (256 * ceil(tiles / 256)) of the chip (300 tiles
-// -> 59 %; measured 73 vs 97 TFLOP/s with three slices, tools/zsweep.sh).  Layers with few tiles are split up to the
-// workgroup target (never past it); larger ones take the smallest factor that fills the last round of 256 to >= 85 %.
+// Split factor of the halo kernel over its `nch` k-chunks.  A CU finishes its workgroups at a nearly fixed rate (one
+// resident workgroup already keeps its MFMA pipe busy), so a launch runs as long as its fullest CU: `wg` workgroups use
+// wg / (256 * ceil(wg / 256)) of the chip (300 tiles: 59 %; measured 73 vs 97-100 TFLOP/s with 3-4 slices, and one full
+// round of 256 is as fast as two, tools/zsweep.sh).  The factor maximises that fill, with a small preference for fewer
+// slabs (less reduce traffic).
 inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
 {
     int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
@@ -1504,20 +1502,12 @@ inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
 #endif
     if (nch < 8 || tiles >= 1024) return 1;
     const int zmax = std::min(nch / 2, 16);
-    if (tiles < TEF_HALO_WG_TARGET / 4) {           // stay at or just below two full rounds (80 tiles: 480, not 560)
-        int z = TEF_HALO_WG_TARGET / tiles;
-        return std::max(1, std::min(z, zmax));
-    }
-    auto fill = [](int wg) { return (double)wg / (256.0 * ((wg + 255) / 256)); };
-    if (tiles >= 256 && fill(tiles) >= 0.85) return 1;
     int best = 1;
-    double best_fill = tiles >= 256 ? fill(tiles) : 0.0;
-    for (int z = 2; z <= std::min(zmax, 8); ++z) {
+    double best_score = -1.0;
+    for (int z = 1; z <= zmax; ++z) {
         int wg = tiles * z;
-        if (wg < 400) continue;
-        double f = fill(wg);
-        if (f >= 0.85) return z;
-        if (f > best_fill + 1e-9) { best_fill = f; best = z; }
+        double score = (double)wg / (256.0 * ((wg + 255) / 256)) - 0.02 * z;     // fill of the rounds, fewer slabs preferred
+        if (score > best_score + 1e-9) { best_score = score; best = z; }
     }
     return best;
 }
