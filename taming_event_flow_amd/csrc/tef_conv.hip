@@ -549,6 +549,11 @@ constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
 // the halo columns hold real neighbours and are loaded with the patch, edge tiles are masked.
 // S = 2: the stride-2 encoder heads (forward only): the tile's R x W outputs read a (2R + 1) x (2W + 1) input patch with
 // stride-2 windows (padding 1: only the left / top halo exists, and it is zero).
+#ifdef TEF_HALO_ABL_NOBAR
+#define HALO_SYNC() __builtin_amdgcn_sched_barrier(0)
+#else
+#define HALO_SYNC() __syncthreads()
+#endif
 template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED, bool GEN, int S = 1>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 {
@@ -558,7 +563,16 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
                   PP = S * W + 8, PLANE = PR * PP;
     constexpr int MR = WR / 32;
     static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
-    __shared__ __attribute__((aligned(16))) float As[2][TR][HLDA];
+    // Three A buffers (one per sub-stage of a chunk) when they fit the 64 KiB of static LDS: a sub-stage's data is then
+    // visible one barrier before it is needed, so its first operands are read BEFORE the barrier and no wave waits for
+    // LDS right after it (PF3 loop below).  Otherwise two buffers and the plain store -> barrier -> read sequence.
+#ifndef TEF_HALO_NO_PF3
+    constexpr bool PF3 = (3 * TR * HLDA + 2 * HC * PLANE) * 4 <= 65536;
+#else
+    constexpr bool PF3 = false;
+#endif
+    constexpr int NA = PF3 ? 3 : 2;
+    __shared__ __attribute__((aligned(16))) float As[NA][TR][HLDA];
     __shared__ __attribute__((aligned(16))) float Ps[2][HC][PLANE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -597,16 +611,20 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     // ---- A sub-tile staging: TR rows x 6 float4 ----
     constexpr int AP = (TR * 6 + NT - 1) / NT;
     float4 ra[AP];
-    auto load_a = [&](int chunk, int sub) {
+    auto load_a_to = [&](float4 (&ra)[AP], int chunk, int sub) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             int piece = min(tid + p * NT, TR * 6 - 1);
             int r = piece / 6, q4 = piece - r * 6;
             int rc = min(row0 + r, g.rows - 1);
+#ifdef TEF_HALO_ABL_NOLOAD
+            ra[p] = make_float4((float)rc, (float)chunk, (float)sub, (float)q4);
+#else
             ra[p] = *reinterpret_cast<const float4 *>(g.A + (size_t)rc * g.lda + (size_t)chunk * HK + sub * HS + q4 * 4);
+#endif
         }
     };
-    auto store_a = [&](int buf) {
+    auto store_a_from = [&](const float4 (&ra)[AP], int buf) {
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             int piece = tid + p * NT;
@@ -616,6 +634,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             }
         }
     };
+    auto load_a = [&](int chunk, int sub) { load_a_to(ra, chunk, sub); };
+    auto store_a = [&](int buf) { store_a_from(ra, buf); };
 
     // ---- patch staging: 8 channels x PR rows x S W / 4 float4 ----
     constexpr int Q = S * W / 4, PIECES = HC * PR * Q, PPT = (PIECES + NT - 1) / NT;
@@ -665,7 +685,11 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             // pofs = (image of the tile) * HWi + offset inside the plane: move the image part to the channel stride
             int sub = IPT > 1 ? pofs[p] / HWi : 0;
             size_t o = ok ? ((size_t)(img + sub) * cs + clc) * HWi + (pofs[p] - sub * HWi) : 0;
+#ifdef TEF_HALO_ABL_NOLOAD
+            rp[p] = make_float4((float)o, 1.f, 2.f, 3.f);
+#else
             rp[p] = *reinterpret_cast<const float4 *>(src + o);
+#endif
             if (GATED) {
                 rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + ((ok && second) ? o : 0));
                 if (ok && second) pmask |= 1u << (8 + p);
@@ -718,62 +742,122 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     const int pl = wc * 32 + (lane & 31);
     const int prow_l = IPT > 1 ? ((pl >> LOGW) / RI) * (RI + 2) + (pl >> LOGW) % RI : (pl >> LOGW);
     const int pbase = (4 * h) * PLANE + S * prow_l * PP + S * (pl & (W - 1)) + 3;
+    // operands of one tap: A rows of the wave's MR blocks, patch values of the lane's pixel (4 channels of this half)
+    struct Ops { float4 fa[MR]; float4 fb; };
+    auto read_ops = [&](int abuf, int pbuf, int tap, Ops &o) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#ifdef TEF_HALO_ABL_NOLDS
+#pragma unroll
+        for (int i = 0; i < MR; ++i) o.fa[i] = make_float4((float)(lane + kx), (float)abuf, (float)i, 1.0f);
+        o.fb = make_float4((float)pbuf, (float)ky, (float)kx, (float)lane);
+#else
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+            o.fa[i] = *reinterpret_cast<const float4 *>(&As[abuf][wr * WR + i * 32 + (lane & 31)][kx * HC + 4 * h]);
+        const float *bp = &Ps[pbuf][0][0] + pbase + ky * PP + kx;
+        o.fb = make_float4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]);
+#endif
+    };
+    auto mfma_ops = [&](const Ops &o) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+#ifdef TEF_HALO_ABL_NOMFMA
+            asm volatile("" :: "v"(o.fa[i].x), "v"(o.fa[i].y), "v"(o.fa[i].z), "v"(o.fa[i].w), "v"(o.fb.x), "v"(o.fb.y), "v"(o.fb.z), "v"(o.fb.w));
+            acc[i][0] += o.fa[i].x * o.fb.x;
+#else
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].x, o.fb.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].y, o.fb.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].z, o.fb.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].w, o.fb.w, acc[i], 0, 0, 0);
+#endif
+        }
+    };
     auto multiply = [&](int abuf, int pbuf, int sub) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            const int tap = sub * 3 + t, ky = tap / 3, kx = tap - ky * 3;
-            float4 fa[MR];
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-                fa[i] = *reinterpret_cast<const float4 *>(&As[abuf][wr * WR + i * 32 + (lane & 31)][t * HC + 4 * h]);
-            const float *bp = &Ps[pbuf][0][0] + pbase + ky * PP + kx;
-            float4 fb = make_float4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]);
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
-            }
+            Ops o;
+            read_ops(abuf, pbuf, sub * 3 + t, o);
+            mfma_ops(o);
         }
     };
 
-    load_p(c_begin);
-    load_a(c_begin, 0);
-    store_p(0);
-    store_a(0);
-    __syncthreads();
-    int abuf = 0, pbuf = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-        const int cn = min(c + 1, c_end - 1);       // the last chunk re-loads itself (stored, never read)
-        // sub-stage 0
-        load_a(c, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(abuf, pbuf, 0);
-        pin();
-        store_a(abuf ^ 1);
-        __syncthreads();
-        abuf ^= 1;
-        // sub-stage 1: also start the next chunk's patch
-        load_a(c, 2);
-        load_p(cn);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(abuf, pbuf, 1);
-        pin();
-        store_a(abuf ^ 1);
-        __syncthreads();
-        abuf ^= 1;
-        // sub-stage 2
-        load_a(cn, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        multiply(abuf, pbuf, 2);
-        pin();
-        pin_p();
-        store_a(abuf ^ 1);
-        store_p(pbuf ^ 1);
-        __syncthreads();
-        abuf ^= 1;
-        pbuf ^= 1;
+    if constexpr (!PF3) {
+        load_p(c_begin);
+        load_a(c_begin, 0);
+        store_p(0);
+        store_a(0);
+        HALO_SYNC();
+        int abuf = 0, pbuf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            const int cn = min(c + 1, c_end - 1);       // the last chunk re-loads itself (stored, never read)
+            // sub-stage 0
+            load_a(c, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(abuf, pbuf, 0);
+            pin();
+            store_a(abuf ^ 1);
+            HALO_SYNC();
+            abuf ^= 1;
+            // sub-stage 1: also start the next chunk's patch
+            load_a(c, 2);
+            load_p(cn);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(abuf, pbuf, 1);
+            pin();
+            store_a(abuf ^ 1);
+            HALO_SYNC();
+            abuf ^= 1;
+            // sub-stage 2
+            load_a(cn, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(abuf, pbuf, 2);
+            pin();
+            pin_p();
+            store_a(abuf ^ 1);
+            store_p(pbuf ^ 1);
+            HALO_SYNC();
+            abuf ^= 1;
+            pbuf ^= 1;
+        }
+    } else {
+        // Sub-stage `sub` of a chunk lives in As[sub].  Iteration (c, sub): store the A data of the sub-stage two ahead
+        // (its buffer was last read one iteration ago), start the global loads of the one three ahead, multiply while
+        // reading the next tap's operands — the last tap reads the first operands of the NEXT sub-stage, stored an
+        // iteration ago and visible since the previous barrier — then barrier.  The patch of chunk c + 1 is loaded in
+        // (c, 0) and stored in (c, 1).
+        float4 ra1[AP];
+        load_p(c_begin);
+        load_a(c_begin, 0);
+        load_a_to(ra1, c_begin, 1);
+        store_p(0);
+        store_a(0);
+        store_a_from(ra1, 1);
+        load_a(c_begin, 2);
+        HALO_SYNC();
+        Ops cur, nxt;
+        read_ops(0, 0, 0, cur);
+        int pbuf = 0;
+        for (int c = c_begin; c < c_end; ++c) {
+            const int cn = min(c + 1, c_end - 1);       // the last chunk re-loads itself (stored, never read)
+#pragma unroll
+            for (int sub = 0; sub < 3; ++sub) {
+                pin();
+                store_a((sub + 2) % 3);
+                if (sub == 1) { pin_p(); store_p(pbuf ^ 1); }
+                load_a(cn, sub);                        // three ahead: sub-stage (c + 1, sub)
+                if (sub == 0) load_p(cn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if (t < 2) read_ops(sub, pbuf, sub * 3 + t + 1, nxt);
+                    else read_ops((sub + 1) % 3, sub == 2 ? pbuf ^ 1 : pbuf, sub == 2 ? 0 : (sub + 1) * 3, nxt);
+                    mfma_ops(cur);
+                    cur = nxt;
+                }
+                HALO_SYNC();
+            }
+            pbuf ^= 1;
+        }
     }
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
