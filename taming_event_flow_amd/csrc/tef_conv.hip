@@ -1040,43 +1040,83 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     const int col = col0 + wc * 32 + (lane & 31);
     const int cil = min(col / 9 - c_lo, WGC - 1), tap = col % 9, ky = tap / 3, kx = tap - ky * 3;
     const int pbase = cil * PLANE + ky * PP + kx + 3 + 4 * h;
-    auto multiply = [&](int buf) {
+    // operands of one 8-pixel k-step: g rows of the wave's MR blocks, the lane's (channel, tap) window of the patch
+    struct Ops { float4 fa[MR]; float4 fb; };
+    auto read_ops = [&](int buf, int kh, Ops &o) {
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            float4 fa[MR];
+        for (int i = 0; i < MR; ++i)
+            o.fa[i] = *reinterpret_cast<const float4 *>(&As[buf][wr * WR + i * 32 + (lane & 31)][kh * 8 + 4 * h]);
+        const float *bp = &Ps[buf][pbase + ((kh * 8) / CW) * PP + (kh * 8) % CW];
+        o.fb = make_float4(bp[0], bp[1], bp[2], bp[3]);
+    };
+    auto mfma_ops = [&](const Ops &o) {
 #pragma unroll
-            for (int i = 0; i < MR; ++i)
-                fa[i] = *reinterpret_cast<const float4 *>(&As[buf][wr * WR + i * 32 + (lane & 31)][kh * 8 + 4 * h]);
-            const float *bp = &Ps[buf][pbase + ((kh * 8) / CW) * PP + (kh * 8) % CW];
-            float4 fb = make_float4(bp[0], bp[1], bp[2], bp[3]);
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb.w, acc[i], 0, 0, 0);
-            }
+        for (int i = 0; i < MR; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].x, o.fb.x, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].y, o.fb.y, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].z, o.fb.z, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].w, o.fb.w, acc[i], 0, 0, 0);
         }
     };
 
+#ifdef TEF_WGRAD_NO_PF
     load_a(s_begin);
     load_p(s_begin);
     store_a(0);
     store_p(0);
     __syncthreads();
     int buf = 0;
-    for (int st = s_begin + 1; st < s_end; ++st) {
-        load_a(st);
-        load_p(st);
+    for (int st = s_begin + 1; st <= s_end; ++st) {
+        if (st < s_end) { load_a(st); load_p(st); }
         __builtin_amdgcn_sched_barrier(0);
-        multiply(buf);
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            Ops o;
+            read_ops(buf, kh, o);
+            mfma_ops(o);
+        }
+        if (st == s_end) break;
         pin();
         store_a(buf ^ 1);
         store_p(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
-    multiply(buf);
+#else
+    // The barrier of a stage sits before its LAST k-step, whose operands are already in registers: the buffer is free
+    // and the next stage (stored at the top of the iteration) visible when the barrier opens, and the first operands of
+    // the next stage are read behind the last k-step's MFMAs instead of right after a barrier.  Stages st + 1 and st + 2
+    // beyond the slice are loaded and stored but never multiplied.
+    load_a(s_begin);
+    load_p(s_begin);
+    store_a(0);
+    store_p(0);
+    load_a(s_begin + 1);
+    load_p(s_begin + 1);
+    __syncthreads();
+    Ops cur, nxt;
+    read_ops(0, 0, cur);
+    int buf = 0;
+    for (int st = s_begin; st < s_end; ++st) {
+        pin();
+        store_a(buf ^ 1);
+        store_p(buf ^ 1);
+        load_a(st + 2);
+        load_p(st + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            read_ops(buf, kh + 1, nxt);
+            mfma_ops(cur);
+            cur = nxt;
+        }
+        __syncthreads();
+        read_ops(buf ^ 1, 0, nxt);
+        mfma_ops(cur);
+        cur = nxt;
+        buf ^= 1;
+    }
+#endif
 
     if (col >= g.valid_cols) return;
 #pragma unroll
