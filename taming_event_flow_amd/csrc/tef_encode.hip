@@ -34,44 +34,57 @@ __global__ __launch_bounds__(kThreads) void encode_kernel(const float *__restric
     int npx = (r1 - r0) * W;
     for (int p = threadIdx.x; p < npx; p += blockDim.x) img[p] = 0.0;
     __syncthreads();
-    for (int ee = threadIdx.x; ee < N + N2; ee += blockDim.x) {
-        const float *bx, *by, *bp, *bt;
-        int e = ee;
-        if (ee < N) {
-            bx = xs + (size_t)b * bs, by = ys + (size_t)b * bs, bp = ps + (size_t)b * bs;
-            bt = ts ? ts + (size_t)b * bs : nullptr;
-        } else {
-            e = ee - N;
-            const float *l = list2 + (size_t)b * N2 * 4;
-            bt = l, by = l + 1, bx = l + 2, bp = l + 3;
+    // four events per thread and step, their loads issued together (a workgroup streams every event of the sample)
+    constexpr int U = 4;
+    const int NT = N + N2;
+    for (int e0 = threadIdx.x; e0 < NT; e0 += U * blockDim.x) {
+        float pv[U], tv[U], yv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int ee = min(e0 + u * (int)blockDim.x, NT - 1);
+            const float *bx, *by, *bp, *bt;
+            int e = ee, es_ = es;
+            if (ee < N) {
+                bx = xs + (size_t)b * bs, by = ys + (size_t)b * bs, bp = ps + (size_t)b * bs;
+                bt = ts ? ts + (size_t)b * bs : bp;
+            } else {
+                e = ee - N;
+                es_ = 4;
+                const float *l = list2 + (size_t)b * N2 * 4;
+                bt = l, by = l + 1, bx = l + 2, bp = l + 3;
+            }
+            pv[u] = bp[(size_t)e * es_];
+            tv[u] = bt[(size_t)e * es_];
+            yv[u] = by[(size_t)e * es_];
+            xv[u] = bx[(size_t)e * es_];
         }
-        int es_ = ee < N ? es : 4;
-        float p = bp[(size_t)e * es_];
-        float v;
-        if (mode == TEF_ENCODE_IMAGE) {
-            v = p;
-        } else if (mode == TEF_ENCODE_CHANNELS) {
-            // mask_pos = {p<0: 0, p>0: 1, else p}; mask_neg = {p>0: 0, p<0: -1, else p}   (encodings.py:72-80)
-            float mpos = p > 0.0f ? 1.0f : (p < 0.0f ? 0.0f : p);
-            float mneg = p < 0.0f ? -1.0f : (p > 0.0f ? 0.0f : p);
-            v = p * (c == 0 ? mpos : mneg);
-        } else {
-            float t = bt[(size_t)e * es_] * (float)(C - 1);            // encodings.py:47
-            v = p * fmaxf(0.0f, 1.0f - fabsf(t - (float)c));          // :52
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e0 + u * (int)blockDim.x >= NT) break;
+            float p = pv[u], v;
+            if (mode == TEF_ENCODE_IMAGE) {
+                v = p;
+            } else if (mode == TEF_ENCODE_CHANNELS) {
+                // mask_pos = {p<0: 0, p>0: 1, else p}; mask_neg = {p>0: 0, p<0: -1, else p}   (encodings.py:72-80)
+                float mpos = p > 0.0f ? 1.0f : (p < 0.0f ? 0.0f : p);
+                float mneg = p < 0.0f ? -1.0f : (p > 0.0f ? 0.0f : p);
+                v = p * (c == 0 ? mpos : mneg);
+            } else {
+                float t = tv[u] * (float)(C - 1);                          // encodings.py:47
+                v = p * fmaxf(0.0f, 1.0f - fabsf(t - (float)c));          // :52
+            }
+            if (v == 0.0f) continue;
+            int iy = (int)yv[u], ix = (int)xv[u];                          // .long() truncation (:24-27)
+            if (iy < 0) iy += H;                                           // python-style negative index
+            if (ix < 0) ix += W;
+            if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
+            atomicAdd(img + (iy - r0) * W + ix, (double)v);
         }
-        if (v == 0.0f) continue;
-        int iy = (int)by[(size_t)e * es_], ix = (int)bx[(size_t)e * es_];   // .long() truncation (:24-27)
-        if (iy < 0) iy += H;                                             // python-style negative index
-        if (ix < 0) ix += W;
-        if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
-        atomicAdd(img + (iy - r0) * W + ix, (double)v);
     }
     __syncthreads();
     float *o = out + ((size_t)b * C + c) * (size_t)(H * W) + (size_t)r0 * W;
     for (int p = threadIdx.x; p < npx; p += blockDim.x) o[p] = (float)img[p];
 }
-
-bool g_attr_done = false;
 
 }  // namespace
 
@@ -90,12 +103,9 @@ static int encode(const float *xs, const float *ys, const float *ts, const float
         if ((N > 0 && !ts) || C < 1) return tef::fail("tef_encode_events: voxel needs ts and bins >= 1"), TEF_ERR_INVALID;
     } else return tef::fail("tef_encode_events: unknown mode"), TEF_ERR_INVALID;
     if ((size_t)W * sizeof(double) > kLdsBudget) return tef::fail("tef_encode_events: row too wide"), TEF_ERR_INVALID;
-    if (!g_attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void *)encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)kLdsBudget);
-        if (e != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e), TEF_ERR_LAUNCH;
-        g_attr_done = true;
-    }
+    static const hipError_t attr = hipFuncSetAttribute((const void *)encode_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    if (attr != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", attr), TEF_ERR_LAUNCH;
     int rows = (int)(kLdsBudget / ((size_t)W * sizeof(double)));
     if (rows > H) rows = H;
     int nbands = (H + rows - 1) / rows;

@@ -1180,18 +1180,14 @@ inline void band_geometry(const Win &w, int *rows_per_band, int *nbands, size_t 
     *lds = (size_t)rows * (w.W + kRowPad) * sizeof(double);
 }
 
-bool g_attr_done = false;
-
+// opt in to > 64 KiB dynamic LDS for the two LDS-resident splat kernels: once per process (thread-safe static init)
 bool ensure_attrs()
 {
-    if (g_attr_done) return true;
-    // opt in to > 64 KiB dynamic LDS for the two LDS-resident splat kernels
-    hipError_t e1 = hipFuncSetAttribute((const void *)splat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kLdsBudget);
-    hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kLdsBudget);
+    static const hipError_t e1 = hipFuncSetAttribute((const void *)splat_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+    static const hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
     if (e1 != hipSuccess || e2 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e1 != hipSuccess ? e1 : e2);
-    g_attr_done = true;
     return true;
 }
 

@@ -3,7 +3,8 @@
 Same classes and methods: ``BaseValidation`` (:12), ``Linear`` (:317), ``Iterative`` (:419) with
 ``update(flow_list, event_list, pol_mask, event_mask)``, ``reset()``, ``num_passes``, ``rsat()``, ``fwl()``,
 ``compute_aee(pred, gt, mask=None)``, ``window_events()``, ``window_flow()``, ``window_iwe()``.  Like the reference
-(:439, :597-599) the module is batch-1 only.  Arithmetic runs in tef_val.hip; torch only concatenates the growing lists.
+(:439, :597-599) the module is batch-1 only.  Arithmetic runs in tef_val.hip; the growing lists the reference rebuilds
+with ``torch.cat`` every pass live in buffers with spare capacity (``_Rows``), same values, each row copied once.
 """
 
 import torch
@@ -17,6 +18,28 @@ except ImportError:      # drop-in mode: this package's directory itself is on s
 def _f32(t, name):
     _lib.require_device_tensor(t, name)
     return t.to(torch.float32).contiguous()
+
+
+class _Rows:
+    """Append-only rows of one of the module's growing lists.  ``append(new)`` returns what the reference's
+    ``torch.cat([old, new], dim=0)`` holds, as a view of a buffer whose capacity doubles when it runs out: the rows
+    already stored are not copied again every pass (the reference's O(P^2) re-concatenation), and in-place kernels
+    keep working on the stored rows."""
+
+    def __init__(self):
+        self.buf, self.n = None, 0
+
+    def append(self, new):
+        m = new.shape[0]
+        if self.buf is None or self.n + m > self.buf.shape[0] or self.buf.shape[1:] != new.shape[1:]:
+            cap = max(2 * (self.n + m), 16)
+            buf = torch.empty((cap,) + tuple(new.shape[1:]), dtype=new.dtype, device=new.device)
+            if self.n:
+                buf[:self.n].copy_(self.buf[:self.n])
+            self.buf = buf
+        self.buf[self.n:self.n + m].copy_(new)
+        self.n += m
+        return self.buf[:self.n]
 
 
 class BaseValidation(torch.nn.Module):
@@ -34,6 +57,7 @@ class BaseValidation(torch.nn.Module):
         self._flow_maps_x = None       # [P, H, W]
         self._flow_maps_y = None
         self._event_mask = None        # [P, H, W]
+        self._rows = {}                # attribute name -> _Rows
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     @property
@@ -67,14 +91,15 @@ class BaseValidation(torch.nn.Module):
         _lib.check(rc, "tef_val_event_image")
         return cnt, tsum
 
-    def forward_prop_flow(self, i, tref, flow_maps_x, flow_maps_y):
+    def forward_prop_flow(self, i, tref, flow_maps_x, flow_maps_y, inplace=False):
         """Forward propagation of flow map i to time tref with bilinear splatting (reference :43-74).
-        flow_maps_*: [P, H, W]; returns ([1,1,H,W], [1,1,H,W]) = (x, y) like the reference."""
+        flow_maps_*: [P, H, W]; returns ([1,1,H,W], [1,1,H,W]) = (x, y) like the reference.  inplace: the result
+        replaces map i (the splat reads the map, a second launch writes it: no hazard)."""
         H, W = self._hw()
         dev = flow_maps_x.device
         scratch = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        ox = torch.empty((H, W), dtype=torch.float32, device=dev)
-        oy = torch.empty((H, W), dtype=torch.float32, device=dev)
+        ox = flow_maps_x[i] if inplace else torch.empty((H, W), dtype=torch.float32, device=dev)
+        oy = flow_maps_y[i] if inplace else torch.empty((H, W), dtype=torch.float32, device=dev)
         rc = _lib.lib().tef_val_forward_prop_flow(flow_maps_x[i].data_ptr(), flow_maps_y[i].data_ptr(), H, W,
                                                   float(tref - i), scratch.data_ptr(), ox.data_ptr(), oy.data_ptr(),
                                                   _lib.stream_ptr())
@@ -94,20 +119,27 @@ class BaseValidation(torch.nn.Module):
         ts = ev[:, 0].clone().contiguous()
         if self.config["loss"]["round_ts"]:
             ts[...] = ts.min() + 0.5
-        loc = ev[:, 1:3].clone().contiguous()
-        pm = _f32(pol_mask[0], "pol_mask").clone()
-        cat = lambda old, new: new if old is None else torch.cat([old, new], dim=0)  # noqa: E731
-        self._event_ts = cat(self._event_ts, ts)
-        self._event_loc = cat(self._event_loc, loc)
-        self._event_pol_mask = cat(self._event_pol_mask, pm)
+        loc = ev[:, 1:3].contiguous()
+        pm = _f32(pol_mask[0], "pol_mask")
+        self._append("_event_ts", ts)
+        self._append("_event_loc", loc)
+        self._append("_event_pol_mask", pm)
         flow = _f32(flow_list[-1], "flow map")            # only the highest-resolution flow (:103)
-        self._flow_maps_x = cat(self._flow_maps_x, flow[0, 0:1].clone())
-        self._flow_maps_y = cat(self._flow_maps_y, flow[0, 1:2].clone())
-        self._event_mask = cat(self._event_mask, _f32(event_mask, "event_mask").reshape(-1, H, W))
+        self._append("_flow_maps_x", flow[0, 0:1])
+        self._append("_flow_maps_y", flow[0, 1:2])
+        self._append("_event_mask", _f32(event_mask, "event_mask").reshape(-1, H, W))
         return ts, loc, pm
+
+    def _append(self, name, new):
+        """self.<name> = cat([self.<name>, new]) (the rows of `new` are copied, never aliased)"""
+        rows = self._rows.get(name)
+        if rows is None or getattr(self, name) is None:
+            rows = self._rows[name] = _Rows()
+        setattr(self, name, rows.append(new))
 
     def reset_base(self):
         self._passes = 0
+        self._rows = {}
         self._event_ts = self._event_loc = self._event_pol_mask = None
         self._flow_maps_x = self._flow_maps_y = self._event_mask = None
 
@@ -185,7 +217,7 @@ class Linear(BaseValidation):
         # flow for every new event from the latest map (:338-342)
         flow = self._event_step(self._flow_maps_x[-1], self._flow_maps_y[-1], loc.clone(), None, None, 0.0,
                                 do_warp=False, want_flow=True)
-        self._event_flow = flow if self._event_flow is None else torch.cat([self._event_flow, flow], dim=0)
+        self._append("_event_flow", flow)
         self._passes += 1
 
     def reset(self):
@@ -239,12 +271,11 @@ class Iterative(BaseValidation):
         ts, loc, pm = self.update_base(flow_list, event_list, pol_mask, event_mask)
         H, W = self._hw()
         fx_new, fy_new = self._flow_maps_x[-1], self._flow_maps_y[-1]
-        cat = lambda old, new: new if old is None else torch.cat([old, new], dim=0)  # noqa: E731
 
         # forward warping of EVERY event seen so far with the newest map, to time passes + 1 (:487-517)
-        self._fw_event_warp_ts = cat(self._fw_event_warp_ts, ts.clone())
-        self._fw_event_loc = cat(self._fw_event_loc, loc.clone())
-        self._fw_event_pol_mask = cat(self._fw_event_pol_mask, pm.clone())
+        self._append("_fw_event_warp_ts", ts)
+        self._append("_fw_event_loc", loc)
+        self._append("_fw_event_pol_mask", pm)
         self._event_step(fx_new, fy_new, self._fw_event_loc, self._fw_event_warp_ts, self._fw_event_pol_mask,
                          self._passes + 1)
 
@@ -252,15 +283,14 @@ class Iterative(BaseValidation):
         bw_loc, bw_ts, bw_pm = loc.clone(), ts.clone(), pm.clone()
         for k in range(self._passes, -1, -1):
             self._event_step(self._flow_maps_x[k], self._flow_maps_y[k], bw_loc, bw_ts, bw_pm, k)
-        self._bw_event_loc = cat(self._bw_event_loc, bw_loc)
-        self._bw_event_pol_mask = cat(self._bw_event_pol_mask, bw_pm)
+        self._append("_bw_event_loc", bw_loc)
+        self._append("_bw_event_pol_mask", bw_pm)
 
         # forward-propagated flow: every earlier map moves one step along itself (:560-576)
-        self._fw_prop_flow_maps_x = cat(self._fw_prop_flow_maps_x, fx_new.unsqueeze(0).clone())
-        self._fw_prop_flow_maps_y = cat(self._fw_prop_flow_maps_y, fy_new.unsqueeze(0).clone())
+        self._append("_fw_prop_flow_maps_x", fx_new.unsqueeze(0))
+        self._append("_fw_prop_flow_maps_y", fy_new.unsqueeze(0))
         for i in range(self._passes):
-            wx, wy = self.forward_prop_flow(i, i + 1, self._fw_prop_flow_maps_x, self._fw_prop_flow_maps_y)
-            self._fw_prop_flow_maps_x[i], self._fw_prop_flow_maps_y[i] = wx[0, 0], wy[0, 0]
+            self.forward_prop_flow(i, i + 1, self._fw_prop_flow_maps_x, self._fw_prop_flow_maps_y, inplace=True)
 
         # accumulated flow by backward warping of the pixel grid (:578-604)
         if self._flow_warping_indices is None:
