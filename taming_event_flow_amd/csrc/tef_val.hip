@@ -117,32 +117,17 @@ __global__ __launch_bounds__(1024) void val_metrics_kernel(const float *__restri
 {
     __shared__ double sh[1024];
     double s1[2] = {0, 0}, s2[2] = {0, 0}, sq[2] = {0, 0}, nz[2] = {0, 0};
-    // one workgroup (the result is two scalars and the caller hands over no scratch): four pixels per thread and step,
-    // all 32 loads of a step issued before the first use
-    constexpr int U = 4;
-    for (int p0 = threadIdx.x; p0 < HW; p0 += U * blockDim.x) {
-        float c0[2][U], c1[2][U], t0[2][U], t1[2][U];
+    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int p = min(p0 + u * (int)blockDim.x, HW - 1);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const float *c = k ? cz : cf, *t = k ? tz : tf;
-                c0[k][u] = c[p]; c1[k][u] = c[HW + p]; t0[k][u] = t[p]; t1[k][u] = t[HW + p];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (p0 + u * (int)blockDim.x >= HW) break;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                float img = c0[k][u] + c1[k][u];
-                s1[k] += img;
-                s2[k] += (double)img * img;
-                float a0 = t0[k][u] / (c0[k][u] + 1e-9f) / passes, a1 = t1[k][u] / (c1[k][u] + 1e-9f) / passes;
-                sq[k] += (double)(a0 * a0) + (double)(a1 * a1);
-                nz[k] += (img > 0.0f) ? 1.0 : 0.0;
-            }
+        for (int k = 0; k < 2; ++k) {
+            const float *c = k ? cz : cf, *t = k ? tz : tf;
+            float c0 = c[p], c1 = c[HW + p];
+            float img = c0 + c1;
+            s1[k] += img;
+            s2[k] += (double)img * img;
+            float a0 = t[p] / (c0 + 1e-9f) / passes, a1 = t[HW + p] / (c1 + 1e-9f) / passes;
+            sq[k] += (double)(a0 * a0) + (double)(a1 * a1);
+            nz[k] += (img > 0.0f) ? 1.0 : 0.0;
         }
     }
     double r[8];
