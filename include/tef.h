@@ -235,9 +235,11 @@ int tef_val_event_step(const float *fx, const float *fy, int H, int W, float *lo
  * weighted by ts when both are given).  utils/iwe.py:63-136 as used by flow_val.py:129-143, :174-187, :189-274 */
 int tef_val_event_image(const float *loc, const float *mask, const float *ts, int N, int H, int W, int round_idx,
                         float *cnt, float *tsum, void *stream);
-/* out2 = (FWL, RSAT) from the warped and un-warped count / timestamp images.  flow_val.py:189-274 */
+/* out2 = (FWL, RSAT) from the warped and un-warped count / timestamp images.  flow_val.py:189-274
+ * scratch: tef_val_metrics_scratch_bytes(H, W) bytes of device memory (per-workgroup fp64 partial sums). */
+size_t tef_val_metrics_scratch_bytes(int H, int W);
 int tef_val_metrics(const float *cnt_fw, const float *ts_fw, const float *cnt_zero, const float *ts_zero, int H, int W,
-                    float passes, float *out2, void *stream);
+                    float passes, float *out2, void *scratch, size_t scratch_bytes, void *stream);
 /* forward propagation of one flow map by dt (scratch3 = 3*H*W floats).  flow_val.py:43-74 */
 int tef_val_forward_prop_flow(const float *fx, const float *fy, int H, int W, float dt, float *scratch3, float *out_x,
                               float *out_y, void *stream);

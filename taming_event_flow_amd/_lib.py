@@ -94,7 +94,9 @@ SIGNATURES = {
                                           ctypes.c_float, ctypes.c_int, _fp, _fp]),
     "tef_val_event_image": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
                                            _fp]),
-    "tef_val_metrics": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp]),
+    "tef_val_metrics_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "tef_val_metrics": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp,
+                                       ctypes.c_size_t, _fp]),
     "tef_val_forward_prop_flow": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp, _fp, _fp,
                                                  _fp]),
     "tef_val_accum_flow": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp, _fp]),

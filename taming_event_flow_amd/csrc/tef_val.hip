@@ -111,13 +111,18 @@ __device__ __forceinline__ double block_sum(double v, double *sh)
 
 // FWL (loss/flow_val.py:189-212) = var(fw count image) / var(zero count image) (unbiased, over all pixels);
 // RSAT (:214-274) = [sum (T/(C+eps)/passes)^2 / #{C_pos+C_neg > 0}]_fw / [same]_zero.     out = (fwl, rsat)
-__global__ __launch_bounds__(1024) void val_metrics_kernel(const float *__restrict__ cf, const float *__restrict__ tf,
-                                                           const float *__restrict__ cz, const float *__restrict__ tz,
-                                                           int HW, float passes, float *__restrict__ out)
+// Two launches: every workgroup leaves its 8 partial sums (fp64) in `part`, one workgroup adds them in block order.
+constexpr int kMetricThreads = 256, kMetricBlocksMax = 256;
+
+__global__ __launch_bounds__(kMetricThreads) void val_metrics_partial_kernel(const float *__restrict__ cf,
+                                                                             const float *__restrict__ tf,
+                                                                             const float *__restrict__ cz,
+                                                                             const float *__restrict__ tz, int HW,
+                                                                             float passes, double *__restrict__ part)
 {
-    __shared__ double sh[1024];
+    __shared__ double sh[kMetricThreads];
     double s1[2] = {0, 0}, s2[2] = {0, 0}, sq[2] = {0, 0}, nz[2] = {0, 0};
-    for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const float *c = k ? cz : cf, *t = k ? tz : tf;
@@ -130,19 +135,26 @@ __global__ __launch_bounds__(1024) void val_metrics_kernel(const float *__restri
             nz[k] += (img > 0.0f) ? 1.0 : 0.0;
         }
     }
-    double r[8];
     for (int k = 0; k < 2; ++k) {
-        r[k] = block_sum(s1[k], sh);
-        r[2 + k] = block_sum(s2[k], sh);
-        r[4 + k] = block_sum(sq[k], sh);
-        r[6 + k] = block_sum(nz[k], sh);
+        double r0 = block_sum(s1[k], sh), r1 = block_sum(s2[k], sh), r2 = block_sum(sq[k], sh), r3 = block_sum(nz[k], sh);
+        if (threadIdx.x == 0) {
+            double *o = part + (size_t)blockIdx.x * 8;
+            o[k] = r0; o[2 + k] = r1; o[4 + k] = r2; o[6 + k] = r3;
+        }
     }
-    if (threadIdx.x == 0) {
-        double n = (double)HW;
-        double var_f = (r[2] - r[0] * r[0] / n) / (n - 1.0), var_z = (r[3] - r[1] * r[1] / n) / (n - 1.0);
-        out[0] = (float)(var_f / var_z);
-        out[1] = (float)((r[4] / r[6]) / (r[5] / r[7]));
-    }
+}
+
+__global__ __launch_bounds__(64) void val_metrics_final_kernel(const double *__restrict__ part, int nblocks, int HW,
+                                                                float *__restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        for (int q = 0; q < 8; ++q) r[q] += part[(size_t)b * 8 + q];
+    double n = (double)HW;
+    double var_f = (r[2] - r[0] * r[0] / n) / (n - 1.0), var_z = (r[3] - r[1] * r[1] / n) / (n - 1.0);
+    out[0] = (float)(var_f / var_z);
+    out[1] = (float)((r[4] / r[6]) / (r[5] / r[7]));
 }
 
 // Forward propagation of a flow map (loss/flow_val.py:43-74): every pixel carries its flow vector to
@@ -342,14 +354,31 @@ int tef_val_event_image(const float *loc, const float *mask, const float *ts, in
     return tef::check_launch("val_splat_kernel");
 }
 
-int tef_val_metrics(const float *cnt_fw, const float *ts_fw, const float *cnt_zero, const float *ts_zero, int H, int W,
-                    float passes, float *out2, void *stream)
+static int metric_blocks(int HW)
 {
-    if (!cnt_fw || !ts_fw || !cnt_zero || !ts_zero || !out2 || H * W < 2)
+    int nb = (HW + kMetricThreads * 4 - 1) / (kMetricThreads * 4);
+    return nb < 1 ? 1 : (nb > kMetricBlocksMax ? kMetricBlocksMax : nb);
+}
+
+size_t tef_val_metrics_scratch_bytes(int H, int W)
+{
+    if (H < 1 || W < 1) return 0;
+    return (size_t)metric_blocks(H * W) * 8 * sizeof(double);
+}
+
+int tef_val_metrics(const float *cnt_fw, const float *ts_fw, const float *cnt_zero, const float *ts_zero, int H, int W,
+                    float passes, float *out2, void *scratch, size_t scratch_bytes, void *stream)
+{
+    if (!cnt_fw || !ts_fw || !cnt_zero || !ts_zero || !out2 || !scratch || H * W < 2)
         return tef::fail("tef_val_metrics: bad arguments"), TEF_ERR_INVALID;
-    hipLaunchKernelGGL(val_metrics_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cnt_fw, ts_fw, cnt_zero, ts_zero,
-                       H * W, passes, out2);
-    return tef::check_launch("val_metrics_kernel");
+    if (scratch_bytes < tef_val_metrics_scratch_bytes(H, W)) return tef::fail("tef_val_metrics: scratch too small"), TEF_ERR_WORKSPACE;
+    const int nb = metric_blocks(H * W);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(val_metrics_partial_kernel, dim3(nb), dim3(kMetricThreads), 0, st, cnt_fw, ts_fw, cnt_zero, ts_zero,
+                       H * W, passes, (double *)scratch);
+    if (int rc = tef::check_launch("val_metrics_partial_kernel")) return rc;
+    hipLaunchKernelGGL(val_metrics_final_kernel, dim3(1), dim3(64), 0, st, (const double *)scratch, nb, H * W, out2);
+    return tef::check_launch("val_metrics_final_kernel");
 }
 
 int tef_val_forward_prop_flow(const float *fx, const float *fy, int H, int W, float dt, float *scratch3, float *out_x,

@@ -167,8 +167,10 @@ class BaseValidation(torch.nn.Module):
         cf, tf = self._event_image(fw_loc, fw_mask, ts, True)
         cz, tz = self._event_image(zero_loc, zero_mask, ts, True)
         out = torch.empty((2,), dtype=torch.float32, device=fw_loc.device)
+        nbytes = _lib.lib().tef_val_metrics_scratch_bytes(H, W)
+        scratch = torch.empty((nbytes,), dtype=torch.uint8, device=fw_loc.device)
         rc = _lib.lib().tef_val_metrics(cf.data_ptr(), tf.data_ptr(), cz.data_ptr(), tz.data_ptr(), H, W,
-                                        float(self._passes), out.data_ptr(), _lib.stream_ptr())
+                                        float(self._passes), out.data_ptr(), scratch.data_ptr(), nbytes, _lib.stream_ptr())
         _lib.check(rc, "tef_val_metrics")
         return out
 
