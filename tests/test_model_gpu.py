@@ -241,8 +241,9 @@ def test_conv_ragged_geometries(dev, B, C0, C1, N, H, W, k, stride, act, gated):
 
 
 def test_conv_randomised_sweep(dev):
-    """150 random convolution geometries (tools/fuzz_conv.py) against torch's CPU fp32 convolution, forward and every
-    gradient; the long form of this sweep ran 2500 cases, worst 5.7e-5 (single-output-channel weight gradients)."""
+    """150 random convolution geometries (tools/fuzz_conv.py) against torch's CPU convolution in float64, forward and
+    every gradient; the long form of this sweep ran 3000 cases (seed 2026), worst 4.4e-5, plus one single-channel bias
+    gradient (a sum of 60 cancelling terms) at 2.3e-4 where torch's own fp32 result is 1.3e-4 from float64."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location(

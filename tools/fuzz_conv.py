@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the implicit-GEMM convolution (forward, input / gate / weight / bias gradients) against
-torch's CPU fp32 convolution: random channel counts, ragged sizes, strides, 1x1 / 3x3, concat, gating, activations.
+torch's CPU convolution in float64: random channel counts, ragged sizes, strides, 1x1 / 3x3, concat, gating,
+activations.  A case over the 1e-4 bar is re-run through torch's CPU fp32 convolution and only counted when the error is
+more than 4x what fp32 itself leaves on that tensor (cancelling sums, e.g. the bias gradient of a single output channel).
 
     python tools/fuzz_conv.py [--cases 300] [--seed 0]
 """
@@ -77,9 +79,30 @@ def one_case(sm, dev, rng, g):
     y = sm.conv2d(sm.PackedWeights(), dx0, dw, db, stride=stride, act=act, x1=dx1, gate1=dg)
     e = rel_err(y.detach().cpu().numpy(), y_ref.detach().numpy())
     grads = torch.autograd.grad(y, ds, dout.to(dev))
-    for got, want in zip(grads, g_ref):
+    names = ["x0"] + (["x1"] if x1 is not None else []) + (["gate"] if gate is not None else []) + ["w", "b"]
+    per = {"y": e}
+    for name, got, want in zip(names, grads, g_ref):
         if float(want.abs().max()) > 0:
-            e = max(e, rel_err(got.cpu().numpy(), want.numpy()))
+            per["d" + name] = rel_err(got.cpu().numpy(), want.numpy())
+            e = max(e, per["d" + name])
+    if e > 1e-4:        # how far is torch's own CPU fp32 convolution from the float64 result on this case?
+        fs = [t.clone().requires_grad_() for t in leaves]
+        it = iter(fs)
+        f0 = next(it)
+        f1 = next(it) if x1 is not None else None
+        fg = next(it) if gate is not None else None
+        fw, fb = next(it), next(it)
+        fin = f0 if f1 is None else torch.cat([f0, f1 * fg if fg is not None else f1], dim=1)
+        fy = torch.nn.functional.conv2d(fin, fw, fb, stride=stride, padding=k // 2)
+        if act is not None:
+            fy = getattr(torch, act)(fy)
+        fgr = torch.autograd.grad(fy, fs, dout)
+        ref32 = {"d" + n: rel_err(a.numpy(), b.numpy()) for n, a, b in zip(names, fgr, g_ref) if float(b.abs().max()) > 0}
+        desc = dict(desc, per_tensor={k_: float("%.2e" % v) for k_, v in per.items()},
+                    torch_cpu_fp32={k_: float("%.2e" % v) for k_, v in ref32.items()})
+        # a gradient that is a sum of cancelling terms (a bias gradient over a few pixels) is only defined to fp32
+        # rounding of its terms: count the case only where this implementation is clearly worse than torch's own fp32
+        e = max([v for k_, v in per.items() if v > 4.0 * ref32.get(k_, 0.0)], default=0.0)
     return e, desc
 
 
