@@ -746,6 +746,21 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
 // adjoint picks up (I + dt * J^T) per step, and every step leaves dt * adjoint as the gradient of the
 // sampled flow vector.  cy/cx[(ib*P + k)*M + sl] = d/d f_y, d/d f_x of this event's sample of map k.
 // =============================================================================================
+// Streaming accesses of K6 (trajectory planes in, per-map vectors out) carry the non-temporal hint so that they do not
+// push the (A, R) images and flow maps — the gathered, re-used data — out of the XCD's L2.
+#ifndef TEF_NO_NT
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 NT_LD2(const float2 *p)
+{
+    f32x2_v v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_v *>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void NT_ST(float *p, float v) { __builtin_nontemporal_store(v, p); }
+#else
+__device__ __forceinline__ float2 NT_LD2(const float2 *p) { return *p; }
+__device__ __forceinline__ void NT_ST(float *p, float v) { *p = v; }
+#endif
+
 #ifndef TEF_CHAIN_WAVES
 #define TEF_CHAIN_WAVES 1
 #endif
@@ -772,7 +787,7 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     // exactly those (pass, map) pairs, so only they need a value
     const int reach = P / w.mode_div;
     if (bits == 0u) {
-        for (int k = max(0, t - reach + 1); k < min(P, t + reach); ++k) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
+        for (int k = max(0, t - reach + 1); k < min(P, t + reach); ++k) { NT_ST(&coy[(size_t)k * M], 0.0f); NT_ST(&cox[(size_t)k * M], 0.0f); }
         return;
     }
     int kb = (int)((mv >> 8) & 0xffu) - 1, kf = (int)((mv >> 16) & 0xffu);
@@ -799,14 +814,14 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = P .. t+1
         int ks = min(min(P, kf - 1), k_top);
         for (int k = min(P, t + reach); k > ks; --k)
-            if (k - 1 > t) { coy[(size_t)(k - 1) * M] = 0.0f; cox[(size_t)(k - 1) * M] = 0.0f; }
+            if (k - 1 > t) { NT_ST(&coy[(size_t)(k - 1) * M], 0.0f); NT_ST(&cox[(size_t)(k - 1) * M], 0.0f); }
         float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
-        if (ks > t) cur = tr[(size_t)ks * w.Mt];
-        if (ks - 1 > t) nxt = tr[(size_t)(ks - 1) * w.Mt];
+        if (ks > t) cur = NT_LD2(&tr[(size_t)ks * w.Mt]);
+        if (ks - 1 > t) nxt = NT_LD2(&tr[(size_t)(ks - 1) * w.Mt]);
         for (int k = ks; k > t; --k) {
             // every load of the step is unconditional (clamped plane / map, result masked): trajectory prefetch, the
             // two flow rows and the two image rows are in flight together
-            float2 nn = tr[(size_t)max(k - 2, t + 1) * w.Mt];
+            float2 nn = NT_LD2(&tr[(size_t)max(k - 2, t + 1) * w.Mt]);
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
 #ifndef TEF_ABL_NOFLOW
             {
@@ -822,8 +837,8 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
                 c0y += c * ay;
                 c0x += c * ax;
             } else {
-                coy[(size_t)(k - 1) * M] = ay;
-                cox[(size_t)(k - 1) * M] = ax;
+                NT_ST(&coy[(size_t)(k - 1) * M], ay);
+                NT_ST(&cox[(size_t)(k - 1) * M], ax);
                 float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
                 ay = ny;
                 ax = nx;
@@ -837,12 +852,12 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = 0 .. t
         int ks = max(max(0, kb + 1), k_bot);
         for (int k = max(0, t - reach + 1); k < ks; ++k)
-            if (k < t) { coy[(size_t)k * M] = 0.0f; cox[(size_t)k * M] = 0.0f; }
+            if (k < t) { NT_ST(&coy[(size_t)k * M], 0.0f); NT_ST(&cox[(size_t)k * M], 0.0f); }
         float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
-        if (ks <= t) cur = tr[(size_t)ks * w.Mt];
-        if (ks + 1 <= t) nxt = tr[(size_t)(ks + 1) * w.Mt];
+        if (ks <= t) cur = NT_LD2(&tr[(size_t)ks * w.Mt]);
+        if (ks + 1 <= t) nxt = NT_LD2(&tr[(size_t)(ks + 1) * w.Mt]);
         for (int k = ks; k <= t; ++k) {
-            float2 nn = tr[(size_t)min(k + 2, t) * w.Mt];
+            float2 nn = NT_LD2(&tr[(size_t)min(k + 2, t) * w.Mt]);
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
 #ifndef TEF_ABL_NOFLOW
             {
@@ -858,8 +873,8 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
                 c0y += c * ay;
                 c0x += c * ax;
             } else {
-                coy[(size_t)k * M] = -ay;
-                cox[(size_t)k * M] = -ax;
+                NT_ST(&coy[(size_t)k * M], -ay);
+                NT_ST(&cox[(size_t)k * M], -ax);
                 float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
                 ay = ny;
                 ax = nx;
@@ -868,8 +883,8 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
             nxt = nn;
         }
     }
-    coy[(size_t)t * M] = c0y;
-    cox[(size_t)t * M] = c0x;
+    NT_ST(&coy[(size_t)t * M], c0y);
+    NT_ST(&cox[(size_t)t * M], c0x);
 }
 
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
