@@ -3,7 +3,7 @@
 window length, heads, temporal scales, modes, ragged / empty passes, detached lists, float coordinates, flow kinds,
 smoothing weights, round_ts.  Prints every case whose error exceeds the 1e-4 bar and the worst case seen.
 
-    python tools/fuzz_loss.py [--cases 200] [--seed 0]
+    python tests/fuzz_loss.py [--cases 200] [--seed 0]
 """
 import argparse
 import os
@@ -15,7 +15,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))      # conftest / test_loss_gpu helpers when run as a script
 
 
 def sweep(cases, seed, verbose=True):

@@ -181,13 +181,13 @@ def test_eval_resolution_and_long_window(dev):
 
 
 def test_randomised_sweep(dev):
-    """120 random windows (tools/fuzz_loss.py: resolutions, scales, modes, ragged / empty passes, float coordinates,
+    """120 random windows (tests/fuzz_loss.py: resolutions, scales, modes, ragged / empty passes, float coordinates,
     smoothing terms, row-banded frames) against the oracle; the long form of this sweep ran 4000 cases clean."""
     import importlib.util
     import os
 
     spec = importlib.util.spec_from_file_location(
-        "fuzz_loss", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_loss.py"))
+        "fuzz_loss", os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz_loss.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     bad, worst = fuzz.sweep(120, seed=2024, verbose=False)
