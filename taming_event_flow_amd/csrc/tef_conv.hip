@@ -900,10 +900,15 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 // =====================================================================================================================
 constexpr int WGC = 16;          // input channels a 128-column tile can touch
 
-template <int NT, int TR, int WR, int LOGW, bool GATED>
+// S = 2: the stride-2 encoder heads.  W is the OUTPUT width; the stage's RB x CW output pixels read a (2 RB + 1) x
+// (2 CW + 1) input patch (padding 1: top row and left column are the halo, nothing is needed on the right), and a
+// lane's window steps two input pixels per output pixel.
+template <int NT, int TR, int WR, int LOGW, bool GATED, int S = 1>
 __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
 {
-    constexpr int W = 1 << LOGW, CW = W < 32 ? W : 32, RB = 32 / CW, PR = RB + 2, PP = CW + 8, PLANE = PR * PP + 1;
+    static_assert(S == 1 || !GATED, "the stride-2 heads have one ungated source");
+    constexpr int W = 1 << LOGW, CW = W < 32 ? W : 32, RB = 32 / CW, PR = S == 1 ? RB + 2 : 2 * RB + 1,
+                  PP = S * CW + 8, PLANE = PR * PP + 1;
     constexpr int MR = WR / 32;
     static_assert((TR / WR) * 4 == NT / 64, "one wave per WR x 32 sub-tile");
     __shared__ __attribute__((aligned(16))) float As[2][TR][LDK];
@@ -912,7 +917,8 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
-    const int H = g.G.SH, HWi = H * W;
+    const int H = g.G.SH, WI = S * W, HWi = H * WI;      // input image; HWo: pixels per output image (= HWi at stride 1)
+    const int HWo = S == 1 ? HWi : g.G.OH * W;
     const int Ct = g.G.C0 + g.G.C1;
     const int c_lo = col0 / 9;
     const int nst = g.K / 32;                                  // pixel stages in total (g.K = padded pixel count)
@@ -926,13 +932,13 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     auto load_a = [&](int st) {
         amask = 0;
         const int m0 = st * 32;
-        const int img = m0 / HWi, po = m0 - img * HWi;
+        const int img = m0 / HWo, po = m0 - img * HWo;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             int piece = tid + p * NT;
             int r = piece >> 3, q4 = piece & 7;
             bool ok = (TR * 8 % NT == 0 || piece < TR * 8) && (row0 + r) < g.rows && m0 < g.G.npix;
-            size_t o = ok ? ((size_t)img * g.rows + row0 + r) * HWi + po + q4 * 4 : 0;
+            size_t o = ok ? ((size_t)img * g.rows + row0 + r) * HWo + po + q4 * 4 : 0;
             ra[p] = *reinterpret_cast<const float4 *>(g.A + o);
             if (ok) amask |= 1u << p;
         }
@@ -949,8 +955,9 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     };
 
     // ---- patch staging: 16 channels x PR rows x (CW / 4 float4 + 2 halo scalars) ----
-    constexpr int Q = CW / 4, PIECES = WGC * PR * Q, PPT = (PIECES + NT - 1) / NT;
-    constexpr int HPIECES = WGC * PR * 2;
+    constexpr int Q = S * CW / 4, PIECES = WGC * PR * Q, PPT = (PIECES + NT - 1) / NT;
+    constexpr int HSIDES = S == 1 ? 2 : 1;                 // halo columns per patch row
+    constexpr int HPIECES = WGC * PR * HSIDES;
     static_assert(HPIECES <= NT, "one halo element per thread");
     float4 rp[PPT], rq[PPT];
     float rh = 0.0f, rhq = 1.0f;
@@ -958,8 +965,8 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     auto load_p = [&](int st) {
         pmask = 0;
         const int m0 = st * 32;
-        const int img = m0 / HWi, po = m0 - img * HWi;
-        const int y0 = po >> LOGW, x0 = po & (W - 1);
+        const int img = m0 / HWo, po = m0 - img * HWo;
+        const int y0 = S * (po >> LOGW), x0 = S * (po & (W - 1));     // first input row / column of the stage's windows (+ halo)
         const bool live = m0 < g.G.npix;
 #pragma unroll
         for (int p = 0; p < PPT; ++p) {
@@ -972,7 +979,7 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
             bool second = ok && ci >= g.G.C0;
             const float *src = second ? g.G.src1 : g.G.src0;
             int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
-            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * W + x0 + q4 * 4 : 0;
+            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * WI + x0 + q4 * 4 : 0;
             rp[p] = *reinterpret_cast<const float4 *>(src + o);
             if (GATED) {
                 rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + (second ? o : 0));
@@ -982,13 +989,13 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
         }
         {   // halo columns x0 - 1 and x0 + CW (inside the row only when the row is wider than the stage)
             int pc = tid < HPIECES ? tid : 0;
-            int cl = pc / (PR * 2), rem = pc - cl * (PR * 2), prow = rem >> 1, side = rem & 1;
+            int cl = pc / (PR * HSIDES), rem = pc - cl * (PR * HSIDES), prow = rem / HSIDES, side = rem - prow * HSIDES;
             int ci = c_lo + cl, y = y0 - 1 + prow, x = side ? x0 + CW : x0 - 1;
-            bool ok = tid < HPIECES && live && ci < Ct && y >= 0 && y < H && x >= 0 && x < W;
+            bool ok = tid < HPIECES && live && ci < Ct && y >= 0 && y < H && x >= 0 && x < WI;
             bool second = ok && ci >= g.G.C0;
             const float *src = second ? g.G.src1 : g.G.src0;
             int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
-            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * W + x : 0;
+            size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * WI + x : 0;
             rh = src[o];
             if (GATED) {
                 rhq = g.G.gate1[second ? o : 0];
@@ -1011,7 +1018,7 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
             }
         }
         if (tid < HPIECES) {
-            int cl = tid / (PR * 2), rem = tid - cl * (PR * 2), prow = rem >> 1, side = rem & 1;
+            int cl = tid / (PR * HSIDES), rem = tid - cl * (PR * HSIDES), prow = rem / HSIDES, side = rem - prow * HSIDES;
             float v = rh;
             if (GATED && (pmask & (1u << 17))) v *= rhq;
             if (!(pmask & (1u << 16))) v = 0.0f;
@@ -1039,15 +1046,15 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     // lane's column = (input channel, tap): its window base in the patch (pixel (ry, rx) of the stage adds ry * PP + rx)
     const int col = col0 + wc * 32 + (lane & 31);
     const int cil = min(col / 9 - c_lo, WGC - 1), tap = col % 9, ky = tap / 3, kx = tap - ky * 3;
-    const int pbase = cil * PLANE + ky * PP + kx + 3 + 4 * h;
+    const int pbase = cil * PLANE + ky * PP + kx + 3 + S * 4 * h;
     // operands of one 8-pixel k-step: g rows of the wave's MR blocks, the lane's (channel, tap) window of the patch
     struct Ops { float4 fa[MR]; float4 fb; };
     auto read_ops = [&](int buf, int kh, Ops &o) {
 #pragma unroll
         for (int i = 0; i < MR; ++i)
             o.fa[i] = *reinterpret_cast<const float4 *>(&As[buf][wr * WR + i * 32 + (lane & 31)][kh * 8 + 4 * h]);
-        const float *bp = &Ps[buf][pbase + ((kh * 8) / CW) * PP + (kh * 8) % CW];
-        o.fb = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        const float *bp = &Ps[buf][pbase + S * (((kh * 8) / CW) * PP + (kh * 8) % CW)];
+        o.fb = make_float4(bp[0], bp[S], bp[2 * S], bp[3 * S]);
     };
     auto mfma_ops = [&](const Ops &o) {
 #pragma unroll
@@ -1653,6 +1660,43 @@ int launch_wgrad_halo_w(const GemmArgs &g, int z, hipStream_t st)
     return tef::check_launch("wgrad3x3_halo_kernel");
 }
 
+// stride-2 heads: logw = log2(output width) from halo_s2_logw
+inline int wgrad_s2_logw(const tef_conv_desc *d)
+{
+#ifdef TEF_CONV_NO_WGRAD_S2
+    return 0;
+#else
+    return halo_s2_logw(d);
+#endif
+}
+
+template <int LOGW>
+int launch_wgrad_halo_s2_w(const GemmArgs &g, int z, hipStream_t st)
+{
+    dim3 grid((g.cols + 127) / 128, 1, z);
+    if (g.rows > 64) {
+        grid.y = (g.rows + 127) / 128;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 128, 64, LOGW, false, 2>), grid, dim3(512), 0, st, g);
+    } else if (g.rows > 32) {
+        grid.y = (g.rows + 63) / 64;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 64, 32, LOGW, false, 2>), grid, dim3(512), 0, st, g);
+    } else {
+        grid.y = (g.rows + 31) / 32;
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<256, 32, 32, LOGW, false, 2>), grid, dim3(256), 0, st, g);
+    }
+    return tef::check_launch("wgrad3x3_halo_kernel (stride 2)");
+}
+
+inline int launch_wgrad_halo_s2(const GemmArgs &g, int logw, int z, hipStream_t st)
+{
+    switch (logw) {
+    case 4: return launch_wgrad_halo_s2_w<4>(g, z, st);
+    case 5: return launch_wgrad_halo_s2_w<5>(g, z, st);
+    case 6: return launch_wgrad_halo_s2_w<6>(g, z, st);
+    default: return launch_wgrad_halo_s2_w<7>(g, z, st);
+    }
+}
+
 inline int launch_wgrad_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
 {
     const bool gated = g.G.gate1 != nullptr;
@@ -1899,6 +1943,10 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
             g.cols = q.K; g.valid_cols = q.K;
             g.ksplit = ks / 32;
             if (int rc = launch_wgrad_halo(g, logw, z, st)) return rc;
+        } else if (int logw = wgrad_s2_logw(d)) {
+            g.cols = q.K; g.valid_cols = q.K;
+            g.ksplit = ks / 32;
+            if (int rc = launch_wgrad_halo_s2(g, logw, z, st)) return rc;
         } else
 #endif
         if (int rc = launch_gemm<A_NCHW, B_GATHER_T, EPI_ATOMIC>(g, z, st)) return rc;
