@@ -69,6 +69,7 @@ struct GemmArgs {
     int hwA;              // A_NCHW: pixels per image of g
     int ksplit;           // EPI_ATOMIC / EPI_SLAB: reduction range per blockIdx.z
     int valid_cols;
+    int s2d_ct;           // stride-2 input gradient on the halo kernel: rows = 4 parity classes x s2d_ct channels
 };
 
 __device__ __forceinline__ float apply_act(float v, int act)
@@ -554,9 +555,15 @@ constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
 #else
 #define HALO_SYNC() __syncthreads()
 #endif
-template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED, bool GEN, int S = 1>
+// S2D: input gradient of a STRIDE-2 layer as a stride-1 convolution over the output-gradient grid.  Input pixel
+// (2a + py, 2b + px) only sees g at (a + dy, b + dx), dy, dx in {0, 1}: rows = (parity class (py, px), input channel),
+// weights packed per class with zeros at the taps a class does not use (pack_s2d_kernel), those taps' MFMAs skipped
+// (1 / 2 / 2 / 4 taps instead of 9), results stored depth-to-space.  4x less matrix work than gathering through the
+// transposed stride.
+template <int NT, int TR, int WR, int LOGW, int IPT, int EPI, bool GATED, bool GEN, int S = 1, bool S2D = false>
 __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 {
+    static_assert(!S2D || (S == 1 && !GATED), "the stride-2 input gradient reads one ungated source at stride 1");
     static_assert(!GEN || IPT == 1, "general tiles hold one image");
     static_assert(S == 1 || (!GEN && IPT == 1), "stride-2 tiles are whole output rows of one image");
     constexpr int W = 1 << LOGW, R = 128 >> LOGW, RI = R / IPT, PR = S == 1 ? IPT * (RI + 2) : 2 * R + 1,
@@ -594,6 +601,17 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     }
     const int Ct = g.G.C0 + g.G.C1;
     const int nch = g.lda / HK;
+    unsigned tapmask = 0x1ffu;                            // S2D: taps (ky' * 3 + kx') some class of this row tile uses
+    if (S2D) {
+        tapmask = 0;
+        const int cls0 = row0 / g.s2d_ct, cls1 = (min(row0 + TR, g.rows) - 1) / g.s2d_ct;
+        for (int cls = cls0; cls <= cls1; ++cls) {
+            const unsigned ys = (cls >> 1) ? 6u : 2u, xs = (cls & 1) ? 6u : 2u;      // bit k: window row / column k used
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    if (((ys >> ky) & 1u) && ((xs >> kx) & 1u)) tapmask |= 1u << (ky * 3 + kx);
+        }
+    }
     int c_begin = 0, c_end = nch;
     if (EPI == EPI_SLAB) {
         c_begin = blockIdx.z * g.ksplit;
@@ -775,6 +793,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     auto multiply = [&](int abuf, int pbuf, int sub) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
+            if (S2D && !((tapmask >> (sub * 3 + t)) & 1u)) continue;
             Ops o;
             read_ops(abuf, pbuf, sub * 3 + t, o);
             mfma_ops(o);
@@ -851,7 +870,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
                 for (int t = 0; t < 3; ++t) {
                     if (t < 2) read_ops(sub, pbuf, sub * 3 + t + 1, nxt);
                     else read_ops((sub + 1) % 3, sub == 2 ? pbuf ^ 1 : pbuf, sub == 2 ? 0 : (sub + 1) * 3, nxt);
-                    mfma_ops(cur);
+                    if (!S2D || ((tapmask >> (sub * 3 + t)) & 1u)) mfma_ops(cur);
                     cur = nxt;
                 }
                 HALO_SYNC();
@@ -879,7 +898,11 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             int r = row0 + wr * WR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
             if (r >= g.rows) continue;
             float v = acc[i][e];
-            if (EPI == EPI_FWD) {
+            if (EPI == EPI_FWD && S2D) {        // depth-to-space: class (py, px) of channel ci -> pixel (2a + py, 2b + px)
+                const int wg = GEN ? WI : W, cls = r / g.s2d_ct, ci = r - cls * g.s2d_ct;
+                const int a = px / wg, b = px - a * wg;
+                g.C[(((size_t)img_l * g.s2d_ct + ci) * (2 * g.G.SH) + 2 * a + (cls >> 1)) * (size_t)(2 * wg) + 2 * b + (cls & 1)] = v;
+            } else if (EPI == EPI_FWD) {
                 if (g.bias) v += g.bias[r];
                 v = apply_act(v, g.act);
                 if (r < g.split) g.C[((size_t)img_l * g.split + r) * g.hw + px] = v;
@@ -1173,6 +1196,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     else out2[((size_t)img * (rows - split) + (r - split)) * hw + px] = v;
 }
 
+// split-K epilogue of the stride-2 input gradient (conv3x3_halo_kernel, S2D): slab rows = (parity class, channel), slab
+// columns = pixels (img, a, b) of the hg x wg output-gradient grid; dx[img][ci][2a + py][2b + px] = sum of the slabs.
+// One thread per pixel PAIR of the input row: it adds the px = 0 and px = 1 classes and stores 8 bytes.
+__global__ __launch_bounds__(256) void splitk_reduce_s2d_kernel(const float *__restrict__ slab, int z, int ct, int cols,
+                                                                int hg, int wg, float *__restrict__ dx)
+{
+    const size_t plane = (size_t)4 * ct * cols;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)2 * ct * cols) return;
+    int rr = (int)(idx / cols), c = (int)(idx - (size_t)rr * cols);        // rr = py * ct + ci
+    int py = rr / ct, ci = rr - py * ct;
+    const float *s0 = slab + ((size_t)(2 * py) * ct + ci) * cols + c, *s1 = s0 + (size_t)ct * cols;
+    float v0 = 0.0f, v1 = 0.0f;
+    for (int k = 0; k < z; ++k) { v0 += s0[(size_t)k * plane]; v1 += s1[(size_t)k * plane]; }
+    int img = c / (hg * wg), p = c - img * (hg * wg), a = p / wg, b = p - a * wg;
+    float *o = dx + (((size_t)img * ct + ci) * (2 * hg) + 2 * a + py) * (size_t)(2 * wg) + 2 * b;
+    *reinterpret_cast<float2 *>(o) = make_float2(v0, v1);
+}
+
 // g = dout * act'(out) (out = post-activation: relu' = out > 0, tanh' = 1 - out^2, sigmoid' = out (1 - out)),
 // db[n] += sum over batch and pixels of g.   One block row per channel.
 // dy / out may come as two tensors (channels [0, iosplit) and [iosplit, N): the split outputs of a fused conv).
@@ -1395,6 +1437,26 @@ __global__ __launch_bounds__(256) void pack_halo_kernel(const float *__restrict_
     }
 }
 
+// Stride-2 input gradient on the halo kernel (S2D): w2s [4 Ct][nch2][9][8], row = class (py, px) * Ct + ci, window tap
+// (ky', kx') reads g at (a + ky' - 1, b + kx' - 1).  Row 2a + py of the input meets output row a + dy through kernel row
+// ky = 1 (py = 0, dy = 0), ky = 2 (py = 1, dy = 0) or ky = 0 (py = 1, dy = 1); columns likewise; every other tap is zero.
+__global__ __launch_bounds__(256) void pack_s2d_kernel(const float *__restrict__ w, int rows, int row0, int N, int Ct,
+                                                       int nch2, float *__restrict__ w2s)
+{
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lda2 = nch2 * HK;
+    int n_lo = row0, n_hi = (row0 + rows == N) ? nch2 * HC : row0 + rows;      // the last part also writes the padding
+    int span = (n_hi - n_lo) * 9;
+    if (idx >= (size_t)4 * Ct * span) return;
+    int row = (int)(idx / span), r = (int)(idx - (size_t)row * span);
+    int cls = row / Ct, ci = row - cls * Ct, py = cls >> 1, px = cls & 1;
+    int n = n_lo + r / 9, tap = r - (r / 9) * 9, kyw = tap / 3, kxw = tap - kyw * 3;
+    int ky = py ? (kyw == 2 ? 0 : (kyw == 1 ? 2 : -1)) : (kyw == 1 ? 1 : -1);
+    int kx = px ? (kxw == 2 ? 0 : (kxw == 1 ? 2 : -1)) : (kxw == 1 ? 1 : -1);
+    float v = (n < N && ky >= 0 && kx >= 0) ? w[((size_t)(n - row0) * Ct + ci) * 9 + ky * 3 + kx] : 0.0f;
+    w2s[(size_t)row * lda2 + (size_t)(n / HC) * HK + tap * HC + (n % HC)] = v;
+}
+
 // ConvGRU state update (models/submodules.py:150) and its backward.
 __global__ __launch_bounds__(256) void gru_blend_kernel(const float *__restrict__ h, const float *__restrict__ u,
                                                         const float *__restrict__ o, size_t n, float *__restrict__ out)
@@ -1523,7 +1585,7 @@ inline int halo_gen_logw(const tef_conv_desc *d)
     return best_eff >= 0.6 ? best : 0;
 }
 
-template <int LOGW, int EPI, bool GATED, bool GEN>
+template <int LOGW, int EPI, bool GATED, bool GEN, bool S2D = false>
 int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
     constexpr int IPT = (LOGW == 3 && !GEN) ? 2 : 1;
@@ -1533,10 +1595,10 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
     dim3 grid(tiles, 1, z);
     if (g.rows > 64) {
         grid.y = (g.rows + 127) / 128;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
-    } else if (g.rows > 32) {
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, g);
+    } else if (g.rows > 32 || S2D) {
         grid.y = (g.rows + 63) / 64;
-        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, g);
     } else if constexpr (GEN && LOGW == 3) {     // 8 x 16 rectangles: the 288 halo elements need more than 256 threads
         grid.y = (g.rows + 63) / 64;
         hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, g);
@@ -1563,6 +1625,24 @@ int launch_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
     case 105: return gated ? launch_halo_w<5, EPI, true, true>(g, z, st) : launch_halo_w<5, EPI, false, true>(g, z, st);
     case 106: return gated ? launch_halo_w<6, EPI, true, true>(g, z, st) : launch_halo_w<6, EPI, false, true>(g, z, st);
     default: return gated ? launch_halo_w<7, EPI, true, true>(g, z, st) : launch_halo_w<7, EPI, false, true>(g, z, st);
+    }
+}
+
+// the stride-2 input gradient (S2D) on the same geometries, never gated
+template <int EPI>
+int launch_halo_s2d(const GemmArgs &g, int logw, int z, hipStream_t st)
+{
+    switch (logw) {
+    case 3: return launch_halo_w<3, EPI, false, false, true>(g, z, st);
+    case 4: return launch_halo_w<4, EPI, false, false, true>(g, z, st);
+    case 5: return launch_halo_w<5, EPI, false, false, true>(g, z, st);
+    case 6: return launch_halo_w<6, EPI, false, false, true>(g, z, st);
+    case 7: return launch_halo_w<7, EPI, false, false, true>(g, z, st);
+    case 103: return launch_halo_w<3, EPI, false, true, true>(g, z, st);
+    case 104: return launch_halo_w<4, EPI, false, true, true>(g, z, st);
+    case 105: return launch_halo_w<5, EPI, false, true, true>(g, z, st);
+    case 106: return launch_halo_w<6, EPI, false, true, true>(g, z, st);
+    default: return launch_halo_w<7, EPI, false, true, true>(g, z, st);
     }
 }
 
@@ -1641,6 +1721,21 @@ inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
         if (score > best_score + 1e-9) { best_score = score; best = z; }
     }
     return best;
+}
+
+// Stride-2 3x3 layers whose input gradient runs on the halo kernel (S2D): one source, even input size, at least 16
+// input channels (64 rows), and the output-gradient grid is a halo geometry.  *gd: that grid as a stride-1 layer with
+// N inputs and 4 Ct outputs; returns its halo mode (0: not eligible).
+inline int s2d_mode(const tef_conv_desc *d, tef_conv_desc *gd)
+{
+#ifdef TEF_CONV_NO_S2D
+    return 0;
+#endif
+    if (d->ksize != 3 || d->stride != 2 || d->C1 != 0 || (d->H & 1) || (d->W & 1) || d->C0 < 16) return 0;
+    tef_conv_desc t = *d;
+    t.C0 = d->N; t.C1 = 0; t.N = 4 * d->C0; t.H = d->H / 2; t.W = d->W / 2; t.stride = 1;
+    if (gd) *gd = t;
+    return halo_mode(&t);
 }
 
 template <int LOGW, bool GATED>
@@ -1723,6 +1818,8 @@ ConvLayout conv_layout(const tef_conv_desc *d, const Geo &q)
     int kh1 = ((q.Ct + HC - 1) / HC) * HK, kh2 = ((d->N + HC - 1) / HC) * HK;
     size_t s_fwd = (size_t)std::max(k_splits(d->N, q.M, q.Kp), halo_splits(d, d->N, q.M, kh1 / HK)) * d->N * q.M;
     size_t s_bwd = (size_t)std::max(k_splits(q.Ct, q.Min, q.K2p), halo_splits(d, q.Ct, q.Min, kh2 / HK)) * q.Ct * q.Min;
+    tef_conv_desc gd;
+    if (s2d_mode(d, &gd)) s_bwd = std::max(s_bwd, (size_t)halo_splits(&gd, gd.N, q.M, kh2 / HK) * gd.N * q.M);
     L.slab = take(std::max(s_fwd, s_bwd));
     L.total = o;
     return L;
@@ -1763,7 +1860,7 @@ size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, 
     size_t np_ = (size_t)d->N * q.Kp, n2 = (size_t)q.Ct * q.K2p;
     if (d->ksize == 3) {           // + the halo-kernel layouts
         np_ += (size_t)d->N * ((q.Ct + HC - 1) / HC) * HK;
-        n2 += (size_t)q.Ct * ((d->N + HC - 1) / HC) * HK;
+        n2 += (size_t)(s2d_mode(d, nullptr) ? 4 : 1) * q.Ct * ((d->N + HC - 1) / HC) * HK;      // S2D: four parity classes
     }
     if (wp_floats) *wp_floats = np_;
     if (w2_floats) *w2_floats = n2;
@@ -1789,6 +1886,12 @@ int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, 
         hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, rows,
                            row0, d->N, q.Ct, nch, nch2, wp + (size_t)d->N * q.Kp, w2 + (size_t)q.Ct * q.K2p);
         if (int rc = tef::check_launch("pack_halo_kernel")) return rc;
+        if (s2d_mode(d, nullptr)) {      // the stride-1 input-gradient layout is unused at stride 2: the region holds the S2D rows
+            size_t ns = (size_t)4 * q.Ct * (n_hi - row0) * 9;
+            hipLaunchKernelGGL(pack_s2d_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, rows,
+                               row0, d->N, q.Ct, nch2, w2 + (size_t)q.Ct * q.K2p);
+            if (int rc = tef::check_launch("pack_s2d_kernel")) return rc;
+        }
     }
     return 0;
 }
@@ -1964,6 +2067,28 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         g.C = dx0; g.C2 = dx1; g.split = d->C0; g.bias = nullptr; g.act = TEF_ACT_NONE; g.hw = d->H * d->W;
         tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
 #ifndef TEF_CONV_NO_HALO
+        tef_conv_desc gd;
+        if (int logw = s2d_mode(d, &gd)) {   // stride 2: four parity classes over the output-gradient grid (S2D)
+            Geo gq;
+            if (!make_geo(&gd, &gq)) return TEF_ERR_INVALID;
+            const int nch2 = (N + HC - 1) / HC;
+            GemmArgs s{};
+            s.A = w2 + (size_t)q.Ct * q.K2p; s.lda = nch2 * HK; s.rows = 4 * q.Ct;
+            s.G = forward_gather(&gd, gq, gsrc, nullptr, nullptr);
+            s.cols = q.M; s.K = gq.Kp;
+            s.C = dx0; s.C2 = nullptr; s.split = 4 * q.Ct; s.bias = nullptr; s.act = TEF_ACT_NONE; s.hw = q.Ho * q.Wo;
+            s.s2d_ct = q.Ct;
+            int z = halo_splits(&gd, 4 * q.Ct, q.M, nch2);
+            if (z <= 1) return launch_halo_s2d<EPI_FWD>(s, logw, 1, st);
+            s.C = slab; s.ldc = q.M; s.valid_cols = q.M;
+            s.ksplit = (nch2 + z - 1) / z;
+            z = (nch2 + s.ksplit - 1) / s.ksplit;
+            if (int rc = launch_halo_s2d<EPI_SLAB>(s, logw, z, st)) return rc;
+            size_t n = (size_t)2 * q.Ct * q.M;
+            hipLaunchKernelGGL(splitk_reduce_s2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.M,
+                               q.Ho, q.Wo, dx0);
+            return tef::check_launch("splitk_reduce_s2d_kernel");
+        }
         if (int logw = halo_mode(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;

@@ -195,6 +195,10 @@ def test_conv_against_torch_reference_large(dev):
     (1, 12, 0, 20, 30, 40, 3, 1, "relu", False),    # 8 x 16 halo rectangles (deepest eval level), <= 32 output rows
     (2, 5, 6, 70, 33, 24, 3, 1, "tanh", True),      # 8 x 16 rectangles, ragged bottom edge, concat + gate
     (1, 64, 8, 40, 30, 40, 3, 1, "relu", True),     # 8 x 16 rectangles with the reduction split over slabs
+    (2, 20, 0, 40, 16, 32, 3, 2, "relu", False),    # stride-2 input gradient by parity classes (8 x 16 gradient grid)
+    (1, 64, 0, 24, 24, 48, 3, 2, None, False),      # the same on general 8 x 16 rectangles (12 x 24 gradient grid)
+    (2, 130, 0, 9, 16, 16, 3, 2, "tanh", False),    # class boundaries inside a row tile (130 channels), two 8 x 8 grids per tile
+    (4, 48, 0, 200, 32, 32, 3, 2, "relu", False),   # the same with the reduction split over slabs (25 chunks)
 ])
 def test_conv_ragged_geometries(dev, B, C0, C1, N, H, W, k, stride, act, gated):
     """tef_conv_forward / backward against torch's CPU fp32 convolution on shapes that exercise every staging path."""
