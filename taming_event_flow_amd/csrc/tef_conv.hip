@@ -2035,9 +2035,23 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         g.cols = q.Kp; g.K = q.Mp;
         g.C = dweight; g.C2 = dweight2; g.split = split_rows; g.ldc = q.K; g.valid_cols = q.K;
         int tiles = ((q.Kp + 127) / 128) * ((N + 127) / 128);
+#ifdef TEF_WGRAD_OLD_SPLIT
         int want = std::max(1, 512 / std::max(1, tiles));
         int ks = round_up((q.Mp + want - 1) / want, BK);
         if (ks < 256) ks = std::min(256, q.Mp);
+#else
+        // Slices of the pixel reduction: a launch runs ceil(workgroups / 256) rounds (one workgroup keeps a CU busy), a
+        // round costs its slice's 32-pixel stages plus about three stages of prologue and atomics epilogue.
+        const int stages = q.Mp / BK;
+        int want = 1;
+        double best = 1e30;
+        for (int zc = 1; zc <= 64 && zc * 4 <= std::max(4, stages); ++zc) {
+            int per = (stages + zc - 1) / zc, zz = (stages + per - 1) / per;
+            double cost = (double)((tiles * zz + 255) / 256) * (per + 3.0);
+            if (cost < best - 1e-9) { best = cost; want = zz; }
+        }
+        int ks = round_up((q.Mp + want - 1) / want, BK);
+#endif
         g.ksplit = ks;
         int z = (q.Mp + ks - 1) / ks;
         tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
