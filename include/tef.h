@@ -211,6 +211,23 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
                             const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
                             int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
                             float *dbias2, int split_rows, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Deferred weight gradient (BPTT windows: one long reduction over the passes instead of one short reduction per pass).
+ * tef_conv_backward_keep is tef_conv_backward_split with g = dY * act'(out) written to g_keep ([B][N][Ho][Wo], caller
+ * owned) instead of the workspace whenever the call forms it (an activation, or outputs in two tensors; otherwise g is
+ * dout itself); pass dweight = NULL there and hand the kept g and the layer inputs of up to TEF_CONV_MAX_PARTS calls to
+ * tef_conv_wgrad_parts, which adds sum over parts of g_p (x) gather(x_p) into dweight (/ dweight2 beyond split_rows).
+ * Only layers on the LDS-halo weight-gradient kernels (tef_conv_wgrad_parts_supported). */
+#define TEF_CONV_MAX_PARTS 16
+int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                           const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
+                           int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
+                           float *dbias2, int split_rows, float *g_keep, void *workspace, size_t workspace_bytes,
+                           void *stream);
+int tef_conv_wgrad_parts_supported(const tef_conv_desc *d);
+int tef_conv_wgrad_parts(const tef_conv_desc *d, int nparts, const float *const *g, const float *const *x0,
+                         const float *const *x1, const float *const *gate1, float *dweight, float *dweight2,
+                         int split_rows, void *stream);
 /* ConvGRU state update new_state = prev * (1 - update) + out_inputs * update (submodules.py:150) and its backward
  * (dh = direct path only; the paths through the gates go through tef_conv_backward). n = element count. */
 int tef_gru_blend(const float *h, const float *u, const float *o, size_t n, float *out, void *stream);

@@ -88,6 +88,13 @@ SIGNATURES = {
     "tef_conv_backward_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                                ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp,
                                                ctypes.c_size_t, _fp]),
+    "tef_conv_backward_keep": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
+                                              ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp,
+                                              ctypes.c_size_t, _fp]),
+    "tef_conv_wgrad_parts_supported": (ctypes.c_int, [ctypes.POINTER(ConvDesc)]),
+    "tef_conv_wgrad_parts": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_void_p), _fp, _fp, ctypes.c_int, _fp]),
     "tef_gru_blend": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_size_t, _fp, _fp]),
     "tef_gru_blend_backward": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_val_event_step": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,

@@ -923,11 +923,18 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 // =====================================================================================================================
 constexpr int WGC = 16;          // input channels a 128-column tile can touch
 
+// Deferred weight gradient over several backward calls of one layer (the passes of a BPTT window): part p holds images
+// [p * B, (p + 1) * B) of one long pixel reduction; n == 0: the single set of tensors in GemmArgs.
+struct WgradParts {
+    const float *A[TEF_CONV_MAX_PARTS], *src0[TEF_CONV_MAX_PARTS], *src1[TEF_CONV_MAX_PARTS], *gate1[TEF_CONV_MAX_PARTS];
+    int n, B;
+};
+
 // S = 2: the stride-2 encoder heads.  W is the OUTPUT width; the stage's RB x CW output pixels read a (2 RB + 1) x
 // (2 CW + 1) input patch (padding 1: top row and left column are the halo, nothing is needed on the right), and a
 // lane's window steps two input pixels per output pixel.
 template <int NT, int TR, int WR, int LOGW, bool GATED, int S = 1>
-__global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
+__global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g, WgradParts wp)
 {
     static_assert(S == 1 || !GATED, "the stride-2 heads have one ungated source");
     constexpr int W = 1 << LOGW, CW = W < 32 ? W : 32, RB = 32 / CW, PR = S == 1 ? RB + 2 : 2 * RB + 1,
@@ -955,14 +962,21 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     auto load_a = [&](int st) {
         amask = 0;
         const int m0 = st * 32;
-        const int img = m0 / HWo, po = m0 - img * HWo;
+        int img = m0 / HWo;
+        const int po = m0 - img * HWo;
+        const float *Ab = g.A;
+        if (wp.n) {                                   // the stage's part (uniform): its tensors, image index inside it
+            int part = min(img / wp.B, wp.n - 1);
+            Ab = wp.A[part];
+            img -= part * wp.B;
+        }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
             int piece = tid + p * NT;
             int r = piece >> 3, q4 = piece & 7;
             bool ok = (TR * 8 % NT == 0 || piece < TR * 8) && (row0 + r) < g.rows && m0 < g.G.npix;
             size_t o = ok ? ((size_t)img * g.rows + row0 + r) * HWo + po + q4 * 4 : 0;
-            ra[p] = *reinterpret_cast<const float4 *>(g.A + o);
+            ra[p] = *reinterpret_cast<const float4 *>(Ab + o);
             if (ok) amask |= 1u << p;
         }
     };
@@ -988,7 +1002,14 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
     auto load_p = [&](int st) {
         pmask = 0;
         const int m0 = st * 32;
-        const int img = m0 / HWo, po = m0 - img * HWo;
+        int img = m0 / HWo;
+        const int po = m0 - img * HWo;
+        const float *s0 = g.G.src0, *s1 = g.G.src1, *gt = g.G.gate1;
+        if (wp.n) {
+            int part = min(img / wp.B, wp.n - 1);
+            s0 = wp.src0[part]; s1 = wp.src1[part]; gt = wp.gate1[part];
+            img -= part * wp.B;
+        }
         const int y0 = S * (po >> LOGW), x0 = S * (po & (W - 1));     // first input row / column of the stage's windows (+ halo)
         const bool live = m0 < g.G.npix;
 #pragma unroll
@@ -1000,12 +1021,12 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
             int ci = c_lo + cl, y = y0 - 1 + prow;
             bool ok = has && live && ci < Ct && y >= 0 && y < H;
             bool second = ok && ci >= g.G.C0;
-            const float *src = second ? g.G.src1 : g.G.src0;
+            const float *src = second ? s1 : s0;
             int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
             size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * WI + x0 + q4 * 4 : 0;
             rp[p] = *reinterpret_cast<const float4 *>(src + o);
             if (GATED) {
-                rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + (second ? o : 0));
+                rq[p] = *reinterpret_cast<const float4 *>(gt + (second ? o : 0));
                 if (second) pmask |= 1u << (8 + p);
             }
             if (ok) pmask |= 1u << p;
@@ -1016,12 +1037,12 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g)
             int ci = c_lo + cl, y = y0 - 1 + prow, x = side ? x0 + CW : x0 - 1;
             bool ok = tid < HPIECES && live && ci < Ct && y >= 0 && y < H && x >= 0 && x < WI;
             bool second = ok && ci >= g.G.C0;
-            const float *src = second ? g.G.src1 : g.G.src0;
+            const float *src = second ? s1 : s0;
             int cs = second ? g.G.C1 : g.G.C0, clc = second ? ci - g.G.C0 : ci;
             size_t o = ok ? ((size_t)img * cs + clc) * HWi + y * WI + x : 0;
             rh = src[o];
             if (GATED) {
-                rhq = g.G.gate1[second ? o : 0];
+                rhq = gt[second ? o : 0];
                 if (second) pmask |= 1u << 17;
             }
             if (ok) pmask |= 1u << 16;
@@ -1739,18 +1760,18 @@ inline int s2d_mode(const tef_conv_desc *d, tef_conv_desc *gd)
 }
 
 template <int LOGW, bool GATED>
-int launch_wgrad_halo_w(const GemmArgs &g, int z, hipStream_t st)
+int launch_wgrad_halo_w(const GemmArgs &g, const WgradParts &wp, int z, hipStream_t st)
 {
     dim3 grid((g.cols + 127) / 128, 1, z);
     if (g.rows > 64) {
         grid.y = (g.rows + 127) / 128;
-        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 128, 64, LOGW, GATED>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 128, 64, LOGW, GATED>), grid, dim3(512), 0, st, g, wp);
     } else if (g.rows > 32) {
         grid.y = (g.rows + 63) / 64;
-        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 64, 32, LOGW, GATED>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 64, 32, LOGW, GATED>), grid, dim3(512), 0, st, g, wp);
     } else {
         grid.y = (g.rows + 31) / 32;
-        hipLaunchKernelGGL((wgrad3x3_halo_kernel<256, 32, 32, LOGW, GATED>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<256, 32, 32, LOGW, GATED>), grid, dim3(256), 0, st, g, wp);
     }
     return tef::check_launch("wgrad3x3_halo_kernel");
 }
@@ -1766,41 +1787,41 @@ inline int wgrad_s2_logw(const tef_conv_desc *d)
 }
 
 template <int LOGW>
-int launch_wgrad_halo_s2_w(const GemmArgs &g, int z, hipStream_t st)
+int launch_wgrad_halo_s2_w(const GemmArgs &g, const WgradParts &wp, int z, hipStream_t st)
 {
     dim3 grid((g.cols + 127) / 128, 1, z);
     if (g.rows > 64) {
         grid.y = (g.rows + 127) / 128;
-        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 128, 64, LOGW, false, 2>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 128, 64, LOGW, false, 2>), grid, dim3(512), 0, st, g, wp);
     } else if (g.rows > 32) {
         grid.y = (g.rows + 63) / 64;
-        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 64, 32, LOGW, false, 2>), grid, dim3(512), 0, st, g);
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<512, 64, 32, LOGW, false, 2>), grid, dim3(512), 0, st, g, wp);
     } else {
         grid.y = (g.rows + 31) / 32;
-        hipLaunchKernelGGL((wgrad3x3_halo_kernel<256, 32, 32, LOGW, false, 2>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL((wgrad3x3_halo_kernel<256, 32, 32, LOGW, false, 2>), grid, dim3(256), 0, st, g, wp);
     }
     return tef::check_launch("wgrad3x3_halo_kernel (stride 2)");
 }
 
-inline int launch_wgrad_halo_s2(const GemmArgs &g, int logw, int z, hipStream_t st)
+inline int launch_wgrad_halo_s2(const GemmArgs &g, const WgradParts &wp, int logw, int z, hipStream_t st)
 {
     switch (logw) {
-    case 4: return launch_wgrad_halo_s2_w<4>(g, z, st);
-    case 5: return launch_wgrad_halo_s2_w<5>(g, z, st);
-    case 6: return launch_wgrad_halo_s2_w<6>(g, z, st);
-    default: return launch_wgrad_halo_s2_w<7>(g, z, st);
+    case 4: return launch_wgrad_halo_s2_w<4>(g, wp, z, st);
+    case 5: return launch_wgrad_halo_s2_w<5>(g, wp, z, st);
+    case 6: return launch_wgrad_halo_s2_w<6>(g, wp, z, st);
+    default: return launch_wgrad_halo_s2_w<7>(g, wp, z, st);
     }
 }
 
-inline int launch_wgrad_halo(const GemmArgs &g, int logw, int z, hipStream_t st)
+inline int launch_wgrad_halo(const GemmArgs &g, const WgradParts &wp, int logw, int z, hipStream_t st)
 {
     const bool gated = g.G.gate1 != nullptr;
     switch (logw) {
-    case 3: return gated ? launch_wgrad_halo_w<3, true>(g, z, st) : launch_wgrad_halo_w<3, false>(g, z, st);
-    case 4: return gated ? launch_wgrad_halo_w<4, true>(g, z, st) : launch_wgrad_halo_w<4, false>(g, z, st);
-    case 5: return gated ? launch_wgrad_halo_w<5, true>(g, z, st) : launch_wgrad_halo_w<5, false>(g, z, st);
-    case 6: return gated ? launch_wgrad_halo_w<6, true>(g, z, st) : launch_wgrad_halo_w<6, false>(g, z, st);
-    default: return gated ? launch_wgrad_halo_w<7, true>(g, z, st) : launch_wgrad_halo_w<7, false>(g, z, st);
+    case 3: return gated ? launch_wgrad_halo_w<3, true>(g, wp, z, st) : launch_wgrad_halo_w<3, false>(g, wp, z, st);
+    case 4: return gated ? launch_wgrad_halo_w<4, true>(g, wp, z, st) : launch_wgrad_halo_w<4, false>(g, wp, z, st);
+    case 5: return gated ? launch_wgrad_halo_w<5, true>(g, wp, z, st) : launch_wgrad_halo_w<5, false>(g, wp, z, st);
+    case 6: return gated ? launch_wgrad_halo_w<6, true>(g, wp, z, st) : launch_wgrad_halo_w<6, false>(g, wp, z, st);
+    default: return gated ? launch_wgrad_halo_w<7, true>(g, wp, z, st) : launch_wgrad_halo_w<7, false>(g, wp, z, st);
     }
 }
 
@@ -1833,6 +1854,57 @@ Gather forward_gather(const tef_conv_desc *d, const Geo &q, const float *x0, con
     G.ks = d->ksize; G.pad = d->ksize / 2; G.mul = d->stride; G.div = 1; G.sgn = 1;
     G.K = q.K; G.npix = q.M; G.npix_src = (long)d->B * d->H * d->W;
     return G;
+}
+
+// dW[n][k] += sum_m g[n][m] * x_gather[m][k].  wp.n > 0: one reduction over the images of all parts (the halo kernels only).
+static int conv_wgrad(const tef_conv_desc *d, const Geo &q, const float *gsrc, const float *x0, const float *x1,
+                      const float *gate1, const WgradParts &wp, float *dweight, float *dweight2, int split_rows,
+                      hipStream_t st)
+{
+    const int N = d->N, HW = q.Ho * q.Wo;
+    const int nimg = wp.n ? wp.n : 1;
+    const int Mtot = q.M * nimg, Mp = round_up(Mtot, BK);
+    GemmArgs g{};
+    g.A = gsrc; g.rows = N; g.hwA = HW;
+    g.G = forward_gather(d, q, x0, x1, gate1);
+    g.G.npix = Mtot;
+    g.cols = q.Kp; g.K = Mp;
+    g.C = dweight; g.C2 = dweight2; g.split = split_rows; g.ldc = q.K; g.valid_cols = q.K;
+    int tiles = ((q.Kp + 127) / 128) * ((N + 127) / 128);
+#ifdef TEF_WGRAD_OLD_SPLIT
+    int want = std::max(1, 512 / std::max(1, tiles));
+    int ks = round_up((Mp + want - 1) / want, BK);
+    if (ks < 256) ks = std::min(256, Mp);
+#else
+    // Slices of the pixel reduction: a launch runs ceil(workgroups / 256) rounds (one workgroup keeps a CU busy), a
+    // round costs its slice's 32-pixel stages plus about three stages of prologue and atomics epilogue.
+    const int stages = Mp / BK;
+    int want = 1;
+    double best = 1e30;
+    for (int zc = 1; zc <= 64 && zc * 4 <= std::max(4, stages); ++zc) {
+        int per = (stages + zc - 1) / zc, zz = (stages + per - 1) / per;
+        double cost = (double)((tiles * zz + 255) / 256) * (per + 3.0);
+        if (cost < best - 1e-9) { best = cost; want = zz; }
+    }
+    int ks = round_up((Mp + want - 1) / want, BK);
+#endif
+    g.ksplit = ks;
+    int z = (Mp + ks - 1) / ks;
+    tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
+#ifndef TEF_CONV_NO_WGRAD_HALO
+    if (int logw = halo_logw(d)) {      // reduction in 32-pixel stages; ksplit counts stages
+        g.cols = q.K; g.valid_cols = q.K;
+        g.ksplit = ks / 32;
+        return launch_wgrad_halo(g, wp, logw, z, st);
+    }
+    if (int logw = wgrad_s2_logw(d)) {
+        g.cols = q.K; g.valid_cols = q.K;
+        g.ksplit = ks / 32;
+        return launch_wgrad_halo_s2(g, wp, logw, z, st);
+    }
+#endif
+    if (wp.n) return tef::fail("tef_conv_wgrad_parts: layer is not on the halo weight-gradient kernels"), TEF_ERR_INVALID;
+    return launch_gemm<A_NCHW, B_GATHER_T, EPI_ATOMIC>(g, z, st);
 }
 
 }  // namespace
@@ -1985,6 +2057,49 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
                             int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
                             float *dbias2, int split_rows, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return tef_conv_backward_keep(d, x0, x1, gate1, w2, out, out2, dout, dout2, io_split, dx0, dx1, dweight, dweight2, dbias,
+                                  dbias2, split_rows, nullptr, workspace, workspace_bytes, stream);
+}
+
+int tef_conv_wgrad_parts_supported(const tef_conv_desc *d)
+{
+    Geo q;
+    if (!make_geo(d, &q)) return 0;
+#ifdef TEF_CONV_NO_WGRAD_HALO
+    return 0;
+#else
+    return (halo_logw(d) || wgrad_s2_logw(d)) ? 1 : 0;
+#endif
+}
+
+int tef_conv_wgrad_parts(const tef_conv_desc *d, int nparts, const float *const *g, const float *const *x0,
+                         const float *const *x1, const float *const *gate1, float *dweight, float *dweight2,
+                         int split_rows, void *stream)
+{
+    Geo q;
+    if (!make_geo(d, &q)) return TEF_ERR_INVALID;
+    if (!g || !x0 || !dweight || nparts < 1 || nparts > TEF_CONV_MAX_PARTS || (d->C1 > 0 && !x1))
+        return tef::fail("tef_conv_wgrad_parts: bad arguments"), TEF_ERR_INVALID;
+    if (split_rows < 0 || split_rows > d->N || (split_rows < d->N && !dweight2))
+        return tef::fail("tef_conv_wgrad_parts: rows beyond split_rows need dweight2"), TEF_ERR_INVALID;
+    if ((long)nparts * q.M > 0x7fffffffL - 64) return tef::fail("tef_conv_wgrad_parts: too many pixels"), TEF_ERR_INVALID;
+    WgradParts wp{};
+    wp.n = nparts; wp.B = d->B;
+    const bool gated = gate1 && gate1[0];
+    for (int p = 0; p < nparts; ++p) {
+        if (!g[p] || !x0[p] || (d->C1 > 0 && !x1[p]) || (gated && !gate1[p]))
+            return tef::fail("tef_conv_wgrad_parts: null part"), TEF_ERR_INVALID;
+        wp.A[p] = g[p]; wp.src0[p] = x0[p]; wp.src1[p] = d->C1 > 0 ? x1[p] : nullptr; wp.gate1[p] = gated ? gate1[p] : nullptr;
+    }
+    return conv_wgrad(d, q, wp.A[0], wp.src0[0], wp.src1[0], wp.gate1[0], wp, dweight, dweight2, split_rows, (hipStream_t)stream);
+}
+
+int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                           const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
+                           int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
+                           float *dbias2, int split_rows, float *g_keep, void *workspace, size_t workspace_bytes,
+                           void *stream)
+{
     Geo q;
     if (!make_geo(d, &q)) return TEF_ERR_INVALID;
     if (!x0 || (d->C1 > 0 && !x1) || !dout || !workspace) return tef::fail("tef_conv_backward: null pointer"), TEF_ERR_INVALID;
@@ -2001,7 +2116,7 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
     if (workspace_bytes < L.total) return tef::fail("tef_conv_backward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    float *gbuf = (float *)(ws + L.gbuf), *slab = (float *)(ws + L.slab);
+    float *gbuf = g_keep ? g_keep : (float *)(ws + L.gbuf), *slab = (float *)(ws + L.slab);
     const int N = d->N, HW = q.Ho * q.Wo;
     const float *gsrc = dout;
     if (pointwise_small(d) && io_split == N && split_rows == N) {
@@ -2029,44 +2144,8 @@ int tef_conv_backward_split(const tef_conv_desc *d, const float *x0, const float
         if (d->act != TEF_ACT_NONE || io_split < N) gsrc = gbuf;
     }
     if (dweight) {   // dW[n][k] += sum_m g[n][m] * x_gather[m][k]
-        GemmArgs g{};
-        g.A = gsrc; g.rows = N; g.hwA = HW;
-        g.G = forward_gather(d, q, x0, x1, gate1);
-        g.cols = q.Kp; g.K = q.Mp;
-        g.C = dweight; g.C2 = dweight2; g.split = split_rows; g.ldc = q.K; g.valid_cols = q.K;
-        int tiles = ((q.Kp + 127) / 128) * ((N + 127) / 128);
-#ifdef TEF_WGRAD_OLD_SPLIT
-        int want = std::max(1, 512 / std::max(1, tiles));
-        int ks = round_up((q.Mp + want - 1) / want, BK);
-        if (ks < 256) ks = std::min(256, q.Mp);
-#else
-        // Slices of the pixel reduction: a launch runs ceil(workgroups / 256) rounds (one workgroup keeps a CU busy), a
-        // round costs its slice's 32-pixel stages plus about three stages of prologue and atomics epilogue.
-        const int stages = q.Mp / BK;
-        int want = 1;
-        double best = 1e30;
-        for (int zc = 1; zc <= 64 && zc * 4 <= std::max(4, stages); ++zc) {
-            int per = (stages + zc - 1) / zc, zz = (stages + per - 1) / per;
-            double cost = (double)((tiles * zz + 255) / 256) * (per + 3.0);
-            if (cost < best - 1e-9) { best = cost; want = zz; }
-        }
-        int ks = round_up((q.Mp + want - 1) / want, BK);
-#endif
-        g.ksplit = ks;
-        int z = (q.Mp + ks - 1) / ks;
-        tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
-#ifndef TEF_CONV_NO_WGRAD_HALO
-        if (int logw = halo_logw(d)) {      // reduction in 32-pixel stages; ksplit counts stages
-            g.cols = q.K; g.valid_cols = q.K;
-            g.ksplit = ks / 32;
-            if (int rc = launch_wgrad_halo(g, logw, z, st)) return rc;
-        } else if (int logw = wgrad_s2_logw(d)) {
-            g.cols = q.K; g.valid_cols = q.K;
-            g.ksplit = ks / 32;
-            if (int rc = launch_wgrad_halo_s2(g, logw, z, st)) return rc;
-        } else
-#endif
-        if (int rc = launch_gemm<A_NCHW, B_GATHER_T, EPI_ATOMIC>(g, z, st)) return rc;
+        WgradParts none{};
+        if (int rc = conv_wgrad(d, q, gsrc, x0, x1, gate1, none, dweight, dweight2, split_rows, st)) return rc;
     }
     if (need_dx) {   // dx[ci][m'] = sum_{n,ky,kx} W[n][ci][ky][kx] * g[n][(m' + pad - k) / stride]
         GemmArgs g{};

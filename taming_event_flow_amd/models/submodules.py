@@ -33,6 +33,11 @@ class PackedWeights:
         # training loops that own pre-allocated .grad buffers (train.Trainer's flat bucket) switch this on: the weight /
         # bias gradients are then accumulated by the kernel straight into .grad (no temporary, no autograd add)
         self.direct_grads = False
+        # with direct_grads: weight gradients of the backward calls of one BPTT window are computed together, as one long
+        # pixel reduction per layer (flush_deferred_wgrads) instead of one short, atomics-heavy reduction per pass
+        self.defer_wgrad = False
+        self.pending = []          # (g, x0, x1, gate1) tensors of the queued backward calls
+        self.pending_meta = None   # (desc, weight .grad tensors, rows of the first weight)
 
     def get(self, weights, desc):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (desc.C0 + desc.C1, desc.N, desc.ksize)
@@ -124,7 +129,28 @@ class _ConvFn(torch.autograd.Function):
         direct = (ctx.packer.direct_grads and nw <= 2 and need_w and all(need[7:7 + nw])
                   and all(w.grad is not None and w.grad.is_contiguous() for w in weights)
                   and (not has_bias or all(b.grad is not None and b.grad.is_contiguous() for b in biases)))
-        if direct:      # the kernel adds into the parameters' own .grad buffers
+        packer = ctx.packer
+        if direct and packer.defer_wgrad and lib.tef_conv_wgrad_parts_supported(ctypes.byref(d)):
+            # input / bias gradients now; g = dY * act'(out) is kept and the weight gradient joins the layer's queue
+            dbs = ([b.grad.data_ptr() for b in biases] + [None]) if has_bias else [None, None]
+            g_formed = d.act != _lib.ACT[None] or io_split < d.N
+            g = torch.empty((d.B, d.N) + tuple(dout.shape[2:]), dtype=torch.float32, device=dev) if g_formed else None
+            rc = lib.tef_conv_backward_keep(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
+                                            _ptr(out), _ptr(out2), dout.data_ptr(), _ptr(dout2), io_split, _ptr(dx0),
+                                            _ptr(dxg), None, None, dbs[0], dbs[1],
+                                            ctx.rows[0] if nw == 2 else d.N, _ptr(g), ws.data_ptr(), nbytes,
+                                            _lib.stream_ptr())
+            _lib.check(rc, "tef_conv_backward_keep")
+            meta = (d, [w.grad for w in weights], ctx.rows[0] if nw == 2 else d.N)
+            if packer.pending and (packer.pending_meta[0].B, packer.pending_meta[0].H, packer.pending_meta[0].W) != (d.B, d.H, d.W):
+                flush_deferred_wgrads(packer)
+            packer.pending_meta = meta
+            packer.pending.append((g if g_formed else dout, x0, x1, gate1))
+            _DEFERRED.add(packer)
+            if len(packer.pending) == _MAX_PARTS:
+                flush_deferred_wgrads(packer)
+            dw = db = None
+        elif direct:      # the kernel adds into the parameters' own .grad buffers
             dws = [w.grad.data_ptr() for w in weights] + [None]
             dbs = ([b.grad.data_ptr() for b in biases] + [None]) if has_bias else [None, None]
             rc = lib.tef_conv_backward_split(ctypes.byref(d), x0.data_ptr(), _ptr(x1), _ptr(gate1), ctx.wt.data_ptr(),
@@ -158,6 +184,43 @@ class _ConvFn(torch.autograd.Function):
         if not has_bias:
             gb = [None] * (len(need) - 7 - nw)
         return (None, None, None, None, None, dx0, dx1, dgate) + tuple(gw) + tuple(gb)
+
+
+_MAX_PARTS = 16        # TEF_CONV_MAX_PARTS (include/tef.h)
+_DEFERRED = set()      # packers with queued weight-gradient parts
+
+
+def flush_deferred_wgrads(packer=None):
+    """Run the queued weight gradients (all layers, or one): one tef_conv_wgrad_parts launch per layer over every backward
+    call since the last flush.  Call after loss.backward() and before the gradients are read (all-reduce, clip, step)."""
+    todo = [packer] if packer is not None else list(_DEFERRED)
+    lib = _lib.lib()
+    for pk in todo:
+        parts = pk.pending
+        if not parts:
+            _DEFERRED.discard(pk)
+            continue
+        d, grads, split_rows = pk.pending_meta
+        n = len(parts)
+        arr = lambda col: (ctypes.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for t in col])  # noqa: E731
+        gs, x0s, x1s, gts = (arr([p[i] for p in parts]) for i in range(4))
+        rc = lib.tef_conv_wgrad_parts(ctypes.byref(d), n, gs, x0s, x1s, gts, grads[0].data_ptr(),
+                                      grads[1].data_ptr() if len(grads) > 1 else None, split_rows, _lib.stream_ptr())
+        _lib.check(rc, "tef_conv_wgrad_parts")
+        pk.pending = []
+        _DEFERRED.discard(pk)
+
+
+def enable_deferred_wgrad(module, on=True):
+    """With enable_direct_grads: queue the weight gradients of the convolutions of `module` during backward and compute
+    them per layer in flush_deferred_wgrads() (the caller must call it after every backward)."""
+    n = 0
+    for m in module.modules():
+        for v in vars(m).values():
+            if isinstance(v, PackedWeights):
+                v.defer_wgrad = on
+                n += 1
+    return n
 
 
 def enable_direct_grads(module, on=True):

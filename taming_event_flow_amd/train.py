@@ -7,6 +7,8 @@ HDF5 loader (dataloader/h5.py needs h5py/cv2 and a dataset; out of scope, SURVEY
 """
 
 import numpy as np
+import os
+
 import torch
 
 from . import parallel, synth
@@ -79,6 +81,9 @@ class Trainer:
         self.loss_function = eval(config["loss"]["warping"])(config, device)
         self.bucket = parallel.FlatGradBucket(self.model.parameters())
         submodules.enable_direct_grads(self.model)      # conv kernels add into the bucket's .grad views
+        # weight gradients of a window's passes: one long reduction per layer after backward (opt out: TEF_NO_DEFERRED_WGRAD=1)
+        self.deferred_wgrad = os.environ.get("TEF_NO_DEFERRED_WGRAD", "0") != "1"
+        submodules.enable_deferred_wgrad(self.model, self.deferred_wgrad)
         opt_kwargs = {"lr": config["optimizer"]["lr"]}
         if config["optimizer"].get("capturable"):
             opt_kwargs["capturable"] = True      # optimiser state stays on the device: the window can live in a hipGraph
@@ -147,6 +152,8 @@ class Trainer:
             return False
         loss = self.loss_function()
         loss.backward()
+        if self.deferred_wgrad:
+            submodules.flush_deferred_wgrads()
         self.bucket.all_reduce_sum()                    # DP: gradient of the global batch (sum of shards)
         if cfg["loss"]["clip_grad"] is not None:
             self.last_grad_norm = self.bucket.clip_(cfg["loss"]["clip_grad"])

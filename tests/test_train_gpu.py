@@ -97,3 +97,37 @@ def test_graph_replay_matches_eager():
     assert abs(l2 - losses_e[1]) <= 1e-3 * abs(losses_e[1]), (l2, losses_e)      # state + weights carried over
     assert abs(l3 - losses_e[2]) <= 2e-2 * abs(losses_e[2]), (l3, losses_e)      # fp32 atomics order + Adam amplify
     assert len({l1, l2, l3}) == 3
+
+
+def test_deferred_weight_gradients_match_immediate():
+    """Weight gradients of a BPTT window computed per layer in one long reduction (flush_deferred_wgrads) equal the per-pass
+    accumulation; the two differ only in the order of the fp32 atomics."""
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd.models import submodules as sm
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    dev = torch.device("cuda:0")
+    grads = []
+    for deferred in (False, True):
+        torch.manual_seed(3)
+        net = RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2).to(dev)
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        sm.enable_direct_grads(net)
+        sm.enable_deferred_wgrad(net, deferred)
+        gen = torch.Generator().manual_seed(5)
+        total = 0.0
+        for _ in range(3):                      # three passes with recurrent state, one backward through all of them
+            x = torch.rand(2, 2, 32, 32, generator=gen).to(dev)
+            total = total + sum((f * f).sum() for f in net(x)["flow"])
+        total.backward()
+        if deferred:
+            assert any(pk.pending for pk in sm._DEFERRED)
+            sm.flush_deferred_wgrads()
+            assert not sm._DEFERRED
+        grads.append([p.grad.detach().clone() for p in net.parameters()])
+    for a, b in zip(*grads):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-12)
