@@ -1606,6 +1606,17 @@ inline int halo_gen_logw(const tef_conv_desc *d)
     return best_eff >= 0.6 ? best : 0;
 }
 
+// Row tile of the halo forward / input-gradient kernel: 128 rows, 64 when there are few of them — or few pixels (the
+// 8 x 8 level: 64-row tiles double the workgroups per slice, i.e. half the slabs to write and reduce).
+#ifndef TEF_HALO_TR64_COLS
+#define TEF_HALO_TR64_COLS 0
+#endif
+inline int halo_row_tile(int rows, int cols)
+{
+    if (rows > 64 && cols > TEF_HALO_TR64_COLS) return 128;
+    return rows > 32 ? 64 : 32;
+}
+
 template <int LOGW, int EPI, bool GATED, bool GEN, bool S2D = false>
 int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
@@ -1614,10 +1625,11 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
     if (GEN) tiles = (unsigned)((g.G.SW + (1 << LOGW) - 1) >> LOGW) * ((g.G.SH + (128 >> LOGW) - 1) / (128 >> LOGW)) *
                      (g.G.npix / (g.G.SH * g.G.SW));
     dim3 grid(tiles, 1, z);
-    if (g.rows > 64) {
+    const int tr = halo_row_tile(g.rows, g.cols);
+    if (tr == 128) {
         grid.y = (g.rows + 127) / 128;
         hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, g);
-    } else if (g.rows > 32 || S2D) {
+    } else if (tr == 64 || S2D) {
         grid.y = (g.rows + 63) / 64;
         hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, g);
     } else if constexpr (GEN && LOGW == 3) {     // 8 x 16 rectangles: the 288 halo elements need more than 256 threads
@@ -1719,7 +1731,7 @@ inline int halo_mode(const tef_conv_desc *d)
 // slabs (less reduce traffic).
 inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
 {
-    int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
+    int tr = halo_row_tile(rows, cols);
     int ctiles = (cols + 127) / 128;
     if (int m = halo_mode(d); m > 100) {      // general rectangles: edge tiles are partly empty
         int lw = m - 100;
