@@ -99,7 +99,8 @@ def test_graph_replay_matches_eager():
     assert len({l1, l2, l3}) == 3
 
 
-def test_deferred_weight_gradients_match_immediate():
+@pytest.mark.parametrize("B,R,passes", [(2, 32, 3), (4, 64, 4)])
+def test_deferred_weight_gradients_match_immediate(B, R, passes):
     """Weight gradients of a BPTT window computed per layer in one long reduction (flush_deferred_wgrads) equal the per-pass
     accumulation; the two differ only in the order of the fp32 atomics."""
     import __graft_entry__ as g
@@ -119,8 +120,8 @@ def test_deferred_weight_gradients_match_immediate():
         sm.enable_deferred_wgrad(net, deferred)
         gen = torch.Generator().manual_seed(5)
         total = 0.0
-        for _ in range(3):                      # three passes with recurrent state, one backward through all of them
-            x = torch.rand(2, 2, 32, 32, generator=gen).to(dev)
+        for _ in range(passes):                 # passes with recurrent state, one backward through all of them
+            x = torch.rand(B, 2, R, R, generator=gen).to(dev)
             total = total + sum((f * f).sum() for f in net(x)["flow"])
         total.backward()
         if deferred:
