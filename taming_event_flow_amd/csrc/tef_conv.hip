@@ -1890,12 +1890,17 @@ static int conv_wgrad(const tef_conv_desc *d, const Geo &q, const float *gsrc, c
 #else
     // Slices of the pixel reduction: a launch runs ceil(workgroups / 256) rounds (one workgroup keeps a CU busy), a
     // round costs its slice's 32-pixel stages plus about three stages of prologue and atomics epilogue.
+    // (32-row layers run 256-thread workgroups, one wave per SIMD each: four of them share a CU)
     const int stages = Mp / BK;
+#ifndef TEF_WGRAD_NARROW_SLOTS
+#define TEF_WGRAD_NARROW_SLOTS 1024
+#endif
+    const int slots = N <= 32 ? TEF_WGRAD_NARROW_SLOTS : 256, zcap = N <= 32 ? 256 : 64;
     int want = 1;
     double best = 1e30;
-    for (int zc = 1; zc <= 64 && zc * 4 <= std::max(4, stages); ++zc) {
+    for (int zc = 1; zc <= zcap && zc * 4 <= std::max(4, stages); ++zc) {
         int per = (stages + zc - 1) / zc, zz = (stages + per - 1) / per;
-        double cost = (double)((tiles * zz + 255) / 256) * (per + 3.0);
+        double cost = (double)((tiles * zz + slots - 1) / slots) * (per + 3.0);
         if (cost < best - 1e-9) { best = cost; want = zz; }
     }
     int ks = round_up((Mp + want - 1) / want, BK);
