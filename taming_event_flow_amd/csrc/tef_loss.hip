@@ -655,6 +655,10 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
 //   dl/dw_k = sum_c m_c * K * 2 A_c (tau - A_c) R_c,  K = grad_out * coef / n
 // followed by the derivative of the bilinear hat weights.
 // ---------------------------------------------------------------------------------------------
+// FAST (the backward of the single-scale Iterative loss, where this function is VALU-bound): `delta` is 1 / delta and
+// both divisions become a multiplication by a reciprocal — gradient arithmetic only (1e-4 bar, measured 1e-6); the
+// coordinates and indices, which must match the forward bit for bit, are untouched.
+template <bool FAST = false>
 __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
                                              const float *__restrict__ stats, int ib, int j, float kscale, float tref,
                                              float delta, float2 p, float ts, float mp, float mn)
@@ -662,11 +666,11 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     const int HW = w.H * w.W;
     const int FB = w.F * w.B;
     size_t q = (size_t)j * FB + ib;
-    float kimg = kscale / stats[q * 2 + 1];
+    float kimg = FAST ? kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]) : kscale / stats[q * 2 + 1];
     const float2 *pos = ar + q * 2 * HW;
     const float2 *neg = pos + HW;
 #ifndef TEF_FAST_DIV
-    float tau = 1.0f - fabsf(tref - ts) / delta;
+    float tau = FAST ? 1.0f - fabsf(tref - ts) * delta : 1.0f - fabsf(tref - ts) / delta;
 #else
     float tau = 1.0f - fabsf(tref - ts) * (1.0f / delta);
 #endif
@@ -764,6 +768,10 @@ __device__ __forceinline__ void NT_ST(float *p, float v) { *p = v; }
 #ifndef TEF_CHAIN_WAVES
 #define TEF_CHAIN_WAVES 1
 #endif
+// ONE: a single temporal scale (scales_loss = 1, the headline configuration).  The kernel is VALU-bound (~450 vector
+// instructions per chain step, 2.9e7 steps per BASELINE window): the per-step scale loop with its integer division
+// (t / scale) and the normalisation constant are hoisted, and the gradient arithmetic uses reciprocals (image_grad<true>).
+template <bool ONE>
 __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
                                                              const uint32_t *__restrict__ meta,
@@ -810,6 +818,14 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
         k_top = max(k_top, min(hi, t + delta));
         k_bot = min(k_bot, max(lo, t - delta + 1));
     }
+    // gradient w.r.t. the position at tref = k
+    const float one_kscale = gout * (1.0f / ((float)(1 << 0) * (float)(2 * reach + 1) * (float)w.S * (float)w.F));
+    const float one_rdelta = 1.0f / (float)reach;
+    auto pos_grad = [&](int k, float2 p) -> float2 {
+        if (!ONE) return iter_position_grad(w, ar, stats, ib, bits, t, k, gout, p, ts, mp, mn);
+        if (t < k - reach || t >= k + reach) return make_float2(0.0f, 0.0f);      // window [0, P], delta = reach
+        return image_grad<true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_rdelta, p, ts, mp, mn);
+    };
     float ay = 0.0f, ax = 0.0f;
     {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = P .. t+1
         int ks = min(min(P, kf - 1), k_top);
@@ -829,7 +845,7 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
                 quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
             }
 #endif
-            float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
+            float2 gk = pos_grad(k, cur);
             ay += gk.x;
             ax += gk.y;
             if (k - 1 == t) {
@@ -865,7 +881,7 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
                 quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
             }
 #endif
-            float2 gk = iter_position_grad(w, ar, stats, ib, bits, t, k, gout, cur, ts, mp, mn);
+            float2 gk = pos_grad(k, cur);
             ay += gk.x;
             ax += gk.y;
             if (k == t) {
@@ -1322,8 +1338,14 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     if (w.M > 0) {
         int chunks = (w.M + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
+#ifndef TEF_NO_CHAIN_ONE
+        if (w.kind == TEF_KIND_ITERATIVE && w.S == 1)
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+                             stats, grad_out, cy, cx, chunks);
+        else
+#endif
         if (w.kind == TEF_KIND_ITERATIVE)
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
                              stats, grad_out, cy, cx, chunks);
         else
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
