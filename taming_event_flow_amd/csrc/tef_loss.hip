@@ -161,7 +161,8 @@ __device__ __forceinline__ float unnormalize(float v, int size)
     return (nn + 1.0f) * ((float)(size - 1) / 2.0f);         // ATen ComputeLocation<align_corners=true>
 }
 
-__device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
+// fractions and the top-left cell of the lookup; y0 / x0 may lie outside the map
+__device__ __forceinline__ Taps taps_core(float y, float x, int H, int W, int &y0, int &x0)
 {
     Taps t;
     float iy = unnormalize(y, H), ix = unnormalize(x, W);
@@ -170,7 +171,16 @@ __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
     t.w = ix - fx;
     t.s = 1.0f - t.n;
     t.e = 1.0f - t.w;
-    int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1, x1 = x0 + 1;
+    y0 = (int)fy;
+    x0 = (int)fx;
+    return t;
+}
+
+__device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
+{
+    int y0, x0;
+    Taps t = taps_core(y, x, H, W, y0, x0);
+    int y1 = y0 + 1, x1 = x0 + 1;
     bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y1 >= 0) & (y1 < H);
     bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x1 >= 0) & (x1 < W);
     t.i00 = (vy0 && vx0) ? y0 * W + x0 : -1;
@@ -205,6 +215,17 @@ __device__ __forceinline__ Quad2 load_quad(const float2 *__restrict__ map, const
     Quad2 q;
     load_row(map, t.i00, t.i01, hw, q.v00, q.v01);
     load_row(map, t.i10, t.i11, hw, q.v10, q.v11);
+    return q;
+}
+
+// all four taps inside the map (0 <= y0 < H - 1, 0 <= x0 < W - 1): two plain 16-byte loads, no selects
+__device__ __forceinline__ Quad2 load_quad_interior(const float2 *__restrict__ map, int i00, int W)
+{
+    f32x4_a8 p0 = *reinterpret_cast<const f32x4_a8 *>(map + i00);
+    f32x4_a8 p1 = *reinterpret_cast<const f32x4_a8 *>(map + i00 + W);
+    Quad2 q;
+    q.v00 = make_float2(p0.x, p0.y); q.v01 = make_float2(p0.z, p0.w);
+    q.v10 = make_float2(p1.x, p1.y); q.v11 = make_float2(p1.z, p1.w);
     return q;
 }
 
@@ -655,13 +676,16 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
 //   dl/dw_k = sum_c m_c * K * 2 A_c (tau - A_c) R_c,  K = grad_out * coef / n
 // followed by the derivative of the bilinear hat weights.
 // ---------------------------------------------------------------------------------------------
-// FAST (the backward of the single-scale Iterative loss, where this function is VALU-bound): `delta` is 1 / delta and
-// both divisions become a multiplication by a reciprocal — gradient arithmetic only (1e-4 bar, measured 1e-6); the
-// coordinates and indices, which must match the forward bit for bit, are untouched.
-template <bool FAST = false>
+// FAST (the backward of the single-scale Iterative loss, where this function is VALU-bound): the division by the image's
+// pixel count becomes a multiplication by its reciprocal (a common factor of the gradient, 1 ulp).  tau keeps its true
+// division: where a pixel holds a single event, A == tau bit for bit and (tau - A) must cancel exactly as in the forward
+// (a reciprocal there leaves ulp-sized gradients where the true one is zero: tests/fuzz_loss.py, mode "one", odd P).
+// INTERIOR (decided per wavefront by the caller): all four corners inside the image, the right column adjacent to the
+// left one and a single polarity — the validity selects, the fp32 corner case and the second-polarity branch drop out.
+template <bool FAST = false, bool INTERIOR = false>
 __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
                                              const float *__restrict__ stats, int ib, int j, float kscale, float tref,
-                                             float delta, float2 p, float ts, float mp, float mn)
+                                             float delta, const Splat &sp, float ts, float mp, float mn)
 {
     const int HW = w.H * w.W;
     const int FB = w.F * w.B;
@@ -670,12 +694,30 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     const float2 *pos = ar + q * 2 * HW;
     const float2 *neg = pos + HW;
 #ifndef TEF_FAST_DIV
-    float tau = FAST ? 1.0f - fabsf(tref - ts) * delta : 1.0f - fabsf(tref - ts) / delta;
+    float tau = 1.0f - fabsf(tref - ts) / delta;
 #else
     float tau = 1.0f - fabsf(tref - ts) * (1.0f / delta);
 #endif
-    Splat sp = make_splat(p.x, p.y);
     float gy = 0.0f, gx = 0.0f;
+    if (INTERIOR) {
+        const float2 *pl = (mp != 0.0f) ? pos : neg;
+        const float m1 = (mp != 0.0f) ? mp : mn;
+        f32x4_a8 r[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) r[k] = *reinterpret_cast<const f32x4_a8 *>(pl + sp.iy[k] * w.W + sp.ix[0]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float dw0 = m1 * (2.0f * r[k].x * (tau - r[k].x) * r[k].y);
+            float dw1 = m1 * (2.0f * r[k].z * (tau - r[k].z) * r[k].w);
+            dw0 *= kimg;
+            dw1 *= kimg;
+            gy += dw0 * (sp.sy[k] * sp.wx[0]);
+            gx += dw0 * (sp.wy[k] * sp.sx[0]);
+            gy += dw1 * (sp.sy[k] * sp.wx[1]);
+            gx += dw1 * (sp.wy[k] * sp.sx[1]);
+        }
+        return make_float2(gy, gx);
+    }
     const bool vx0 = (sp.ix[0] >= 0) & (sp.ix[0] < w.W), vx1 = (sp.ix[1] >= 0) & (sp.ix[1] < w.W);
     // One polarity plane per event in the common case (masks are (1,0) / (0,1)): its two rows are fetched by two
     // unconditional 16-byte loads; an event carrying both polarities adds the second plane in a (rare) branch.
@@ -716,6 +758,15 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
         gx += dw1 * (sp.wy[r] * sp.sx[1]);
     }
     return make_float2(gy, gx);
+}
+
+template <bool FAST = false>
+__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
+                                             const float *__restrict__ stats, int ib, int j, float kscale, float tref,
+                                             float delta, float2 p, float ts, float mp, float mn)
+{
+    Splat sp = make_splat(p.x, p.y);
+    return image_grad<FAST, false>(w, ar, stats, ib, j, kscale, tref, delta, sp, ts, mp, mn);
 }
 
 // gradient w.r.t. the event position at tref = k, summed over the temporal scales that use it (Iterative)
@@ -770,7 +821,7 @@ __device__ __forceinline__ void NT_ST(float *p, float v) { *p = v; }
 #endif
 // ONE: a single temporal scale (scales_loss = 1, the headline configuration).  The kernel is VALU-bound (~450 vector
 // instructions per chain step, 2.9e7 steps per BASELINE window): the per-step scale loop with its integer division
-// (t / scale) and the normalisation constant are hoisted, and the gradient arithmetic uses reciprocals (image_grad<true>).
+// (t / scale) and the normalisation constant are hoisted, and 1 / n is a reciprocal (image_grad<true>).
 template <bool ONE>
 __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
@@ -820,11 +871,35 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     }
     // gradient w.r.t. the position at tref = k
     const float one_kscale = gout * (1.0f / ((float)(1 << 0) * (float)(2 * reach + 1) * (float)w.S * (float)w.F));
-    const float one_rdelta = 1.0f / (float)reach;
+    const float one_delta = (float)reach;
     auto pos_grad = [&](int k, float2 p) -> float2 {
         if (!ONE) return iter_position_grad(w, ar, stats, ib, bits, t, k, gout, p, ts, mp, mn);
         if (t < k - reach || t >= k + reach) return make_float2(0.0f, 0.0f);      // window [0, P], delta = reach
-        return image_grad<true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_rdelta, p, ts, mp, mn);
+        return image_grad<true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, p, ts, mp, mn);
+    };
+    // One chain step when EVERY lane of the wavefront has all its flow taps (at `nxt`, map `km`) and image corners (at
+    // `cur`, tref k) inside the frame, adjacent, single polarity: plain 16-byte loads and no validity selects (~25 % fewer
+    // vector instructions; border events send their wavefront through the general code).  Same arithmetic, same order.
+    const bool one_pol = !((mp != 0.0f) & (mn != 0.0f));
+    auto step_interior = [&](int k, int km, float2 cur, float2 nxt, float2 &gk, float &jyy, float &jyx, float &jxy,
+                             float &jxx) -> bool {
+#if defined(TEF_NO_CHAIN_INTERIOR) || defined(TEF_ABL_NOFLOW)
+        return false;
+#endif
+        if (!ONE) return false;
+        int y0, x0;
+        Taps tp = taps_core(nxt.x, nxt.y, H, W, y0, x0);
+        Splat sp = make_splat(cur.x, cur.y);
+        const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (sp.iy[0] >= 0) & (sp.iy[1] < H) &
+                            (sp.ix[0] >= 0) & (sp.ix[1] < W) & (sp.ix[1] == sp.ix[0] + 1);
+        if (__builtin_amdgcn_ballot_w64(!inside) != 0) return false;
+        const int kmc = min(max(km, 0), P - 1);                   // lanes past their chain's end: any valid map
+        Quad2 q = load_quad_interior(flow_map(w, flows, kmc, i, b), y0 * W + x0, W);
+        gk = make_float2(0.0f, 0.0f);
+        if (t >= k - reach && t < k + reach)
+            gk = image_grad<true, true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, sp, ts, mp, mn);
+        quad_jacobian(q, tp, jyy, jyx, jxy, jxx);
+        return true;
     };
     float ay = 0.0f, ax = 0.0f;
     {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = P .. t+1
@@ -839,13 +914,14 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
             // two flow rows and the two image rows are in flight together
             float2 nn = NT_LD2(&tr[(size_t)max(k - 2, t + 1) * w.Mt]);
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+            float2 gk;
+            if (!step_interior(k, k - 1, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
 #ifndef TEF_ABL_NOFLOW
-            {
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
                 quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-            }
 #endif
-            float2 gk = pos_grad(k, cur);
+                gk = pos_grad(k, cur);
+            }
             ay += gk.x;
             ax += gk.y;
             if (k - 1 == t) {
@@ -875,13 +951,14 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
         for (int k = ks; k <= t; ++k) {
             float2 nn = NT_LD2(&tr[(size_t)min(k + 2, t) * w.Mt]);
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+            float2 gk;
+            if (!step_interior(k, k, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
 #ifndef TEF_ABL_NOFLOW
-            {
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
                 quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-            }
 #endif
-            float2 gk = pos_grad(k, cur);
+                gk = pos_grad(k, cur);
+            }
             ay += gk.x;
             ax += gk.y;
             if (k == t) {
