@@ -28,7 +28,7 @@ def per_kernel(path, counter, skip):
                 continue
             sym = row["Kernel_Name"]
             for pre, name in KERNELS.items():
-                if "::" + pre + "(" in sym or sym.startswith(pre):
+                if "::" + pre + "(" in sym or "::" + pre + "<" in sym or sym.startswith(pre):     # plain or templated
                     vals[name].append(float(row["Counter_Value"]) * 1024.0)
                     break
     return {k: (sum(v[skip:]) / max(1, len(v[skip:])), len(v[skip:])) for k, v in vals.items()}
