@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
                     help="experiment: pre-sort the synthetic events of each pass on the host")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--step-graph", action="store_true",
+                    help="loss mode: replay a captured hipGraph of the step (for hosts too slow to enqueue 0.8 ms steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--event-every", type=int, default=4,
@@ -195,13 +197,45 @@ def main():
     for k in range(a.warmup):
         step(k)
     barrier()
+    # One step is six kernel launches behind ~0.3 ms of Python (autograd + ctypes), enqueued asynchronously: the GPU sets
+    # the pace unless the host is unusually slow (1.1-1.2 ms per step seen on some boxes against 0.82).  --step-graph
+    # replays a hipGraph of the same step instead (same launches, same buffers; ~0.1 ms of graph launch per replay, so it
+    # only pays on such hosts); every `event_every`-th step stays eager because its launches carry HIP events.
+    graphs = []
+    if a.step_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for k in range(len(staged)):
+                    step(k)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for k in range(len(staged)):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    out = step(k)
+                graphs.append((gph, out))
+        except Exception as e:                                    # noqa: BLE001
+            print(f"[bench] step graph capture failed ({e!r}); running every step eagerly", file=sys.stderr)
+            graphs = []
+        torch.cuda.synchronize()
     # per-kernel HIP events (start / stop of each launch, on the launch stream) on every `event_every`-th timed step
     lib.tef_profile_enable(0 if a.no_kernel_events else 1)
+    if not a.no_kernel_events:
+        lib.tef_profile_pause(1)
+    barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
+        profiled = not a.no_kernel_events and k % max(1, a.event_every) == 0
         if not a.no_kernel_events:
-            lib.tef_profile_pause(0 if k % max(1, a.event_every) == 0 else 1)
-        last, last_grads = step(k)
+            lib.tef_profile_pause(0 if profiled else 1)
+        if graphs and not profiled:
+            gph, out = graphs[k % len(graphs)]
+            gph.replay()
+            last, last_grads = out
+        else:
+            last, last_grads = step(k)
     t_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (diagnostic: host- vs device-bound)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -250,7 +284,10 @@ def main():
                                    f"N={a.events}+{a.detached} events/pass/sample, {a.flow} flows sigma=2px "
                                    "(BASELINE.json configs[1])",
                        "global_batch": B * world, "events_per_window_per_gpu": events_per_step,
-                       "parallelism": f"dp{world} (batch-sharded, no data-path collective)"},
+                       "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
+                       "launch": ("hipGraph replay of the step; every %d-th step eager with per-kernel HIP events"
+                                  % max(1, a.event_every)) if graphs and not a.no_kernel_events
+                       else ("hipGraph replay of the step" if graphs else "eager")},
             "loss": round(loss_val, 6),
             "ms_update_per_window": round(1e3 * t_update, 3),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),

@@ -331,9 +331,22 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
     int t = E.bin[sl];
     float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
 
+    // Bilinear flow lookup of map k at (y, x).  The kernel is VALU-bound (~135 vector instructions per chain step): when
+    // every lane of the wavefront has its four taps inside the map, two plain 16-byte loads replace the clamped,
+    // select-masked ones (same values, same arithmetic).
+    auto lookup = [&](float y, float x, int k) -> float2 {
+        const float2 *map = flow_map(w, flows, k, i, b);
+#ifndef TEF_NO_WARP_INTERIOR
+        int yi, xi;
+        Taps c = taps_core(y, x, H, W, yi, xi);
+        const bool inside = (yi >= 0) & (yi < H - 1) & (xi >= 0) & (xi < W - 1);
+        if (__builtin_amdgcn_ballot_w64(!inside) == 0) return quad_value(load_quad_interior(map, yi * W + xi, W), c);
+#endif
+        Taps q = make_taps(y, x, H, W);
+        return quad_value(load_quad(map, q, H * W), q);
+    };
     // flow at the original location, shared by the first forward and the first backward step
-    Taps tp = make_taps(y0, x0, H, W);
-    float2 f0 = quad_value(load_quad(flow_map(w, flows, t, i, b), tp, w.H * w.W), tp);
+    float2 f0 = lookup(y0, x0, t);
 
     // an event of pass t is only ever looked at (IWEs, gradient sweep, flow-gradient splat) at reference times within
     // delta_passes[0] of t; the chain still runs to both ends of the window because the border mask needs it
@@ -345,8 +358,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         float dt = (float)(t + 1) - ts;             // utils/iwe.py:14 (tref - ts)
         for (int k = t; k < P; ++k) {
             if (k > t) {
-                Taps q = make_taps(y, x, H, W);
-                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q, w.H * w.W), q);
+                f = lookup(y, x, k);
                 dt = 1.0f;
             }
             y = y + dt * f.x;
@@ -361,8 +373,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         float dt = (float)t - ts;
         for (int k = t; k >= 0; --k) {
             if (k < t) {
-                Taps q = make_taps(y, x, H, W);
-                f = quad_value(load_quad(flow_map(w, flows, k, i, b), q, w.H * w.W), q);
+                f = lookup(y, x, k);
                 dt = -1.0f;
             }
             y = y + dt * f.x;
