@@ -148,13 +148,26 @@ struct Taps {
     float s, n, e, w;         // (1-fy), fy, (1-fx), fx
 };
 
-// True divisions, bit-for-bit the reference's coordinates and timestamps.  (Multiplying by the reciprocal instead —
-// TEF_FAST_DIV, an experiment hook — moves exactly-integer event coordinates across a floor() boundary, fails the
-// golden parity tests and only buys 1 % of the step.)
+// Correctly rounded a / b for an integer constant b (1 <= b < 2^24), bit for bit IEEE division, in three instructions
+// instead of the ~12 of the fp32 division sequence (the chain kernels are VALU-bound): RN_f32((double)a * RN_f64(1 / b)).
+// The double product is within 2^-51 (relative) of a / b, and a / b cannot be that close to a rounding boundary of fp32:
+// a boundary m has a 25-bit significand, a and m * b are multiples of 2^(e_m - 24), so a / b != m implies
+// |a / b - m| >= 2^(e_m - 24) / b >= 2^-49 m; and a / b == m would need m * b (odd 25-bit x odd part of b) to fit the 24
+// bits of a.  A fp32 reciprocal instead (TEF_FAST_DIV, an experiment hook) moves exactly-integer coordinates across a
+// floor() boundary and fails the golden parity tests.
+__device__ __forceinline__ float div_by_const(float a, double rinv) { return (float)((double)a * rinv); }
+
+// IEEE: the plain division sequence (K1: its chain is paced by fp32 issue and the fp64 multiply is the slower of the two
+// there, 0.113 vs 0.116 ms; K6 / K7 gain 3 %).  Both forms give the same bits.
+template <bool IEEE = false>
 __device__ __forceinline__ float unnormalize(float v, int size)
 {
-#ifndef TEF_FAST_DIV
+#if defined(TEF_TRUE_DIV)
     float nn = (2.0f * v) / (float)(size - 1) - 1.0f;       // utils/iwe.py:30-31
+#elif !defined(TEF_FAST_DIV)
+    if (IEEE) return ((2.0f * v) / (float)(size - 1) - 1.0f + 1.0f) * ((float)(size - 1) / 2.0f);
+    const double rinv = 1.0 / (double)(size - 1);            // kernel-invariant: hoisted out of the chain loops
+    float nn = div_by_const(2.0f * v, rinv) - 1.0f;          // utils/iwe.py:30-31
 #else
     float nn = (2.0f * v) * (1.0f / (float)(size - 1)) - 1.0f;
 #endif
@@ -162,10 +175,11 @@ __device__ __forceinline__ float unnormalize(float v, int size)
 }
 
 // fractions and the top-left cell of the lookup; y0 / x0 may lie outside the map
+template <bool IEEE = false>
 __device__ __forceinline__ Taps taps_core(float y, float x, int H, int W, int &y0, int &x0)
 {
     Taps t;
-    float iy = unnormalize(y, H), ix = unnormalize(x, W);
+    float iy = unnormalize<IEEE>(y, H), ix = unnormalize<IEEE>(x, W);
     float fy = floorf(iy), fx = floorf(ix);
     t.n = iy - fy;
     t.w = ix - fx;
@@ -176,10 +190,11 @@ __device__ __forceinline__ Taps taps_core(float y, float x, int H, int W, int &y
     return t;
 }
 
+template <bool IEEE = false>
 __device__ __forceinline__ Taps make_taps(float y, float x, int H, int W)
 {
     int y0, x0;
-    Taps t = taps_core(y, x, H, W, y0, x0);
+    Taps t = taps_core<IEEE>(y, x, H, W, y0, x0);
     int y1 = y0 + 1, x1 = x0 + 1;
     bool vy0 = (y0 >= 0) & (y0 < H), vy1 = (y1 >= 0) & (y1 < H);
     bool vx0 = (x0 >= 0) & (x0 < W), vx1 = (x1 >= 0) & (x1 < W);
@@ -338,11 +353,11 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         const float2 *map = flow_map(w, flows, k, i, b);
 #ifndef TEF_NO_WARP_INTERIOR
         int yi, xi;
-        Taps c = taps_core(y, x, H, W, yi, xi);
+        Taps c = taps_core<true>(y, x, H, W, yi, xi);
         const bool inside = (yi >= 0) & (yi < H - 1) & (xi >= 0) & (xi < W - 1);
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) return quad_value(load_quad_interior(map, yi * W + xi, W), c);
 #endif
-        Taps q = make_taps(y, x, H, W);
+        Taps q = make_taps<true>(y, x, H, W);
         return quad_value(load_quad(map, q, H * W), q);
     };
     // flow at the original location, shared by the first forward and the first backward step
@@ -705,7 +720,8 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     const float2 *pos = ar + q * 2 * HW;
     const float2 *neg = pos + HW;
 #ifndef TEF_FAST_DIV
-    float tau = 1.0f - fabsf(tref - ts) / delta;
+    // (FAST: delta is kernel-invariant there, an integer number of passes: the same bits from the cheaper exact form)
+    float tau = FAST ? 1.0f - div_by_const(fabsf(tref - ts), 1.0 / (double)delta) : 1.0f - fabsf(tref - ts) / delta;
 #else
     float tau = 1.0f - fabsf(tref - ts) * (1.0f / delta);
 #endif
