@@ -111,23 +111,66 @@ def algorithmic_bytes(a, delta):
     }, splats
 
 
-def main():
-    a = parse()
-    import torch
+def launch_ranks(a):
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks as CHILD processes (the same command
+    the driver uses: torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) before anything in this process
+    has touched the GPU, pass their output through (rank 0 prints the JSON line) and exit with their code.  The parent
+    never initialises HIP and never re-execs."""
+    import socket
+    import subprocess
 
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    return subprocess.call(cmd, env=env)
+
+
+def init_ranks(a):
+    """-> (torch, dist | None, device, rank, world).  One process per GPU; backend "nccl" = RCCL over xGMI.
+    TEF_BENCH_BACKEND=gloo + TEF_BENCH_SHARE_GPU=1 let the multi-rank control flow be exercised on a 1-GPU box."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with "
+                         f"torch.distributed.run --nproc-per-node {a.gpus} (or plain `python bench.py --gpus {a.gpus}`)")
+    if os.environ.get("TEF_BENCH_LAUNCH_ONLY") == "1":      # launcher test hook (tests/test_bench_launch.py): no GPU needed
+        print(json.dumps({"launch_only": True, "rank": rank, "world": world, "local": local}), flush=True)
+        raise SystemExit(0)
+    import torch
+
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("TEF_BENCH_SHARE_GPU") == "1"
+    if ndev < 1 or (world > ndev and not share):
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {ndev} visible")
+    idx = local % ndev if share else local
+    torch.cuda.set_device(idx)
+    dev = torch.device("cuda", idx)
+    dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist = None
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+        backend = os.environ.get("TEF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == a.gpus and dist.get_rank() == rank
+    return torch, dist, dev, rank, world
+
+
+def main():
+    a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(a))
+    torch, dist, dev, rank, world = init_ranks(a)
 
     import __graft_entry__ as ge
 
@@ -346,21 +389,38 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
     cfg["data"]["passes_loss"] = a.passes
     cfg["loss"]["warping"] = a.warping
     torch.manual_seed(1234)                      # identical initial weights on every rank
-    if a.graph and world > 1:
-        a.graph = False                          # the DP window (RCCL all-reduce + flag exchange) is replayed eagerly
-    if a.graph:
-        cfg["optimizer"]["capturable"] = True
-    tr = train.Trainer(cfg, dev)
-    src = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100 + rank)
     P = a.passes
+    from taming_event_flow_amd import parallel
+
+    def build(graph):
+        cfg["optimizer"]["capturable"] = bool(graph)
+        torch.manual_seed(1234)
+        tr_ = train.Trainer(cfg, dev)
+        src_ = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100 + rank)
+        return tr_, src_
+
+    tr, src = build(a.graph)
 
     def window():
         for _ in range(P):
             tr.step(src.next(), new_seq=False)
 
     if a.graph:
+        # under DP the captured window contains the RCCL all-reduce; the new_seq flag is exchanged on the host.  If the
+        # capture fails on ANY rank, every rank falls back to the eager window together.
         tr.reset()
-        window = tr.capture_window([src.next() for _ in range(P)])
+        failed = False
+        try:
+            captured = tr.capture_window([src.next() for _ in range(P)])
+        except Exception as e:                                    # noqa: BLE001
+            print(f"[bench] rank {rank}: window graph capture failed ({e!r}); eager window", file=sys.stderr)
+            failed = True
+        if parallel.any_rank(failed):
+            a.graph = False
+            torch.cuda.synchronize()
+            tr, src = build(False)
+        else:
+            window = captured
 
     def barrier():
         if dist:

@@ -49,13 +49,36 @@ class FlatGradBucket:
         return norm
 
 
-def any_rank(flag, device):
-    """True on every rank if `flag` is True on at least one (lock-step `new_seq`)."""
+_FLAG_GROUP = None
+
+
+def _flag_group():
+    """Host-side (gloo) group for the one-int flag exchange.  With RCCL as the default backend the flag would have to
+    travel through the GPU stream, and reading it back would drain the stream on every pass; a CPU group leaves the
+    asynchronous launch queue alone.  Created on first use — by every rank together, since every rank exchanges the
+    flag on every pass."""
+    global _FLAG_GROUP
+    if _FLAG_GROUP is None:
+        _FLAG_GROUP = dist.group.WORLD if dist.get_backend() == "gloo" else dist.new_group(backend="gloo")
+    return _FLAG_GROUP
+
+
+def any_rank(flag, device=None):
+    """True on every rank if `flag` is True on at least one (lock-step `new_seq`, reference train_flow.py:83-87 applied
+    to the global batch).  EVERY rank must call this at the same point of every pass, whatever its own flag is: a rank
+    that skipped the exchange would pair the other ranks' flag all-reduce with its next collective (the gradient
+    all-reduce) and hang or corrupt it.  No collective (and no device sync) outside DP."""
     if not is_distributed():
         return bool(flag)
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_flag_group())
     return bool(t.item())
+
+
+def reset_groups():
+    """Forget the cached flag group (after destroy_process_group)."""
+    global _FLAG_GROUP
+    _FLAG_GROUP = None
 
 
 def shard_range(global_batch, rank, world):

@@ -70,15 +70,39 @@ class SyntheticSequences:
         return batch
 
 
+class CapturedWindow:
+    """A loss window captured by Trainer.capture_window.  `inputs[t]` is pass t's batch dict of STATIC tensors: write
+    the next window's data into them (`.copy_`), then `replay()`.  `new_seq` is the reference's reset flag for the
+    window's first pass (train_flow.py:83-87); a captured window is P passes long by construction, so sequences must
+    change at window boundaries (DSEC: 200 passes per sequence, P = 10)."""
+
+    def __init__(self, trainer, graph, graph_tail, inputs, states):
+        self.trainer, self.graph, self.graph_tail, self.inputs, self.states = trainer, graph, graph_tail, inputs, states
+
+    def replay(self, new_seq=False):
+        if parallel.any_rank(new_seq):       # host-side exchange, outside the graph; all ranks reset together
+            for s in self.states:            # loss containers and gradients are already clear at a window boundary
+                s.zero_()
+        self.graph.replay()
+        if self.graph_tail is not None:      # DP: the collective runs between the two graphs, on the same stream
+            self.trainer.bucket.all_reduce_sum()
+            self.graph_tail.replay()
+        return self.trainer.last_loss
+
+    __call__ = replay
+
+
 class Trainer:
     """model + loss + optimiser wired like reference train_flow.py:60-70, plus the DP gradient bucket."""
 
-    def __init__(self, config, device):
+    def __init__(self, config, device, model=None, loss_function=None):
         self.cfg, self.device = config, device
         num_bins = 2 if config["data"]["voxel"] is None else config["data"]["voxel"]
-        self.model = eval(config["model"]["name"])(config["model"].copy(), num_bins, key="flow").to(device)
+        if model is None:
+            model = eval(config["model"]["name"])(config["model"].copy(), num_bins, key="flow")
+        self.model = model.to(device)
         self.model.train()
-        self.loss_function = eval(config["loss"]["warping"])(config, device)
+        self.loss_function = loss_function if loss_function is not None else eval(config["loss"]["warping"])(config, device)
         self.bucket = parallel.FlatGradBucket(self.model.parameters())
         submodules.enable_direct_grads(self.model)      # conv kernels add into the bucket's .grad views
         # weight gradients of a window's passes: one long reduction per layer after backward (opt out: TEF_NO_DEFERRED_WGRAD=1)
@@ -98,24 +122,36 @@ class Trainer:
         self.bucket.zero()
 
     def capture_window(self, batches, warmup=2):
-        """Capture one whole loss window (P passes of `batches`, loss, BPTT backward, clip, optimiser step) into a
-        hipGraph and return a zero-argument replay function: ~10^3 kernel launches become one graph launch, so the
-        window is device-bound instead of host-bound.  Static shapes and buffers: the caller refreshes the contents of
-        the `batches` tensors in place before each replay.  Single-process only (the lock-step flag needs a host sync);
-        under DP the gradient all-reduce would be captured too, but the flag is exchanged outside the graph."""
-        if parallel.is_distributed():
-            raise NotImplementedError("graph capture of the DP window is not wired yet")
+        """Capture one whole loss window (P passes, loss, BPTT backward, [DP all-reduce], clip, optimiser step) into a
+        hipGraph: ~10^3 kernel launches become one graph launch, so the window is device-bound instead of host-bound.
+        Returns a `CapturedWindow`: the caller writes each new window's batch tensors into `.inputs` (static buffers,
+        same shapes as `batches`) and calls `.replay(new_seq)`.  Under DP the window is TWO graphs around the gradient
+        all-reduce — [P passes, loss, BPTT backward] -> RCCL all-reduce(SUM), enqueued eagerly on the same stream ->
+        [clip, optimiser step, state hand-over] — so no collective is ever stream-captured; the lock-step `new_seq`
+        flag is exchanged on the host before the first graph is launched."""
         P = self.cfg["data"]["passes_loss"]
         assert len(batches) == P
         if warmup < 1:
             raise ValueError("capture needs at least one eager window (allocations, recurrent state buffers)")
-        originals = [{k: v.clone() for k, v in b.items()} for b in batches]
+        if self.loss_function.num_passes != 0:
+            raise RuntimeError("capture_window must start at a window boundary")
+        inputs = [{k: v.clone() for k, v in b.items()} for b in batches]          # public static input buffers
+        work = [{k: torch.empty_like(v) for k, v in b.items()} for b in batches]   # update() shifts timestamps in place
+
+        split = parallel.is_distributed()
+
+        def run_head():          # everything up to the local gradient
+            for src, dst in zip(inputs, work):
+                for k in src:
+                    dst[k].copy_(src[k])
+                complete = self._forward_update(dst)
+            assert complete
+            self._backward_window()
 
         def run():
-            for b, o in zip(batches, originals):
-                for k in b:
-                    b[k].copy_(o[k])            # update() shifts the timestamps of the caller's lists in place
-                self.step(b, new_seq=False)
+            run_head()
+            self.bucket.all_reduce_sum()
+            self._apply_update()
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -131,35 +167,60 @@ class Trainer:
         # end-of-window state back, so consecutive replays carry the state exactly like the eager loop
         static_states = [s.detach().clone() for s in self.model.arch.states]
         self.model.arch.states = static_states
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            run()
+        def tail():
+            self._apply_update()
             for dst, src in zip(static_states, self.model.arch.states):
                 dst.copy_(src.detach())
+
+        graph, graph_tail = torch.cuda.CUDAGraph(), None
+        with torch.cuda.graph(graph):
+            run_head()
+            if not split:
+                tail()
+        if split:
+            graph_tail = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_tail, pool=graph.pool()):
+                tail()
         self.model.arch.states = static_states
-        return graph.replay
+        return CapturedWindow(self, graph, graph_tail, inputs, static_states)
 
     def step(self, inputs, new_seq=False):
         """One pass (train_flow.py:83-137).  Returns True when an optimiser step happened."""
-        cfg = self.cfg
-        if new_seq is not False and parallel.any_rank(new_seq, self.device):
+        if parallel.any_rank(new_seq):      # every rank exchanges its flag on every pass (no-op outside DP)
             self.reset()
+        return self._pass(inputs)
+
+    def _pass(self, inputs):
+        if not self._forward_update(inputs):
+            return False
+        self._backward_window()
+        self.bucket.all_reduce_sum()                    # DP: gradient of the global batch (sum of shards)
+        self._apply_update()
+        return True
+
+    def _forward_update(self, inputs):
+        """train_flow.py:101-118: forward, scale, hand the pass to the loss.  True when the window is complete."""
+        cfg = self.cfg
         x = self.model(inputs["net_input"])
         flows = [f * cfg["loss"]["flow_scaling"] for f in x["flow"]]
         self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
                                   inputs["d_event_list_pol_mask"])
-        if self.loss_function.num_passes < cfg["data"]["passes_loss"]:
-            return False
+        return self.loss_function.num_passes >= cfg["data"]["passes_loss"]
+
+    def _backward_window(self):
+        """train_flow.py:120-125: loss over the window, BPTT backward (local shard of the batch)."""
         loss = self.loss_function()
         loss.backward()
         if self.deferred_wgrad:
             submodules.flush_deferred_wgrads()
-        self.bucket.all_reduce_sum()                    # DP: gradient of the global batch (sum of shards)
+        self.last_loss = loss.detach()
+
+    def _apply_update(self):
+        """train_flow.py:127-137 on the (already reduced) flat gradient: clip, step, clear, cut the graph."""
+        cfg = self.cfg
         if cfg["loss"]["clip_grad"] is not None:
             self.last_grad_norm = self.bucket.clip_(cfg["loss"]["clip_grad"])
         self.optimizer.step()
         self.bucket.zero()                              # optimizer.zero_grad() keeping the flat views
         self.model.detach_states()
         self.loss_function.reset()
-        self.last_loss = loss.detach()
-        return True
