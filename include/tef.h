@@ -60,8 +60,9 @@ long tef_profile_calls(int slot);
 typedef struct tef_events {
     const float *ts, *y, *x, *mp, *mn;
     const uint8_t *bin;
-    const int *cls;   /* [B][TEF_MAX_PASSES][3]: per sample and pass, where the pos-only / neg-only / both-polarity
-                         runs of the pass end (slots relative to the pass start); written by tef_pack_events */
+    const int *cls;   /* [B][TEF_MAX_PASSES][3]: per sample and pass, where the pos-only (mask exactly (1,0)) /
+                         neg-only ((0,1)) / general (both polarities set, or a mask value other than 0 or 1) runs of
+                         the pass end (slots relative to the pass start); written by tef_pack_events */
     int cap;
 } tef_events;
 

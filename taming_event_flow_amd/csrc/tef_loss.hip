@@ -44,17 +44,11 @@ namespace {
 constexpr float kEps = 1e-9f;
 constexpr int kSplatThreads = 1024;
 constexpr size_t kLdsBudget = 144 * 1024;   // per-workgroup accumulator budget (160 KiB LDS per CU on gfx950)
-#ifndef TEF_ROWPAD
-#define TEF_ROWPAD 8
-#endif
-constexpr int kRowPad = TEF_ROWPAD;                  // fp64 LDS rows are W + 8 wide: rows 16 banks apart, so the 8x8-pixel
+constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the 8x8-pixel
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
 constexpr int kMaxSegs = 4 * TEF_MAX_PASSES;
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
-#ifndef TEF_UNROLL
-#define TEF_UNROLL 4
-#endif
-constexpr int kUnroll = TEF_UNROLL;
+constexpr int kUnroll = 4;
 
 // meta word written by K1 per (head, sample, slot)
 constexpr uint32_t kMetaPos = 1u << 24;      // mask_pos != 0
@@ -153,8 +147,8 @@ struct Taps {
 // The double product is within 2^-51 (relative) of a / b, and a / b cannot be that close to a rounding boundary of fp32:
 // a boundary m has a 25-bit significand, a and m * b are multiples of 2^(e_m - 24), so a / b != m implies
 // |a / b - m| >= 2^(e_m - 24) / b >= 2^-49 m; and a / b == m would need m * b (odd 25-bit x odd part of b) to fit the 24
-// bits of a.  A fp32 reciprocal instead (TEF_FAST_DIV, an experiment hook) moves exactly-integer coordinates across a
-// floor() boundary and fails the golden parity tests.
+// bits of a.  (A fp32 reciprocal instead moves exactly-integer coordinates across a floor() boundary and fails the
+// golden parity tests: DESIGN.md section 9.)
 __device__ __forceinline__ float div_by_const(float a, double rinv) { return (float)((double)a * rinv); }
 
 // IEEE: the plain division sequence (K1: its chain is paced by fp32 issue and the fp64 multiply is the slower of the two
@@ -162,15 +156,9 @@ __device__ __forceinline__ float div_by_const(float a, double rinv) { return (fl
 template <bool IEEE = false>
 __device__ __forceinline__ float unnormalize(float v, int size)
 {
-#if defined(TEF_TRUE_DIV)
-    float nn = (2.0f * v) / (float)(size - 1) - 1.0f;       // utils/iwe.py:30-31
-#elif !defined(TEF_FAST_DIV)
     if (IEEE) return ((2.0f * v) / (float)(size - 1) - 1.0f + 1.0f) * ((float)(size - 1) / 2.0f);
     const double rinv = 1.0 / (double)(size - 1);            // kernel-invariant: hoisted out of the chain loops
     float nn = div_by_const(2.0f * v, rinv) - 1.0f;          // utils/iwe.py:30-31
-#else
-    float nn = (2.0f * v) * (1.0f / (float)(size - 1)) - 1.0f;
-#endif
     return (nn + 1.0f) * ((float)(size - 1) / 2.0f);         // ATen ComputeLocation<align_corners=true>
 }
 
@@ -351,12 +339,10 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
     // select-masked ones (same values, same arithmetic).
     auto lookup = [&](float y, float x, int k) -> float2 {
         const float2 *map = flow_map(w, flows, k, i, b);
-#ifndef TEF_NO_WARP_INTERIOR
         int yi, xi;
         Taps c = taps_core<true>(y, x, H, W, yi, xi);
         const bool inside = (yi >= 0) & (yi < H - 1) & (xi >= 0) & (xi < W - 1);
         if (__builtin_amdgcn_ballot_w64(!inside) == 0) return quad_value(load_quad_interior(map, yi * W + xi, W), c);
-#endif
         Taps q = make_taps<true>(y, x, H, W);
         return quad_value(load_quad(map, q, H * W), q);
     };
@@ -453,7 +439,7 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
     *mo = pack_meta(bits, -1, 0, mp, mn);
 }
 
-// LDS image plane helpers of the two scatter kernels: [rows][W + kRowPad] doubles.
+// LDS image plane helpers of the two scatter kernels: [rows][W + kRowPad] 8-byte accumulators.
 // zero fill with 16-byte stores; write-out [rows][W] floats without a per-element division: when the workgroup covers
 // whole rows (blockDim % (W/2) == 0) a thread keeps its column pair and walks down the rows with 16-byte LDS reads.
 __device__ __forceinline__ void lds_plane_zero(double *img, int n)
@@ -463,6 +449,29 @@ __device__ __forceinline__ void lds_plane_zero(double *img, int n)
     if ((n & 1) && threadIdx.x == 0) img[n - 1] = 0.0;
 }
 
+// Fixed-point accumulators of the IWE scatter (K2).  Measured on this chip (tools/lds_atomic_patterns.hip, cycles per
+// wave-instruction per CU): ds_add_f64 9.6 conflict-free, 17 / 33 at 2- / 4-way bank conflicts, 31 on the footprint of a
+// sorted wavefront; ds_add_u64 7.8 / 9.4 / 17 and 18 on that footprint (ds_add_f32: 194 whatever the pattern).  The
+// integer atomic is twice as fast where it matters, and integer sums are exact: the images no longer depend on the
+// arrival order, so the loss is bitwise reproducible from run to run.
+// Format: two's-complement Q17.46.  A contribution v = w [* tau] (fp32, |v| < 32) becomes RN(v * 2^46) in three
+// instructions: 96 + v has ulp 2^-46 over (64, 128), so the difference of the bit patterns of (96 + v) and 96 IS that
+// integer.  Exact whenever v's lowest mantissa bit is >= 2^-46 (every bilinear weight >= 2^-23), otherwise rounded to
+// 2^-47 absolute.  n contributions of at most 1 cannot overflow while n < 2^17: the workgroup knows its event count up
+// front and takes the fp64 path beyond that, and when its runs hold general (non-0/1) mask values.
+constexpr double kFxMagic = 96.0;
+constexpr int kFxMaxEvents = 1 << 17;
+__device__ __forceinline__ unsigned long long to_fixed(float v)
+{
+    return (unsigned long long)(__double_as_longlong((double)v + kFxMagic) - __double_as_longlong(kFxMagic));
+}
+template <bool FX>
+__device__ __forceinline__ float acc_value(double a)
+{
+    return FX ? (float)((double)__double_as_longlong(a) * 0x1p-46) : (float)a;
+}
+
+template <bool FX = false>
 __device__ __forceinline__ void lds_plane_store(const double *img, int rows, int W, int WP, float *__restrict__ o)
 {
     const int half = W >> 1;
@@ -471,59 +480,82 @@ __device__ __forceinline__ void lds_plane_store(const double *img, int rows, int
         int r = threadIdx.x / half, c = (threadIdx.x - r * half) * 2;
         for (; r < rows; r += rstep) {
             double2 d = *reinterpret_cast<const double2 *>(img + r * WP + c);
-            *reinterpret_cast<float2 *>(o + (size_t)r * W + c) = make_float2((float)d.x, (float)d.y);
+            *reinterpret_cast<float2 *>(o + (size_t)r * W + c) = make_float2(acc_value<FX>(d.x), acc_value<FX>(d.y));
         }
     } else {
         for (int p = threadIdx.x; p < rows * W; p += blockDim.x) {
             int r = p / W;
-            o[p] = (float)img[r * WP + (p - r * W)];
+            o[p] = acc_value<FX>(img[r * WP + (p - r * W)]);
         }
     }
 }
 
 // =============================================================================================
 // K2: image of warped events.  loss/flow.py:81-110 iwe_formatting = utils/iwe.py:63-136
-// get_interpolation + 4x interpolate (scatter_add_).  One workgroup owns ONE quantity
-// (QT = false: event count C, QT = true: weighted timestamp sum T) of ONE polarity of one image
-// (or a row band of it) in LDS, accumulated in fp64 with ds_add_f64.
+// get_interpolation + 4x interpolate (scatter_add_).  One workgroup owns BOTH quantities (event count C and
+// weighted timestamp sum T) of ONE polarity of a ROW BAND of one image in LDS (two planes of 64 rows at
+// 128x128 = 136 KiB): an event is read, bounds-tested and split into corner weights once for its eight
+// accumulations, and a wavefront whose events lie outside the band (events are sorted by 8x8 tile, so that is
+// decided a wavefront at a time) leaves after a dozen instructions.  Accumulators: Q17.46 integers (FX,
+// ds_add_u64) or fp64 (general masks / very long runs).
 //   out [(j * F*B + ib) * 2 + c][H*W] float, summed over grad AND detached events (:725-726).
-// The four (polarity, quantity) variants of an image read the same trajectory plane; xcd_split keeps
-// them on one XCD so the plane is fetched from HBM once.
+// The (polarity, band) variants of an image read the same trajectory plane; xcd_split keeps them on one XCD so
+// the plane is fetched from HBM once.
 // =============================================================================================
-template <bool QT>
-__device__ __forceinline__ void splat_one(const Win &w, const Img &im, float2 p, float ts, float m, double *img,
-                                          int r0, int r1)
+template <bool FX>
+__device__ __forceinline__ void acc_add(double *cell, float v)
 {
-    Splat sp = make_splat(p.x, p.y);                 // traj stores (y, x) in (.x, .y)
-    float tau = 0.0f;
-#ifndef TEF_FAST_DIV
-    if (QT) tau = 1.0f - fabsf(im.tref - ts) / im.delta;     // :94-95
-#else
-    if (QT) tau = 1.0f - fabsf(im.tref - ts) * im.inv_delta;
-#endif
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int iy = sp.iy[k >> 1], ix = sp.ix[k & 1];
-        float wgt = sp.wy[k >> 1] * sp.wx[k & 1];
-        // positions of contributing events are inside the frame (border mask), so a corner outside it has weight 0;
-        // only the row-band test is a real filter
-        if (wgt == 0.0f || iy < r0 || iy >= r1) continue;
-        float v = QT ? (wgt * tau) * m : wgt * m;
-        atomicAdd(img + (iy - r0) * (w.W + kRowPad) + ix, (double)v);
+    if (FX) atomicAdd(reinterpret_cast<unsigned long long *>(cell), to_fixed(v));
+    else atomicAdd(cell, (double)v);
+}
+
+// p = (y, x) inside the frame (shared border mask), so 0 <= floor(y) <= H - 1 and 0 <= floor(x) <= W - 1; the right
+// column may be W (lands in the row padding, weight 0) and the bottom row H (rejected by the band test).  The far
+// corners are addressed as +1: floor(v + 1) differs from floor(v) + 1 only where fp32 rounds v + 1 up to an integer,
+// and then its weight max(0, 1 - |v - floor(v + 1)|) is 0.
+template <bool FX>
+__device__ __forceinline__ void splat_one(float2 p, float ts, float m, const Img &im, double rdelta, double *img_c,
+                                          double *img_t, int r0, int nrows, int WP)
+{
+    const float y = p.x, x = p.y;                    // traj stores (y, x) in (.x, .y)
+    const float fy0 = floorf(y);
+    const int rr = (int)fy0 - r0;
+    float wy0 = fmaxf(1.0f - fabsf(y - fy0), 0.0f), wy1 = fmaxf(1.0f - fabsf(y - floorf(y + 1.0f)), 0.0f);   // utils/iwe.py:97-107
+    const bool ok0 = (rr >= 0) & (rr < nrows), ok1 = (rr + 1 >= 0) & (rr + 1 < nrows) & (wy1 != 0.0f);
+    if (!(ok0 | ok1)) return;
+    const float fx0 = floorf(x);
+    float wx0 = fmaxf(1.0f - fabsf(x - fx0), 0.0f), wx1 = fmaxf(1.0f - fabsf(x - floorf(x + 1.0f)), 0.0f);
+    // tau = 1 - |tref - ts| / delta (:94-95); delta is an integer number of passes: exact division by a constant
+    const float tau = 1.0f - div_by_const(fabsf(im.tref - ts), rdelta);
+    const int cell = rr * WP + (int)fx0;
+    if (ok0) {
+        float w00 = wy0 * wx0, w01 = wy0 * wx1;
+        acc_add<FX>(img_c + cell, FX ? w00 : w00 * m);
+        acc_add<FX>(img_c + cell + 1, FX ? w01 : w01 * m);
+        acc_add<FX>(img_t + cell, FX ? w00 * tau : (w00 * tau) * m);
+        acc_add<FX>(img_t + cell + 1, FX ? w01 * tau : (w01 * tau) * m);
+    }
+    if (ok1) {
+        float w10 = wy1 * wx0, w11 = wy1 * wx1;
+        acc_add<FX>(img_c + cell + WP, FX ? w10 : w10 * m);
+        acc_add<FX>(img_c + cell + WP + 1, FX ? w11 : w11 * m);
+        acc_add<FX>(img_t + cell + WP, FX ? w10 * tau : (w10 * tau) * m);
+        acc_add<FX>(img_t + cell + WP + 1, FX ? w11 * tau : (w11 * tau) * m);
     }
 }
 
 // one contiguous run of slots [u0, u0 + len) of unified slot space (all of the workgroup's polarity)
-template <bool QT>
-__device__ __forceinline__ void splat_run(const Win &w, const Img &im, const Events &g, const Events &d, int b, int c,
-                                          int u0, int len, const float2 *__restrict__ pl,
-                                          const uint32_t *__restrict__ mt, double *img, int r0, int r1)
+template <bool FX>
+__device__ __forceinline__ void splat_run(const Win &w, const Img &im, double rdelta, const Events &g, const Events &d,
+                                          int b, int c, int u0, int len, const float2 *__restrict__ pl,
+                                          const uint32_t *__restrict__ mt, double *img_c, double *img_t, int r0,
+                                          int nrows)
 {
     const bool isd = u0 >= w.M;
     const Events &E = isd ? d : g;
     const float *tsp = E.ts + (size_t)b * E.cap - (isd ? w.M : 0);      // indexed by unified slot
     const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap - (isd ? w.M : 0);
-    const int stride = blockDim.x;
+    const int stride = blockDim.x, WP = w.W + kRowPad;
     for (int v0 = threadIdx.x; v0 < len; v0 += kUnroll * stride) {
         uint32_t mv[kUnroll];
         float2 p[kUnroll];
@@ -535,57 +567,124 @@ __device__ __forceinline__ void splat_run(const Win &w, const Img &im, const Eve
             int u = u0 + (ok ? v : v0);
             mv[q] = ok ? mt[u] : 0u;
             p[q] = pl[u];
-            ts[q] = QT ? tsp[u] : 0.0f;
+            ts[q] = tsp[u];
         }
 #pragma unroll
         for (int q = 0; q < kUnroll; ++q) {
             if (!((mv[q] >> im.s) & 1u)) continue;   // shared border mask (:671-681)
             float m = 1.0f;
-            if (mv[q] & kMetaNonUnit) m = mask[u0 + v0 + q * stride];
-            splat_one<QT>(w, im, p[q], ts[q], m, img, r0, r1);
+            if (!FX && (mv[q] & kMetaNonUnit)) m = mask[u0 + v0 + q * stride];
+            splat_one<FX>(p[q], ts[q], m, im, rdelta, img_c, img_t, r0, nrows, WP);
         }
     }
 }
 
-// events of polarity c of pass t: classes are stored [pos-only | neg-only | both | padding]
-template <bool QT>
-__device__ __forceinline__ void splat_pass(const Win &w, const Img &im, const Events &g, const Events &d,
+// events of polarity c of pass t: classes are stored [pos-only | neg-only | general | padding]; "general" = both
+// polarities set or a mask value other than 0 / 1 (never produced by the reference loader, dataloader/base.py:265-278)
+template <bool FX>
+__device__ __forceinline__ void splat_pass(const Win &w, const Img &im, double rdelta, const Events &g, const Events &d,
                                            const int *cl, int b, int c, int base, int slot0,
                                            const float2 *__restrict__ pl, const uint32_t *__restrict__ mt,
-                                           double *img, int r0, int r1)
+                                           double *img_c, double *img_t, int r0, int nrows)
 {
     int n0 = cl[0], n01 = cl[1], n012 = cl[2];
     if (c == 0) {
-        splat_run<QT>(w, im, g, d, b, c, base + slot0, n0, pl, mt, img, r0, r1);
-        splat_run<QT>(w, im, g, d, b, c, base + slot0 + n01, n012 - n01, pl, mt, img, r0, r1);
+        splat_run<FX>(w, im, rdelta, g, d, b, c, base + slot0, n0, pl, mt, img_c, img_t, r0, nrows);
+        if (!FX) splat_run<FX>(w, im, rdelta, g, d, b, c, base + slot0 + n01, n012 - n01, pl, mt, img_c, img_t, r0, nrows);
     } else {
-        splat_run<QT>(w, im, g, d, b, c, base + slot0 + n0, n012 - n0, pl, mt, img, r0, r1);
+        splat_run<FX>(w, im, rdelta, g, d, b, c, base + slot0 + n0, (FX ? n01 : n012) - n0, pl, mt, img_c, img_t, r0, nrows);
     }
 }
 
-template <bool QT>
-__device__ __forceinline__ void splat_body(const Win &w, const Events &g, const Events &d,
-                                           const float2 *__restrict__ traj, const uint32_t *__restrict__ meta,
-                                           float *__restrict__ out, int j, int ib, int c, int band, int rows_per_band,
-                                           double *img)
+template <bool FX>
+__device__ __forceinline__ void splat_image(const Win &w, const Img &im, const Events &g, const Events &d,
+                                            const float2 *__restrict__ traj, const uint32_t *__restrict__ meta,
+                                            float *__restrict__ iwe_c, float *__restrict__ iwe_t, int j, int ib, int c,
+                                            int r0, int nrows, double *img_c, double *img_t)
 {
     const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad;
-    int b = ib % w.B;
-    int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
-    int nlds = (r1 - r0) * WP;
-    lds_plane_zero(img, nlds);
-    __syncthreads();
-    Img im = decode_image(w, j);
+    const int b = ib % w.B;
+    const double rdelta = 1.0 / (double)im.delta;
     const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
     const uint32_t *mt = meta + (size_t)ib * w.Mt;
     for (int t = im.le; t < im.he; ++t)
-        splat_pass<QT>(w, im, g, d, g.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3, b, c, 0, w.off[t], pl, mt, img, r0, r1);
+        splat_pass<FX>(w, im, rdelta, g, d, g.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3, b, c, 0, w.off[t], pl, mt, img_c,
+                       img_t, r0, nrows);
     if (w.Md > 0)
         for (int t = im.le; t < im.he; ++t)
-            splat_pass<QT>(w, im, g, d, d.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3, b, c, w.M, w.doff[t], pl, mt, img, r0, r1);
+            splat_pass<FX>(w, im, rdelta, g, d, d.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3, b, c, w.M, w.doff[t], pl, mt,
+                           img_c, img_t, r0, nrows);
     __syncthreads();
-    float *o = out + (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
-    lds_plane_store(img, r1 - r0, W, WP, o);
+    const size_t o = (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
+    lds_plane_store<FX>(img_c, nrows, W, WP, iwe_c + o);
+    lds_plane_store<FX>(img_t, nrows, W, WP, iwe_t + o);
+}
+
+// The integer path of one (image, polarity, band): the runs of the workgroup's polarity (one per pass and list) are
+// listed in LDS and streamed as one sequence of chunks of kUnroll events per thread, the loads of chunk q + 1 issued
+// before chunk q is processed (across run boundaries too): with one workgroup per CU (its planes fill the LDS) there
+// are only four waves per SIMD to hide a global-load round trip behind, and un-prefetched the waves sat in s_waitcnt
+// for 56 % of their cycles (SQ_WAIT_ANY) with the vector ALU 52 % busy.
+constexpr int kMaxRuns = 2 * TEF_MAX_PASSES;
+struct SplatBatch {
+    uint32_t mv[kUnroll];
+    float2 p[kUnroll];
+    float ts[kUnroll];
+};
+
+__device__ __forceinline__ void splat_image_fx(const Win &w, const Img &im, const Events &g, const Events &d,
+                                               const float2 *__restrict__ traj, const uint32_t *__restrict__ meta,
+                                               float *__restrict__ iwe_c, float *__restrict__ iwe_t, int j, int ib,
+                                               int c, int r0, int nrows, double *img_c, double *img_t,
+                                               const int *run_u0, const int *run_len, int nruns, int ngrad_runs)
+{
+    const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad;
+    const int b = ib % w.B;
+    const double rdelta = 1.0 / (double)im.delta;
+    const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
+    const uint32_t *mt = meta + (size_t)ib * w.Mt;
+    const float *tsg = g.ts + (size_t)b * g.cap;                                   // indexed by unified slot
+    const float *tsd = (w.Md > 0) ? d.ts + (size_t)b * d.cap - w.M : tsg;
+    const int stride = blockDim.x, step = kUnroll * stride;
+    auto run_length = [&](int r) { return __builtin_amdgcn_readfirstlane(run_len[r]); };
+    auto load = [&](int r, int base, SplatBatch &B) {
+        const int len = run_length(r), u0 = __builtin_amdgcn_readfirstlane(run_u0[r]);
+        const float *tsp = (r >= ngrad_runs) ? tsd : tsg;
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) {
+            int v = base + (int)threadIdx.x + q * stride;
+            bool ok = v < len;
+            int u = u0 + (ok ? v : 0);
+            B.mv[q] = ok ? mt[u] : 0u;
+            B.p[q] = pl[u];
+            B.ts[q] = tsp[u];
+        }
+    };
+    int r = 0, base = 0;
+    while (r < nruns && run_length(r) == 0) ++r;
+    SplatBatch cur;
+    if (r < nruns) load(r, base, cur);
+    while (r < nruns) {
+        int rn = r, bn = base + step;
+        if (bn >= run_length(r)) {
+            bn = 0;
+            ++rn;
+            while (rn < nruns && run_length(rn) == 0) ++rn;
+        }
+        SplatBatch nxt;
+        if (rn < nruns) load(rn, bn, nxt);
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q)
+            if ((cur.mv[q] >> im.s) & 1u)            // shared border mask (:671-681)
+                splat_one<true>(cur.p[q], cur.ts[q], 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
+        cur = nxt;
+        r = rn;
+        base = bn;
+    }
+    __syncthreads();
+    const size_t o = (((size_t)j * FB + ib) * 2 + c) * (size_t)(H * W) + (size_t)r0 * W;
+    lds_plane_store<true>(img_c, nrows, W, WP, iwe_c + o);
+    lds_plane_store<true>(img_t, nrows, W, WP, iwe_t + o);
 }
 
 __global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, Events d,
@@ -597,14 +696,42 @@ __global__ __launch_bounds__(kSplatThreads) void splat_kernel(Win w, Events g, E
     extern __shared__ double lds_img[];
     const int FB = w.F * w.B;
     int item, sub;
-    xcd_split(blockIdx.x, 4 * nbands, item, sub);     // item = (sorted image, head, sample); sub = (band, pol, quantity)
+    xcd_split(blockIdx.x, 2 * nbands, item, sub);     // item = (sorted image, head, sample); sub = (band, polarity)
     if (item >= w.nimg * FB) return;
-    int j = w.order[item / FB], ib = item % FB;
-    int qt = sub & 1, c = (sub >> 1) & 1, band = sub >> 2;
-    if (qt)
-        splat_body<true>(w, g, d, traj, meta, iwe_t, j, ib, c, band, rows_per_band, lds_img);
+    const int j = w.order[item / FB], ib = item % FB;
+    const int c = sub & 1, band = sub >> 1;
+    const int b = ib % w.B, WP = w.W + kRowPad;
+    const int r0 = band * rows_per_band, nrows = min(w.H, r0 + rows_per_band) - r0;
+    double *img_c = lds_img, *img_t = lds_img + nrows * WP;
+    lds_plane_zero(lds_img, 2 * nrows * WP);         // all-zero bits: 0.0 and integer 0 alike
+    Img im = decode_image(w, j);
+    // workgroup-uniform choice of the accumulator: integers unless a run holds general masks or could overflow
+    __shared__ int run_u0[kMaxRuns], run_len[kMaxRuns];
+    const int nb = im.he - im.le, nruns = nb * (w.Md > 0 ? 2 : 1);
+    int nev = 0, ngen = 0;
+    for (int t = im.le; t < im.he; ++t) {
+        const int *cl = g.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3;
+        nev += c ? cl[1] - cl[0] : cl[0];
+        ngen += cl[2] - cl[1];
+        if (w.Md > 0) {
+            const int *dl = d.cls + ((size_t)b * TEF_MAX_PASSES + t) * 3;
+            nev += c ? dl[1] - dl[0] : dl[0];
+            ngen += dl[2] - dl[1];
+        }
+    }
+    if ((int)threadIdx.x < nruns) {      // run list of the integer path: [pos-only] or [neg-only] slots of every pass / list
+        const int r = threadIdx.x;
+        const bool isd = r >= nb;
+        const int t = im.le + (isd ? r - nb : r);
+        const int *cl = (isd ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
+        run_u0[r] = (isd ? w.M + w.doff[t] : w.off[t]) + (c ? cl[0] : 0);
+        run_len[r] = c ? cl[1] - cl[0] : cl[0];
+    }
+    __syncthreads();
+    if (ngen == 0 && nev < kFxMaxEvents)
+        splat_image_fx(w, im, g, d, traj, meta, iwe_c, iwe_t, j, ib, c, r0, nrows, img_c, img_t, run_u0, run_len, nruns, nb);
     else
-        splat_body<false>(w, g, d, traj, meta, iwe_c, j, ib, c, band, rows_per_band, lds_img);
+        splat_image<false>(w, im, g, d, traj, meta, iwe_c, iwe_t, j, ib, c, r0, nrows, img_c, img_t);
 }
 
 // =============================================================================================
@@ -719,12 +846,8 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     float kimg = FAST ? kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]) : kscale / stats[q * 2 + 1];
     const float2 *pos = ar + q * 2 * HW;
     const float2 *neg = pos + HW;
-#ifndef TEF_FAST_DIV
     // (FAST: delta is kernel-invariant there, an integer number of passes: the same bits from the cheaper exact form)
     float tau = FAST ? 1.0f - div_by_const(fabsf(tref - ts), 1.0 / (double)delta) : 1.0f - fabsf(tref - ts) / delta;
-#else
-    float tau = 1.0f - fabsf(tref - ts) * (1.0f / delta);
-#endif
     float gy = 0.0f, gx = 0.0f;
     if (INTERIOR) {
         const float2 *pl = (mp != 0.0f) ? pos : neg;
@@ -802,9 +925,6 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
                                                      int k, float gout, float2 p, float ts, float mp, float mn)
 {
     float2 g = make_float2(0.0f, 0.0f);
-#ifdef TEF_ABL_NOIWE
-    return make_float2(p.x * 1e-9f, p.y * 1e-9f);       // diagnostic build: no IWE lookups
-#endif
     for (int s = 0; s < w.S; ++s) {
         if (!((bits >> s) & 1u)) continue;
         int scale = w.P >> s, wi = t / scale;
@@ -830,7 +950,6 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
 // =============================================================================================
 // Streaming accesses of K6 (trajectory planes in, per-map vectors out) carry the non-temporal hint so that they do not
 // push the (A, R) images and flow maps — the gathered, re-used data — out of the XCD's L2.
-#ifndef TEF_NO_NT
 typedef float f32x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 NT_LD2(const float2 *p)
 {
@@ -838,19 +957,12 @@ __device__ __forceinline__ float2 NT_LD2(const float2 *p)
     return make_float2(v.x, v.y);
 }
 __device__ __forceinline__ void NT_ST(float *p, float v) { __builtin_nontemporal_store(v, p); }
-#else
-__device__ __forceinline__ float2 NT_LD2(const float2 *p) { return *p; }
-__device__ __forceinline__ void NT_ST(float *p, float v) { *p = v; }
-#endif
 
-#ifndef TEF_CHAIN_WAVES
-#define TEF_CHAIN_WAVES 1
-#endif
 // ONE: a single temporal scale (scales_loss = 1, the headline configuration).  The kernel is VALU-bound (~450 vector
 // instructions per chain step, 2.9e7 steps per BASELINE window): the per-step scale loop with its integer division
 // (t / scale) and the normalisation constant are hoisted, and 1 / n is a reciprocal (image_grad<true>).
 template <bool ONE>
-__global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
+__global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
                                                              const uint32_t *__restrict__ meta,
                                                              const float2 *__restrict__ ar,
@@ -910,9 +1022,6 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
     const bool one_pol = !((mp != 0.0f) & (mn != 0.0f));
     auto step_interior = [&](int k, int km, float2 cur, float2 nxt, float2 &gk, float &jyy, float &jyx, float &jxy,
                              float &jxx) -> bool {
-#if defined(TEF_NO_CHAIN_INTERIOR) || defined(TEF_ABL_NOFLOW)
-        return false;
-#endif
         if (!ONE) return false;
         int y0, x0;
         Taps tp = taps_core(nxt.x, nxt.y, H, W, y0, x0);
@@ -943,10 +1052,8 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
             float2 gk;
             if (!step_interior(k, k - 1, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
-#ifndef TEF_ABL_NOFLOW
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
                 quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-#endif
                 gk = pos_grad(k, cur);
             }
             ay += gk.x;
@@ -980,10 +1087,8 @@ __global__ __launch_bounds__(256, TEF_CHAIN_WAVES) void iter_chain_bwd_kernel(Wi
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
             float2 gk;
             if (!step_interior(k, k, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
-#ifndef TEF_ABL_NOFLOW
                 Taps tp = make_taps(nxt.x, nxt.y, H, W);
                 quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-#endif
                 gk = pos_grad(k, cur);
             }
             ay += gk.x;
@@ -1132,8 +1237,9 @@ constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x t
 __device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, int H, int W, int tile, int tw,
                                         int ntiles)
 {
-    // pos-only, neg-only, both polarities (general masks), collate padding
+    // pos-only (mask exactly (1, 0)), neg-only ((0, 1)), general (both polarities or other values), collate padding
     int cls = (mp != 0.0f) ? (mn != 0.0f ? 2 : 0) : (mn != 0.0f ? 1 : 3);
+    if ((mp != 0.0f && mp != 1.0f) || (mn != 0.0f && mn != 1.0f)) cls = 2;     // general mask values: fp64 splat path
     int ty = min(max((int)y, 0), H - 1) / tile, tx = min(max((int)x, 0), W - 1) / tile;
     return cls * ntiles + ty * tw + tx;
 }
@@ -1228,7 +1334,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     if (c->B < 1 || c->H < 2 || c->W < 2 || c->F < 1) return tef::fail("bad B/H/W/F");
     if (c->P < 1 || c->P > TEF_MAX_PASSES) return tef::fail("passes_loss out of range [1, 64]");
     if (c->S < 1 || c->S > TEF_MAX_SCALES) return tef::fail("scales_loss out of range [1, 6]");
-    if ((size_t)(c->W + kRowPad) * sizeof(double) > kLdsBudget) return tef::fail("image row does not fit the LDS band");
+    if (2 * (size_t)(c->W + kRowPad) * sizeof(double) > kLdsBudget) return tef::fail("image row does not fit the LDS band");
     if (c->kind == TEF_KIND_ITERATIVE) {
         // iterative_mode "four" raises TypeError in the reference itself (loss/flow.py:666-692); only one/two exist here
         if (c->mode_div != 1 && c->mode_div != 2) return tef::fail("iterative_mode must be 'one' or 'two'");
@@ -1306,13 +1412,14 @@ inline Events to_events(const tef_events *e)
         hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev_a_, ev_b_, 0, __VA_ARGS__);          \
     } while (0)
 
-inline void band_geometry(const Win &w, int *rows_per_band, int *nbands, size_t *lds)
+inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds)
 {
-    int rows = (int)(kLdsBudget / ((size_t)(w.W + kRowPad) * sizeof(double)));
+    int rows = (int)(kLdsBudget / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
     if (rows > w.H) rows = w.H;
-    *rows_per_band = rows;
     *nbands = (w.H + rows - 1) / rows;
-    *lds = (size_t)rows * (w.W + kRowPad) * sizeof(double);
+    rows = (w.H + *nbands - 1) / *nbands;            // equal bands
+    *rows_per_band = rows;
+    *lds = (size_t)planes * rows * (w.W + kRowPad) * sizeof(double);
 }
 
 // opt in to > 64 KiB dynamic LDS for the two LDS-resident splat kernels: once per process (thread-safe static init)
@@ -1344,10 +1451,7 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, fl
     if (B < 1 || N < 0 || slot0 < 0 || slot0 + N > cap || pass_idx < 0 || pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
         return tef::fail("tef_pack_events: bad sizes"), TEF_ERR_INVALID;
     if (N == 0) return 0;
-#ifndef TEF_SORT_TILE
-#define TEF_SORT_TILE 8
-#endif
-    int tile = TEF_SORT_TILE;
+    int tile = 8;
     while (4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;
     int nbins = 4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
     size_t lds = (size_t)(nbins + kPackThreads) * sizeof(int);
@@ -1407,8 +1511,8 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
     size_t lds;
-    band_geometry(w, &rows, &nbands, &lds);
-    TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_kernel, dim3(xcd_grid(w.nimg * FB, 4 * nbands)), dim3(kSplatThreads), lds, st, w,
+    band_geometry(w, 2, &rows, &nbands, &lds);
+    TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_kernel, dim3(xcd_grid(w.nimg * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w,
                      g, d, traj, meta, iwe_c, iwe_t, rows, nbands);
     if (int rc = tef::check_launch("splat_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_STATS, image_stats_kernel, dim3((unsigned)(w.nimg * FB), kStatParts), dim3(256), 0, st, w,
@@ -1442,13 +1546,10 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     if (w.M > 0) {
         int chunks = (w.M + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
-#ifndef TEF_NO_CHAIN_ONE
         if (w.kind == TEF_KIND_ITERATIVE && w.S == 1)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
                              stats, grad_out, cy, cx, chunks);
-        else
-#endif
-        if (w.kind == TEF_KIND_ITERATIVE)
+        else if (w.kind == TEF_KIND_ITERATIVE)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
                              stats, grad_out, cy, cx, chunks);
         else
@@ -1458,7 +1559,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
     int rows, nbands;
     size_t lds;
-    band_geometry(w, &rows, &nbands, &lds);
+    band_geometry(w, 1, &rows, &nbands, &lds);
     TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(xcd_grid(w.P * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w,
                      g, traj, cy, cx, dflows, rows, nbands);
     return tef::check_launch("dflow_splat_kernel");
