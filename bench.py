@@ -139,7 +139,7 @@ def init_ranks(a):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with "
                          f"torch.distributed.run --nproc-per-node {a.gpus} (or plain `python bench.py --gpus {a.gpus}`)")
     if os.environ.get("TEF_BENCH_LAUNCH_ONLY") == "1":      # launcher test hook (tests/test_bench_launch.py): no GPU needed
-        print(json.dumps({"launch_only": True, "rank": rank, "world": world, "local": local}), flush=True)
+        os.write(1, (json.dumps({"launch_only": True, "rank": rank, "world": world, "local": local}) + "\n").encode())
         raise SystemExit(0)
     import torch
 
