@@ -243,6 +243,44 @@ int tef_upsample_bilinear(const float *x, int planes, int H, int W, int scale_h,
 int tef_upsample_bilinear_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
                                    float *dx, void *stream);
 
+/* The same with a second addend and a crop: y [planes][H*scale_h - crop_top][W*scale_w - crop_left] =
+ * mul * upsample(x + x2)[crop_top:, crop_left:] (x2 may be NULL).  The sum is the decoder's skip connection
+ * (models/arch.py:236 skip_fn "sum" followed by UpsampleConvLayer's interpolate); the crop undoes the top / left padding of
+ * RecEVFlowNet.forward (models/model_util.py:52-65, models/model.py:83).  Backward: dy is the cropped tensor. */
+int tef_upsample_bilinear_crop(const float *x, const float *x2, int planes, int H, int W, int scale_h, int scale_w,
+                               float mul, int crop_top, int crop_left, float *y, void *stream);
+int tef_upsample_bilinear_crop_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
+                                        int crop_top, int crop_left, float *dx, void *stream);
+
+/* ---- fused ConvGRU cell: ConvGRU.forward, models/submodules.py:134-152, and its backward -------------------------------
+ * x (the cell input) and h (previous state, zeros for a fresh sequence, :141-143) are [B,C,H,W]; gates are 3x3.
+ * Forward: (u, r) = sigmoid(conv([x, h]; update | reset weights)), o = tanh(conv([x, h * r]; out weights)),
+ * hn = h * (1 - u) + o * u.  wp_ur / wp_o are packed weights (tef_conv_pack_weight with N = 2C rows update-then-reset,
+ * and N = C), bias_ur = [2C] update-then-reset.  u, r, o are kept by the caller for the backward. */
+typedef struct tef_gru_desc {
+    int B, C, H, W;
+} tef_gru_desc;
+size_t tef_convgru_workspace_bytes(const tef_gru_desc *d);
+int tef_convgru_cell_fwd(const tef_gru_desc *d, const float *x, const float *h, const float *wp_ur, const float *wp_o,
+                         const float *bias_ur, const float *bias_o, float *u, float *r, float *o, float *hn,
+                         void *workspace, size_t workspace_bytes, void *stream);
+/* Backward.  dhn: HOST array of ndhn (1..4) device pointers whose SUM is d loss / d hn (the new state feeds the next
+ * encoder, a decoder skip connection and the next pass: the addends are summed where they are consumed).
+ * Outputs: dx, dh (overwritten); g_ur [B,2C,H,W] and g_o [B,C,H,W] = gradients w.r.t. the gate pre-activations, kept for
+ * tef_conv_wgrad_parts when dw_* are NULL (BPTT window: one weight-gradient reduction per layer over all passes),
+ * otherwise dw_u / dw_r / dw_o [C,2C,3,3] are accumulated (+=) here; db_* [C] accumulated (+=), may be NULL. */
+int tef_convgru_cell_bwd(const tef_gru_desc *d, const float *x, const float *h, const float *u, const float *r,
+                         const float *o, const float *const *dhn, int ndhn, const float *w2_ur, const float *w2_o,
+                         float *g_ur, float *g_o, float *dx, float *dh, float *dw_u, float *dw_r, float *dw_o,
+                         float *db_u, float *db_r, float *db_o, void *workspace, size_t workspace_bytes, void *stream);
+/* g [B,C,HW] = (sum of the ndy (1..4) tensors dy[k]) * act'(out), dbias [C] += per-channel sums of g (NULL to skip): the
+ * pre-activation gradient of any conv layer whose output has several consumers (then tef_conv_backward* with
+ * TEF_ACT_NONE on g).  dy: HOST array of device pointers.  out = the layer's activated output (unused for TEF_ACT_NONE). */
+int tef_grad_act(const float *const *dy, int ndy, const float *out, int act, int B, int C, int HW, float *g, float *dbias,
+                 void *stream);
+/* out = act(a + b), n elements: the residual connection of ResidualBlock (models/submodules.py:219-226). */
+int tef_add_act(const float *a, const float *b, int act, size_t n, float *out, void *stream);
+
 /* ---- validation metrics (loss/flow_val.py; evaluation only, batch 1, no gradients) ---------------------------------
  * Flow maps are planar [H][W] (fx, fy separately); event lists are loc [N][2] = (y, x), ts [N], mask [N][2]. */
 /* one warping step: flow lookup at loc (flow_out [N][2] = (f_y, f_x) if not NULL); if do_warp: loc += (tref - ts) * flow,

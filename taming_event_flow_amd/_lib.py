@@ -42,6 +42,12 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("B", "C0", "C1", "H", "W", "N", "ksize", "stride", "act")]
 
 
+class GruDesc(ctypes.Structure):
+    """struct tef_gru_desc (include/tef.h)"""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "C", "H", "W")]
+
+
 ACT = {None: 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
 # name -> (restype, argtypes); every symbol include/tef.h declares
@@ -95,6 +101,18 @@ SIGNATURES = {
     "tef_conv_wgrad_parts": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                             ctypes.POINTER(ctypes.c_void_p), _fp, _fp, ctypes.c_int, _fp]),
+    "tef_upsample_bilinear_crop": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    "tef_upsample_bilinear_crop_backward": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,
+                                                           _fp]),
+    "tef_convgru_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(GruDesc)]),
+    "tef_convgru_cell_fwd": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 10 + [_fp, ctypes.c_size_t, _fp]),
+    "tef_convgru_cell_bwd": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 5
+                             + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int] + [_fp] * 12 + [_fp, ctypes.c_size_t, _fp]),
+    "tef_grad_act": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                    ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "tef_add_act": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_size_t, _fp, _fp]),
     "tef_gru_blend": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_size_t, _fp, _fp]),
     "tef_gru_blend_backward": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_val_event_step": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,

@@ -21,21 +21,29 @@ __device__ __forceinline__ void src_index(int o, float inv, int n, int &i0, int 
     l0 = 1.0f - l1;
 }
 
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restrict__ x, int planes, int H, int W, int sh,
-                                                           int sw, float mul, float *__restrict__ y)
+// y [planes][Ho - ct][Wo - cl] = mul * upsample(x + x2)[ct:, cl:]   (x2 may be null; ct / cl = rows / columns cropped at
+// the top / left: RecEVFlowNet pads its input there, models/model_util.py:52-65, and crops the flows again, model.py:83)
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restrict__ x, const float *__restrict__ x2,
+                                                           int planes, int H, int W, int sh, int sw, float mul, int ct,
+                                                           int cl, float *__restrict__ y)
 {
-    const int Ho = H * sh, Wo = W * sw;
+    const int Hc = H * sh - ct, Wc = W * sw - cl;
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)planes * Ho * Wo) return;
-    int ox = (int)(idx % Wo);
-    size_t t = idx / Wo;
-    int oy = (int)(t % Ho), pl = (int)(t / Ho);
+    if (idx >= (size_t)planes * Hc * Wc) return;
+    int ox = (int)(idx % Wc) + cl;
+    size_t t = idx / Wc;
+    int oy = (int)(t % Hc) + ct, pl = (int)(t / Hc);
     int y0, y1, x0, x1;
     float ly0, ly1, lx0, lx1;
     src_index(oy, 1.0f / (float)sh, H, y0, y1, ly0, ly1);
     src_index(ox, 1.0f / (float)sw, W, x0, x1, lx0, lx1);
     const float *p = x + (size_t)pl * H * W;
-    float v = ly0 * (lx0 * p[y0 * W + x0] + lx1 * p[y0 * W + x1]) + ly1 * (lx0 * p[y1 * W + x0] + lx1 * p[y1 * W + x1]);
+    float v00 = p[y0 * W + x0], v01 = p[y0 * W + x1], v10 = p[y1 * W + x0], v11 = p[y1 * W + x1];
+    if (x2) {
+        const float *q = x2 + (size_t)pl * H * W;
+        v00 += q[y0 * W + x0]; v01 += q[y0 * W + x1]; v10 += q[y1 * W + x0]; v11 += q[y1 * W + x1];
+    }
+    float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
     y[idx] = mul * v;
 }
 
@@ -50,21 +58,24 @@ __device__ __forceinline__ float tap_weight(int o, float inv, int n, int i)
     return (i0 == i ? l0 : 0.0f) + (i1 == i ? l1 : 0.0f);
 }
 
+// dy is the cropped tensor [planes][Ho - ct][Wo - cl]: cropped rows / columns carry no gradient
 __global__ __launch_bounds__(128) void upsample_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
-                                                           int sh, int sw, float mul, float *__restrict__ dx)
+                                                           int sh, int sw, float mul, int ct, int cl,
+                                                           float *__restrict__ dx)
 {
     extern __shared__ float trow[];                 // [Wo]
-    const int Ho = H * sh, Wo = W * sw;
+    const int Ho = H * sh, Wo = W * sw, Wc = Wo - cl;
     const int iy = blockIdx.x % H, pl = blockIdx.x / H;
-    const float *g = dy + (size_t)pl * Ho * Wo;
+    const float *g = dy + (size_t)pl * (Ho - ct) * Wc;
     const float invh = 1.0f / (float)sh, invw = 1.0f / (float)sw;
-    const int oy_lo = max(0, (iy - 1) * sh), oy_hi = min(Ho, (iy + 2) * sh);
+    const int oy_lo = max(ct, (iy - 1) * sh), oy_hi = min(Ho, (iy + 2) * sh);
     for (int ox = threadIdx.x; ox < Wo; ox += blockDim.x) {
         float acc = 0.0f;
-        for (int oy = oy_lo; oy < oy_hi; ++oy) {
-            float wy = tap_weight(oy, invh, H, iy);     // uniform across the workgroup
-            if (wy != 0.0f) acc += wy * g[(size_t)oy * Wo + ox];
-        }
+        if (ox >= cl)
+            for (int oy = oy_lo; oy < oy_hi; ++oy) {
+                float wy = tap_weight(oy, invh, H, iy);     // uniform across the workgroup
+                if (wy != 0.0f) acc += wy * g[(size_t)(oy - ct) * Wc + (ox - cl)];
+            }
         trow[ox] = acc;
     }
     __syncthreads();
@@ -83,27 +94,41 @@ __global__ __launch_bounds__(128) void upsample_bwd_kernel(const float *__restri
 
 extern "C" {
 
+int tef_upsample_bilinear_crop(const float *x, const float *x2, int planes, int H, int W, int scale_h, int scale_w,
+                               float mul, int crop_top, int crop_left, float *y, void *stream)
+{
+    if (!x || !y || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1 || crop_top < 0 || crop_left < 0 ||
+        crop_top >= H * scale_h || crop_left >= W * scale_w)
+        return tef::fail("tef_upsample_bilinear: bad arguments"), TEF_ERR_INVALID;
+    size_t n = (size_t)planes * (H * scale_h - crop_top) * (W * scale_w - crop_left);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x2,
+                       planes, H, W, scale_h, scale_w, mul, crop_top, crop_left, y);
+    return tef::check_launch("upsample_fwd_kernel");
+}
+
+int tef_upsample_bilinear_crop_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
+                                        int crop_top, int crop_left, float *dx, void *stream)
+{
+    if (!dy || !dx || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1 || crop_top < 0 || crop_left < 0 ||
+        crop_top >= H * scale_h || crop_left >= W * scale_w)
+        return tef::fail("tef_upsample_bilinear_backward: bad arguments"), TEF_ERR_INVALID;
+    size_t lds = (size_t)W * scale_w * sizeof(float);
+    if (lds > 64 * 1024) return tef::fail("tef_upsample_bilinear_backward: output row too wide"), TEF_ERR_INVALID;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((size_t)planes * H)), dim3(128), lds, (hipStream_t)stream, dy,
+                       planes, H, W, scale_h, scale_w, mul, crop_top, crop_left, dx);
+    return tef::check_launch("upsample_bwd_kernel");
+}
+
 int tef_upsample_bilinear(const float *x, int planes, int H, int W, int scale_h, int scale_w, float mul, float *y,
                           void *stream)
 {
-    if (!x || !y || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1)
-        return tef::fail("tef_upsample_bilinear: bad arguments"), TEF_ERR_INVALID;
-    size_t n = (size_t)planes * H * scale_h * W * scale_w;
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, planes,
-                       H, W, scale_h, scale_w, mul, y);
-    return tef::check_launch("upsample_fwd_kernel");
+    return tef_upsample_bilinear_crop(x, nullptr, planes, H, W, scale_h, scale_w, mul, 0, 0, y, stream);
 }
 
 int tef_upsample_bilinear_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
                                    float *dx, void *stream)
 {
-    if (!dy || !dx || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1)
-        return tef::fail("tef_upsample_bilinear_backward: bad arguments"), TEF_ERR_INVALID;
-    size_t lds = (size_t)W * scale_w * sizeof(float);
-    if (lds > 64 * 1024) return tef::fail("tef_upsample_bilinear_backward: output row too wide"), TEF_ERR_INVALID;
-    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((size_t)planes * H)), dim3(128), lds, (hipStream_t)stream, dy,
-                       planes, H, W, scale_h, scale_w, mul, dx);
-    return tef::check_launch("upsample_bwd_kernel");
+    return tef_upsample_bilinear_crop_backward(dy, planes, H, W, scale_h, scale_w, mul, 0, 0, dx, stream);
 }
 
 }

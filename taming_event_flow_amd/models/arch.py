@@ -1,143 +1,141 @@
-"""Network architectures — drop-in for the reference's ``models/arch.py`` (the parts RecEVFlowNet builds).
+"""Layer table and parameter container of the recurrent multi-resolution U-Net behind RecEVFlowNet.
 
-``BaseUNet`` (:6-194) keeps the constructor arguments, derived attributes and builder methods used by
-``MultiResUNetRecurrent`` (:197-242); module attribute names match so the ``state_dict`` keys are identical.
+Counterpart of the reference's ``models/arch.py`` (``MultiResUNetRecurrent``, :197-242, on ``BaseUNet``, :6-194), built
+the other way round: the reference assembles the network from generic builder methods and walks module lists at run
+time; here the architecture is a small static TABLE (`NetPlan`: one row per convolution with its channel counts,
+stride, activation and the level it lives on) from which both the parameter container and the fused pass
+(`engine.PassEngine`) are derived.  Only the configuration RecEVFlowNet uses is representable — recurrent ConvGRU
+encoders, sum skip connections, bilinear up-sampling decoders, one prediction per decoder — anything else is refused
+when the plan is made, not silently approximated.
+
+The module tree keeps the reference's attribute names (``encoders[i].conv.conv2d``, ``encoders[i].recurrent_block.
+{reset,update,out}_gate``, ``resblocks[i].conv{1,2}``, ``decoders[i].conv2d``, ``preds[i].conv2d``) because they are
+the ``state_dict`` keys checkpoints are exchanged by (reference utils/utils.py:20-31).
 """
 
-import torch
+from collections import namedtuple
+
 import torch.nn as nn
 
-from .submodules import ConvLayer, RecurrentConvLayer, ResidualBlock, TransposedConvLayer, UpsampleConvLayer
+from .engine import PassEngine, run_pass
+from .submodules import ConvLayer, RecurrentConvLayer, ResidualBlock, UpsampleConvLayer, upsample_bilinear
+
+Row = namedtuple("Row", "kind level cin cout ksize stride act")
 
 
-class BaseUNet(nn.Module):
-    """Base class for conventional UNet architecture: symmetric, skip connections on every encoding layer."""
+class NetPlan:
+    """Static description of the network: `rows` lists every convolution (in state_dict order)."""
 
-    ff_type = ConvLayer
-    res_type = ResidualBlock
-    upsample_type = UpsampleConvLayer
-    transpose_type = TransposedConvLayer
+    def __init__(self, num_bins, base_channels=64, num_encoders=4, num_residual_blocks=2, num_output_channels=2,
+                 skip_type="sum", norm=None, use_upsample_conv=True, kernel_size=3, encoder_stride=2, channel_multiplier=2,
+                 activations=("relu", None), final_activation=None, final_bias=True, final_w_scale=None,
+                 recurrent_block_type="convgru", min_size=None):
+        unsupported = []
+        if skip_type != "sum":
+            unsupported.append(f"skip_type={skip_type!r}")
+        if norm is not None:
+            unsupported.append(f"norm={norm!r}")
+        if not use_upsample_conv:
+            unsupported.append("transposed-convolution decoders")
+        if recurrent_block_type != "convgru":
+            unsupported.append(f"recurrent_block_type={recurrent_block_type!r}")
+        if encoder_stride != 2 or kernel_size != 3:
+            unsupported.append("encoder_stride / kernel_size other than 2 / 3")
+        if tuple(activations) != ("relu", None):
+            unsupported.append(f"activations={activations!r}")
+        if unsupported:
+            raise NotImplementedError("RecEVFlowNet on the MI355X path is the reference's default architecture; not built: "
+                                      + ", ".join(unsupported))
+        self.num_bins, self.levels, self.nres, self.nout = num_bins, num_encoders, num_residual_blocks, num_output_channels
+        self.stride, self.ksize = encoder_stride, kernel_size
+        self.final_activation, self.final_bias, self.final_w_scale = final_activation, final_bias, final_w_scale
+        self.width = [int(base_channels * channel_multiplier ** i) for i in range(num_encoders)]     # 64, 128, 256, 512
+        self.multiple = encoder_stride ** num_encoders if min_size is None else min_size
+        rows, cin = [], num_bins
+        for i, c in enumerate(self.width):
+            rows.append(Row("head", i, cin, c, kernel_size, encoder_stride, "relu"))
+            rows.append(Row("gru", i, 2 * c, c, 3, 1, None))
+            cin = c
+        top = self.width[-1]
+        for _ in range(num_residual_blocks):
+            rows.append(Row("res", num_encoders - 1, top, top, 3, 1, "relu"))
+        src = top
+        for k in range(num_encoders):                  # decoder k works on level levels-1-k and emits half its width
+            lvl = num_encoders - 1 - k
+            out = self.width[lvl] // channel_multiplier if lvl > 0 else base_channels // channel_multiplier
+            rows.append(Row("dec", lvl, src + (num_output_channels if k else 0), out, kernel_size, 1, "relu"))
+            rows.append(Row("pred", lvl, out, num_output_channels, 1, 1, final_activation))
+            src = out
+        self.rows = rows
 
-    def __init__(self, num_bins, base_channels, num_encoders, num_residual_blocks, num_output_channels, skip_type,
-                 norm, use_upsample_conv=True, kernel_size=3, encoder_stride=2, channel_multiplier=2,
-                 activations=["relu", None], final_activation=None, final_bias=True, final_w_scale=None,
-                 recurrent_block_type=None):
-        super().__init__()
-        self.base_channels = base_channels
-        self.num_encoders = num_encoders
-        self.num_residual_blocks = num_residual_blocks
-        self.num_output_channels = num_output_channels
-        self.norm = norm
-        self.num_bins = num_bins
-        self.recurrent_block_type = recurrent_block_type
-        self.kernel_size = kernel_size
-        self.encoder_stride = encoder_stride
-        self.channel_multiplier = channel_multiplier
-        self.ff_act, self.rec_act = activations
-        self.final_activation = final_activation
-        self.final_bias = final_bias
-        self.final_w_scale = final_w_scale
+    def padding(self, H, W):
+        """Rows / columns to add at the top / left so that every level halves exactly (model_util.py:52-60)."""
+        m = self.multiple
+        return (m - H % m) % m, (m - W % m) % m
 
-        self.skip_type = skip_type
-        assert self.skip_type is None or self.skip_type in ["sum", "concat"]
-        self.up_type = self.upsample_type if use_upsample_conv else self.transpose_type
-
-        # reference arch.py:60-67
-        self.encoder_input_sizes = [
-            int(self.base_channels * pow(self.channel_multiplier, i - 1)) for i in range(self.num_encoders)
-        ]
-        self.encoder_output_sizes = [
-            int(self.base_channels * pow(self.channel_multiplier, i)) for i in range(self.num_encoders)
-        ]
-        self.max_num_channels = self.encoder_output_sizes[-1]
-
-    def skip_fn(self, x, y, mode="sum"):
-        """reference arch.py:69-80"""
-        assert y.shape[2:] <= x.shape[2:]
-        if x.shape[2:] > y.shape[2:]:
-            print("Warning: skipping row/col in skip_fn() due to odd dimensions throughout the architecture.")
-            x = x[:, :, : y.shape[2], : y.shape[3]]
-        if mode == "sum":
-            assert x.shape[1] == y.shape[1]
-            x = x + y
-        elif mode == "concat":
-            x = torch.cat([x, y], dim=1)
-        return x
-
-    def build_recurrent_encoders(self):
-        """reference arch.py:103-121"""
-        encoders = nn.ModuleList()
-        for i, (input_size, output_size) in enumerate(zip(self.encoder_input_sizes, self.encoder_output_sizes)):
-            if i == 0:
-                input_size = self.num_bins
-            encoders.append(
-                self.rec_type(input_size, output_size, kernel_size=self.kernel_size, stride=self.encoder_stride,
-                              recurrent_block_type=self.recurrent_block_type, activation_ff=self.ff_act,
-                              activation_rec=self.rec_act, norm=self.norm)
-            )
-        return encoders
-
-    def build_resblocks(self):
-        """reference arch.py:123-134"""
-        resblocks = nn.ModuleList()
-        for _ in range(self.num_residual_blocks):
-            resblocks.append(self.res_type(self.max_num_channels, self.max_num_channels, activation=self.ff_act,
-                                           norm=self.norm))
-        return resblocks
-
-    def build_multires_prediction_decoders(self):
-        """reference arch.py:152-168: every decoder but the first also sees the previous prediction (2 channels)."""
-        decoder_input_sizes = reversed(self.encoder_output_sizes)
-        decoder_output_sizes = reversed(self.encoder_input_sizes)
-        decoders = nn.ModuleList()
-        for i, (input_size, output_size) in enumerate(zip(decoder_input_sizes, decoder_output_sizes)):
-            input_size = 2 * input_size if self.skip_type == "concat" else input_size
-            prediction_channels = 0 if i == 0 else self.num_output_channels
-            decoders.append(
-                self.up_type(input_size + prediction_channels, output_size, kernel_size=self.kernel_size,
-                             activation=self.ff_act, norm=self.norm)
-            )
-        return decoders
-
-    def build_multires_prediction_layer(self):
-        """reference arch.py:181-194: 1x1 convolutions with the final activation / weight scale."""
-        preds = nn.ModuleList()
-        for output_size in reversed(self.encoder_input_sizes):
-            preds.append(
-                self.ff_type(output_size, self.num_output_channels, 1, activation=self.final_activation,
-                             norm=self.norm, w_scale=self.final_w_scale, bias=self.final_bias)
-            )
-        return preds
+    def of(self, kind):
+        return [r for r in self.rows if r.kind == kind]
 
 
-class MultiResUNetRecurrent(BaseUNet):
-    """Recurrent UNet: every encoder is followed by a ConvGRU; a prediction at each decoding layer, concatenated
-    (first) into the input of the next decoder (reference arch.py:197-242)."""
-
-    rec_type = RecurrentConvLayer
+class MultiResUNetRecurrent(nn.Module):
+    """Parameters + recurrent state of the network; the arithmetic lives in `engine.PassEngine`."""
 
     def __init__(self, kwargs):
-        super().__init__(**kwargs)
-        self.encoders = self.build_recurrent_encoders()
-        self.resblocks = self.build_resblocks()
-        self.decoders = self.build_multires_prediction_decoders()
-        self.preds = self.build_multires_prediction_layer()
-        self.num_states = self.num_encoders
+        super().__init__()
+        self.plan = plan = NetPlan(**kwargs)
+        self.num_encoders = self.num_states = plan.levels
+        self.encoders = nn.ModuleList(
+            RecurrentConvLayer(r.cin, r.cout, kernel_size=r.ksize, stride=r.stride, recurrent_block_type="convgru",
+                               activation_ff=r.act, activation_rec=None) for r in plan.of("head"))
+        self.resblocks = nn.ModuleList(ResidualBlock(r.cin, r.cout, activation=r.act) for r in plan.of("res"))
+        self.decoders = nn.ModuleList(UpsampleConvLayer(r.cin, r.cout, kernel_size=r.ksize, activation=r.act)
+                                      for r in plan.of("dec"))
+        self.preds = nn.ModuleList(ConvLayer(r.cin, r.cout, 1, activation=r.act, w_scale=plan.final_w_scale,
+                                             bias=plan.final_bias) for r in plan.of("pred"))
         self.states = [None] * self.num_states
+        self._engine = None
+
+    # -- switches train.Trainer flips on every PackedWeights of the tree (submodules.enable_*): read them where they live
+    @property
+    def direct_grads(self):
+        return self.encoders[0].conv._packed.direct_grads
+
+    @property
+    def deferred_wgrad(self):
+        return self.encoders[0].conv._packed.defer_wgrad
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = PassEngine(self)
+        return self._engine
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None                 # workspaces are not part of a checkpoint
+        state["states"] = [None] * self.num_states
+        return state
+
+    def step(self, x):
+        """One fused pass on an input of any size: -> 4 flows at the input resolution, coarse to fine; updates `states`."""
+        flows, self.states = run_pass(self.engine, x, self.states)
+        return flows
 
     def forward(self, x):
-        """:param x: N x num_input_channels x H x W  :return: list of N x num_output_channels x h x w (coarse to fine)"""
-        blocks = []
-        for i, encoder in enumerate(self.encoders):
-            x, self.states[i] = encoder(x, self.states[i])
-            blocks.append(x)
-        for resblock in self.resblocks:
-            x, _ = resblock(x)
-        predictions = []
-        for i, (decoder, pred) in enumerate(zip(self.decoders, self.preds)):
-            x = self.skip_fn(x, blocks[self.num_encoders - i - 1], mode=self.skip_type)
-            if i > 0:
-                x = self.skip_fn(predictions[-1], x, mode="concat")
-            x = decoder(x)
-            predictions.append(pred(x))
-        return predictions
+        """Multi-resolution predictions [B, 2, h_k, w_k] (coarse to fine) for an input whose sides are multiples of
+        2**num_encoders, as the reference's forward (:217-242) returns them: layer by layer through the modules' own
+        autograd nodes.  RecEVFlowNet does not come through here (it calls `step`); this path exists for users of the
+        bare architecture and as the independent check of the fused pass (tests/test_model_gpu.py)."""
+        feats, cur = [], x
+        for i, enc in enumerate(self.encoders):
+            cur, self.states[i] = enc(cur, self.states[i])
+            feats.append(cur)
+        for rb in self.resblocks:
+            cur, _ = rb(cur)
+        preds = []
+        for k, (dec, head) in enumerate(zip(self.decoders, self.preds)):
+            fused = dec.conv_after_upsample(upsample_bilinear(cur + feats[-1 - k], 2, 2),
+                                            upsample_bilinear(preds[-1], 2, 2) if preds else None)
+            cur = fused
+            preds.append(head(cur))
+        return preds

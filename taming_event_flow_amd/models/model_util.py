@@ -1,43 +1,46 @@
-"""State helpers and the E-RAFT image padder (reference models/model_util.py)."""
-import copy
+"""Helpers RecEVFlowNet's callers know by name (reference models/model_util.py): state copies and the padder.
 
+`ImagePadder` survives as the geometry record of the top / left padding (reference :29-71, after E-RAFT): the fused pass
+pads and crops inside its own kernels, so `pad` / `unpad` are only used by code that calls them explicitly."""
 import torch
 
 
-def recursive_clone(tensor):
-    """Clone a tensor or a nested iterable of tensors (reference model_util.py:6-18)."""
-    if hasattr(tensor, "clone"):
-        return tensor.clone()
-    try:
-        return type(tensor)(recursive_clone(t) for t in tensor)
-    except TypeError:
-        print("{} is not iterable and has no clone() method.".format(tensor))
+def recursive_clone(obj):
+    """Structure-preserving clone: tensors are cloned, lists / tuples rebuilt, None kept (reference :6-18)."""
+    if obj is None:
+        return None
+    if isinstance(obj, torch.Tensor):
+        return obj.clone()
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(recursive_clone(o) for o in obj)
+    raise TypeError(f"cannot clone a recurrent state of type {type(obj).__name__}")
 
 
 def copy_states(states):
-    """Deepcopy a list of Nones, clone otherwise (reference model_util.py:20-27)."""
-    if states[0] is None:
-        return copy.deepcopy(states)
-    return recursive_clone(states)
+    """A copy of the per-encoder state list the caller may keep or modify (reference :20-27)."""
+    return recursive_clone(list(states))
 
 
-class ImagePadder(object):
-    """Pads on the LEFT and TOP to a multiple of min_size (reference model_util.py:29-71, from E-RAFT)."""
-
+class ImagePadder:
     def __init__(self, min_size=64):
         self.min_size = min_size
-        self.pad_height = None
-        self.pad_width = None
+        self.pad_height = self.pad_width = None
+
+    def amounts(self, height, width):
+        m = self.min_size
+        return (m - height % m) % m, (m - width % m) % m
 
     def pad(self, image):
-        height, width = image.shape[-2:]
-        pad_height = (self.min_size - height % self.min_size) % self.min_size
-        pad_width = (self.min_size - width % self.min_size) % self.min_size
-        if self.pad_width is None:
-            self.pad_height, self.pad_width = pad_height, pad_width
-        elif pad_height != self.pad_height or pad_width != self.pad_width:
-            raise RuntimeError("ImagePadder: input size changed between calls")   # the reference has a bare `raise`
-        return torch.nn.ZeroPad2d((self.pad_width, 0, self.pad_height, 0))(image)
+        ph, pw = self.amounts(*image.shape[-2:])
+        if self.pad_height is None:
+            self.pad_height, self.pad_width = ph, pw
+        elif (ph, pw) != (self.pad_height, self.pad_width):
+            raise RuntimeError("ImagePadder: the input size changed between calls")     # the reference has a bare `raise`
+        if not (ph or pw):
+            return image
+        out = image.new_zeros(image.shape[:-2] + (image.shape[-2] + ph, image.shape[-1] + pw))
+        out[..., ph:, pw:] = image
+        return out
 
     def unpad(self, image):
         return image[..., self.pad_height:, self.pad_width:]

@@ -38,6 +38,31 @@ class PackedWeights:
         self.defer_wgrad = False
         self.pending = []          # (g, x0, x1, gate1) tensors of the queued backward calls
         self.pending_meta = None   # (desc, weight .grad tensors, rows of the first weight)
+        self.bias_key = self.bias_cat = None
+
+    def invalidate(self):
+        """Forget the packed copies (after parameters were written behind autograd's back, e.g. through `.data`)."""
+        self.key = self.bias_key = None
+
+    def __getstate__(self):
+        """Checkpoints (torch.save(model), reference utils/utils.py:60-61) carry parameters only: packed copies, queued
+        gradient parts and training-loop switches are rebuilt on use."""
+        return {"packed": None}     # (a non-empty state, so that __setstate__ runs when the checkpoint is loaded)
+
+    def __setstate__(self, state):
+        self.__init__()
+
+    def bias(self, biases):
+        """The bias vector of a (row-concatenated) convolution: the parameter itself, or a cached concatenation."""
+        if not biases or biases[0] is None:
+            return None
+        if len(biases) == 1:
+            return biases[0]
+        key = tuple((b.data_ptr(), b._version) for b in biases)
+        if key != self.bias_key:
+            self.bias_cat = torch.cat([b.detach() for b in biases])
+            self.bias_key = key
+        return self.bias_cat
 
     def get(self, weights, desc):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (desc.C0 + desc.C1, desc.N, desc.ksize)
@@ -437,8 +462,14 @@ class UpsampleConvLayer(nn.Module):
         self._packed = PackedWeights()
 
     def forward(self, x):
-        x_upsampled = upsample_bilinear(x, 2, 2)
-        return conv2d(self._packed, x_upsampled, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
+        return self.conv_after_upsample(upsample_bilinear(x, 2, 2))
+
+    def conv_after_upsample(self, up, up_first=None):
+        """The convolution on already up-sampled features; `up_first` supplies the leading input channels from a second
+        tensor (the previous prediction, reference arch.py:238) without concatenating."""
+        if up_first is None:
+            return conv2d(self._packed, up, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation)
+        return conv2d(self._packed, up_first, self.conv2d.weight, self.conv2d.bias, self.stride, self.activation, x1=up)
 
 
 class TransposedConvLayer(nn.Module):
