@@ -1,9 +1,12 @@
 """numpy restatement of the reference loader's per-sample event formatting, split and collate.
 
-*** TEST INFRASTRUCTURE ONLY *** (see oracle/oracle.py).  PARITY UNPINNED: the reference module holding these
-functions (dataloader/base.py) imports OpenCV at module level and cannot be imported in the build container, so this
-file follows the source line by line (cited below) and is checked against hand-computed cases in
-tests/test_loader_oracle.py instead of recorded reference outputs.
+*** TEST INFRASTRUCTURE ONLY *** (see oracle/oracle.py).  Parity is pinned by tests/golden/loader.npz: outputs of the
+reference's own BaseDataLoader methods (event_formatting, augment_events, create_list_encoding, create_polarity_mask,
+split_event_list, custom_collate) on seeded raw streams, recorded by tests/golden/make_golden_loader.py.  (The reference
+module imports OpenCV at its top, which this image lacks and none of these methods use; the generator executes the class
+definition as written, parsed from the reference file, without that import.)  tests/test_loader_oracle.py replays the
+fixture bit for bit through this file.  The window / new_seq state machine of dataloader/h5.py (:268-338) needs h5py and
+a dataset and stays restated-only.
 """
 
 import numpy as np

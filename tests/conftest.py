@@ -22,6 +22,22 @@ def load_case(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(z["meta"]))
     P, F = meta["P"], meta["F"]
+    if meta.get("seeded"):      # inputs regenerated from the seed (tests/golden/make_golden.py::save_seeded_case)
+        import hashlib
+
+        from taming_event_flow_amd import synth
+
+        rng = np.random.default_rng(meta["seed"])
+        win = synth.make_window(rng, meta["B"], meta["H"], meta["W"], P, F, meta["n_grad"], meta["n_det"], meta["sigma"],
+                                "smooth", True, True)
+        h = hashlib.sha256()
+        for t in range(P):
+            for f in win["flows"][t]:
+                h.update(np.ascontiguousarray(f).tobytes())
+            for k in ("ev", "pm", "dev", "dpm"):
+                h.update(np.ascontiguousarray(win[k][t]).tobytes())
+        assert h.hexdigest() == meta["digest"], "regenerated inputs differ from the ones the reference was run on"
+        return meta, win, np.float32(z["loss"]), z["dflows"]
     win = {
         "flows": [[z["flows"][t, i] for i in range(F)] for t in range(P)],
         "ev": [z[f"ev{t}"] for t in range(P)],
@@ -37,6 +53,7 @@ ITERATIVE_CASES = [
     "it_two_zero_flow", "it_two_smooth_terms", "it_two_round_ts", "it_two_float_xy", "it_two_p5_odd",
 ]
 LINEAR_CASES = ["lin_s1_p6", "lin_s2_p8", "lin_smooth_terms", "lin_zero_flow"]
+FULL_RES_CASES = ["it_two_128_p10", "lin_128_p10"]      # BASELINE resolution, inputs regenerated from a seed
 
 
 def rel_err(a, b):

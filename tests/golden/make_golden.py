@@ -90,6 +90,33 @@ def save_loss_case(name, kind, H, W, B, P, F, S, mode, n_grad, n_det, seed, sigm
     print(f"{name}: loss={loss64:.7f} |g|max={np.abs(g).max():.4e} size={os.path.getsize(path)/1e3:.0f} kB")
 
 
+def window_digest(win):
+    """sha256 over every input array of a window (flows, lists, masks), in a fixed order."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for t in range(len(win["flows"])):
+        for f in win["flows"][t]:
+            h.update(np.ascontiguousarray(f).tobytes())
+        for k in ("ev", "pm", "dev", "dpm"):
+            h.update(np.ascontiguousarray(win[k][t]).tobytes())
+    return h.hexdigest()
+
+
+def save_seeded_case(name, kind, H, W, B, P, F, S, mode, n_grad, n_det, seed, sigma=2.0):
+    """A case at the BASELINE resolution: the inputs are NOT stored (10 MB of smooth flow maps) but regenerated from the
+    numpy seed by synth.make_window at test time and checked against the digest recorded here; outputs are stored."""
+    rng = np.random.default_rng(seed)
+    win = synth.make_window(rng, B, H, W, P, F, n_grad, n_det, sigma, "smooth", True, True)
+    cfg = make_config(H, W, B, P, S, mode)
+    loss64, loss32, g = run_loss(kind, cfg, win)
+    meta = dict(kind=kind, H=H, W=W, B=B, P=P, F=F, S=S, mode=mode, spat=None, temp=None, round_ts=False, seed=seed,
+                loss=loss64, n_grad=n_grad, n_det=n_det, sigma=sigma, seeded=True, digest=window_digest(win))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), loss=loss32, dflows=g)
+    print(f"{name}: loss={loss64:.7f} |g|max={np.abs(g).max():.4e} size={os.path.getsize(path)/1e3:.0f} kB")
+
+
 def save_primitives(seed=11):
     """utils/iwe.py primitives on one small batch (values and gradients)."""
     rng = np.random.default_rng(seed)
@@ -166,6 +193,11 @@ def save_encodings(seed=12):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--full-res":
+        # the BASELINE resolution and window (128x128, P = 10, 10 000 gradient + 2 000 detached events per pass), one sample
+        save_seeded_case("it_two_128_p10", "Iterative", 128, 128, 1, 10, 2, 1, "two", 10000, 2000, seed=31)
+        save_seeded_case("lin_128_p10", "Linear", 128, 128, 1, 10, 1, 1, "two", 10000, 2000, seed=32)
+        return
     save_primitives()
     save_encodings()
     # Iterative (loss/flow.py:415) — the north-star path

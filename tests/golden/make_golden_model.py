@@ -119,7 +119,33 @@ def save_net(name, H, W, B, passes, seed):
     print(name, "loss", float(loss.item()), "gnorm total", float(np.sqrt((norms ** 2).sum())))
 
 
+def save_net_eval(name, H, W, passes, seed, stride=4):
+    """DSEC evaluation shape (BASELINE configs[4]): forward only, recurrent state carried over `passes` calls.  The flow
+    maps are stored on a stride-`stride` pixel lattice plus float64 sums / absolute sums of every full map."""
+    rng = np.random.default_rng(seed)
+    net = RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2)
+    load_weights(net, seed)
+    net.eval()
+    out = {"H": H, "W": W, "passes": passes, "seed": seed, "stride": stride}
+    with torch.no_grad():
+        for t in range(passes):
+            x = torch.tensor(rng.poisson(0.2, (1, 2, H, W)).astype(np.float32))
+            out[f"x{t}"] = x.numpy().astype(np.uint8)              # event counts: small integers
+            for i, fl in enumerate(net(x)["flow"]):
+                f = fl.numpy()
+                out[f"flow{t}_{i}"] = f[:, :, ::stride, ::stride].copy()
+                out[f"sum{t}_{i}"] = np.array([f.astype(np.float64).sum(), np.abs(f.astype(np.float64)).sum()])
+        for li, st in enumerate(net.states):
+            s_ = st.numpy()
+            out[f"state_sum{li}"] = np.array([s_.astype(np.float64).sum(), np.abs(s_.astype(np.float64)).sum()])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "saved", os.path.getsize(os.path.join(HERE, name + ".npz")) / 1e3, "kB")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--eval-shape":
+        save_net_eval("model_480x640_eval", 480, 640, 2, seed=43)
+        sys.exit(0)
     save_layers()
     save_net("model_32x32", 32, 32, 1, 2, seed=41)
     save_net("model_40x52_pad", 40, 52, 2, 2, seed=42)

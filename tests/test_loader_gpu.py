@@ -59,6 +59,31 @@ def test_split_mixed_batch(voxel):
     _run([5000, 100, 10, 0, 1000, 1001, 3333], 32, 40, 1000, [0, 1, 2, 4, 7, 3, 5], voxel, 1)
 
 
+def test_reference_recorded_batch():
+    """The HIP loader stage on the raw streams of tests/golden/loader.npz against what the reference's own functions
+    produced for them (recorded by tests/golden/make_golden_loader.py): bit-exact lists and masks."""
+    import os
+
+    from conftest import GOLDEN
+    from taming_event_flow_amd.dataloader.base import collate_raw_events
+
+    z = np.load(os.path.join(GOLDEN, "loader.npz"))
+    H, W, B, G = int(z["H"]), int(z["W"]), int(z["B"]), int(z["G"])
+    offs = np.concatenate([[0], np.cumsum(z["counts"])]).astype(int)
+    dev = torch.device("cuda:0")
+    # the reference casts the float64 raw arrays to fp32 on the host first (base.py:164-167)
+    cat = lambda n: torch.tensor(np.concatenate([z[f"{n}{b}"] for b in range(B)]).astype(np.float32), device=dev)   # noqa: E731
+    sampled = np.full((B, G), -1, np.int32)
+    for b in range(B):
+        if f"sampled{b}" in z.files:
+            sampled[b] = z[f"sampled{b}"]
+    got = collate_raw_events(cat("xs"), cat("ys"), cat("ts"), cat("ps"), offs, (H, W), max_num_grad_events=G,
+                             augmentation=[int(f) for f in z["flags"]], sampled_indices=torch.tensor(sampled))
+    for k in ("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask"):
+        g = got[k].cpu().numpy()
+        assert g.shape == z["col_" + k].shape and np.array_equal(g, z["col_" + k]), k
+
+
 def test_all_empty():
     got = _run([0, 3, 10], 16, 16, 100, None, None, 2)
     assert got["event_list"].shape == (3, 0, 4) and got["d_event_list"].shape == (3, 0, 4)

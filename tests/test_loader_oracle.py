@@ -1,5 +1,8 @@
-"""Loader restatement (oracle/loader.py, parity unpinned: see its header) against hand-computed cases, and the host
-mirror of the reference's static helpers (dataloader/base.py) against it.  CPU only."""
+"""Loader restatement (oracle/loader.py) against outputs recorded from the reference's own functions
+(tests/golden/loader.npz, made by tests/golden/make_golden_loader.py) and hand-computed cases, and the host mirror of the
+reference's static helpers (dataloader/base.py) against it.  CPU only."""
+import os
+
 import numpy as np
 import torch
 
@@ -79,3 +82,64 @@ def test_host_mirror_matches_restatement():
         assert np.array_equal(out[k].numpy(), v), k
     s = draw_sampled_indices([n, 9, 100], 15, torch.Generator().manual_seed(0))
     assert s.shape == (3, 15) and (s[1] == -1).all() and len(set(s[0].tolist())) == 15 and int(s[2].max()) < 100
+
+
+def _fixture():
+    from conftest import GOLDEN
+
+    return np.load(os.path.join(GOLDEN, "loader.npz"))
+
+
+def test_restatement_replays_reference_outputs():
+    """Every stage of one __getitem__ + collate, bit for bit against the reference (formatting incl. the fp32 cast of
+    float64 timestamps, the three flips, list / mask encodings, the split with the recorded multinomial draw, zero-padded
+    collate of a ragged batch with an emptied sample)."""
+    z = _fixture()
+    H, W, B, G = int(z["H"]), int(z["W"]), int(z["B"]), int(z["G"])
+    items = []
+    for b in range(B):
+        xs, ys, ts, ps = z[f"xs{b}"], z[f"ys{b}"], z[f"ts{b}"], z[f"ps{b}"]
+        if xs.shape[0] <= 10:
+            xs = ys = ts = ps = np.empty([0])
+        fx, fy, ft, fp = loader.event_formatting(xs, ys, ts, ps)
+        assert np.array_equal(ft, z[f"fmt_ts{b}"]) and np.array_equal(fp, z[f"fmt_ps{b}"])
+        ax, ay, ap = loader.augment_events(fx, fy, fp, int(z["flags"][b]), (H, W))
+        ev, mk = loader.create_list_encoding(ax, ay, ft, ap), loader.create_polarity_mask(ap)
+        assert np.array_equal(ev, z[f"list{b}"]) and np.array_equal(mk, z[f"mask{b}"]), b
+        sampled = z[f"sampled{b}"] if f"sampled{b}" in z.files else None
+        g, gm, d, dm = loader.split_event_list(ev, mk, G, sampled)
+        for got, key in ((g, "g"), (gm, "gm"), (d, "d"), (dm, "dm")):
+            assert got.shape == z[f"{key}{b}"].shape and np.array_equal(got, z[f"{key}{b}"]), (key, b)
+        items.append({"event_list": g, "event_list_pol_mask": gm, "d_event_list": d, "d_event_list_pol_mask": dm,
+                      "net_input": np.full((2, 3, 3), float(b), np.float32)})
+    col = loader.custom_collate(items)
+    for k in ("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask", "net_input"):
+        assert col[k].shape == z["col_" + k].shape and np.array_equal(col[k], z["col_" + k]), k
+    # the whole stage in one call (the form the HIP loader stage is compared with)
+    offs = np.concatenate([[0], np.cumsum(z["counts"])]).astype(int)
+    cat = lambda n: np.concatenate([z[f"{n}{b}"] for b in range(B)])      # noqa: E731
+    sampled = np.full((B, G), -1, np.int64)
+    for b in range(B):
+        if f"sampled{b}" in z.files:
+            sampled[b] = z[f"sampled{b}"]
+    whole = loader.collate_raw_events(cat("xs"), cat("ys"), cat("ts"), cat("ps"), offs, (H, W), G, list(z["flags"]), sampled, None)
+    for k in ("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask"):
+        assert np.array_equal(whole[k], z["col_" + k]), k
+
+
+def test_host_mirror_replays_reference_outputs():
+    """The torch mirrors of the reference's static helpers (dataloader/base.py here) on the recorded inputs."""
+    z = _fixture()
+    G = int(z["G"])
+    items = []
+    for b in range(int(z["B"])):
+        ev, mk = torch.tensor(z[f"list{b}"]), torch.tensor(z[f"mask{b}"])
+        assert np.array_equal(BaseDataLoader.create_polarity_mask(ev[3]).numpy(), z[f"mask{b}"])
+        torch.manual_seed(100 + b)                     # the generator's seed: the same multinomial draw
+        g, gm, d, dm = BaseDataLoader.split_event_list(ev, mk, G)
+        for got, key in ((g, "g"), (gm, "gm"), (d, "d"), (dm, "dm")):
+            assert np.array_equal(got.numpy(), z[f"{key}{b}"]), (key, b)
+        items.append({"event_list": g, "event_list_pol_mask": gm, "d_event_list": d, "d_event_list_pol_mask": dm})
+    col = BaseDataLoader.custom_collate(items)
+    for k in col:
+        assert np.array_equal(col[k].numpy(), z["col_" + k]), k

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import ITERATIVE_CASES, LINEAR_CASES, load_case, rel_err
+from conftest import FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES)
+@pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES + FULL_RES_CASES)
 def test_golden_cases(name, dev):
     meta, win, loss, dflows = load_case(name)
     l, g, evs = run_hip(meta["kind"], make_cfg(meta), win, dev)

@@ -195,6 +195,32 @@ def test_dsec_eval_shape_forward(dev):
     assert not torch.equal(f1[-1], f2[-1])       # the recurrent state matters
 
 
+def test_dsec_eval_shape_against_reference(dev):
+    """480x640 inference (BASELINE configs[4]) against the reference's recorded flows (tests/golden/
+    model_480x640_eval.npz: two recurrent passes; every flow map on a stride-4 lattice plus float64 sums of the full maps
+    and of the final states)."""
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    z = np.load(os.path.join(GOLDEN, "model_480x640_eval.npz"))
+    st = int(z["stride"])
+    net = load_weights(RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2), int(z["seed"]), dev)
+    net.eval()
+    with torch.no_grad():
+        for t in range(int(z["passes"])):
+            flows = net(torch.tensor(z[f"x{t}"].astype(np.float32), device=dev))["flow"]
+            for i, fl in enumerate(flows):
+                f = fl.cpu().numpy()
+                assert f.shape == (1, 2, 480, 640)
+                assert rel_err(f[:, :, ::st, ::st], z[f"flow{t}_{i}"]) <= TOL, (t, i)
+                ref_sum, ref_abs = z[f"sum{t}_{i}"]
+                assert abs(np.abs(f.astype(np.float64)).sum() - ref_abs) <= 1e-4 * ref_abs, (t, i)
+                assert abs(f.astype(np.float64).sum() - ref_sum) <= 1e-4 * ref_abs, (t, i)
+        for li, s_ in enumerate(net.states):
+            a = s_.cpu().numpy().astype(np.float64)
+            ref_sum, ref_abs = z[f"state_sum{li}"]
+            assert abs(np.abs(a).sum() - ref_abs) <= 1e-4 * ref_abs and abs(a.sum() - ref_sum) <= 1e-4 * ref_abs, li
+
+
 def test_conv_against_torch_reference_large(dev):
     """A full-size layer (ConvGRU level 1 at B=8: 128 ch @ 32x32) against torch's own fp32 conv on the same device."""
     from taming_event_flow_amd.models.submodules import ConvGRU

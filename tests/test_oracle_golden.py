@@ -8,13 +8,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ITERATIVE_CASES, LINEAR_CASES, load_case, rel_err
+from conftest import GOLDEN, FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, load_case, rel_err
 from oracle import oracle
 
 TOL = 1e-5
 
 
-@pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES)
+@pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES + FULL_RES_CASES)
 def test_loss_cases(name):
     meta, win, loss, dflows = load_case(name)
     w = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=meta["S"], mode=meta["mode"],
