@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s sp
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: a >= 0.2 s timed region)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
     ap.add_argument("--passes", type=int, default=10)
     ap.add_argument("--events", type=int, default=10000, help="grad events per pass per sample")
@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--step-graph", action="store_true",
                     help="loss mode: replay a captured hipGraph of the step (for hosts too slow to enqueue 0.8 ms steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-extra", action="store_true",
+                    help="loss mode at 1 GPU: skip the short training-window measurement appended as `extra`")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="per-kernel HIP events are recorded on every K-th timed step (each pair costs a few us of stream time)")
@@ -69,11 +71,14 @@ def make_cfg(a):
 
 
 def pmc_traffic(a):
-    """HBM bytes per launch measured with rocprofv3 PMC counters (profiles/r01_pmc_traffic.json), only when the
+    """HBM bytes per launch measured with rocprofv3 PMC counters (newest profiles/rNN_pmc_traffic.json), only when the
     benchmark runs the exact configuration they were collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not found:
         return {}
+    path = found[-1]
     with open(path) as f:
         d = json.load(f)
     c = d["config"]
@@ -267,21 +272,28 @@ def main():
     lib.tef_profile_enable(0 if a.no_kernel_events else 1)
     if not a.no_kernel_events:
         lib.tef_profile_pause(1)
+    # device time of every step from a HIP event pair on the stream the kernels are launched on (torch's current stream):
+    # SURVEY.md section 8d asks for the median over >= 20 steps beside the wall-clock mean that `value` is made of
+    step_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
         profiled = not a.no_kernel_events and k % max(1, a.event_every) == 0
         if not a.no_kernel_events:
             lib.tef_profile_pause(0 if profiled else 1)
+        step_events[k][0].record()
         if graphs and not profiled:
             gph, out = graphs[k % len(graphs)]
             gph.replay()
             last, last_grads = out
         else:
             last, last_grads = step(k)
+        step_events[k][1].record()
     t_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (diagnostic: host- vs device-bound)
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in step_events)
+    step_ms_median = step_ms[len(step_ms) // 2]
     lib.tef_profile_collect()
     kern = {}
     for s in range(lib.tef_profile_slots()):
@@ -332,7 +344,11 @@ def main():
                                   % max(1, a.event_every)) if graphs and not a.no_kernel_events
                        else ("hipGraph replay of the step" if graphs else "eager")},
             "loss": round(loss_val, 6),
+            "ms_per_step_hip_event_median": round(step_ms_median, 4),
             "ms_update_per_window": round(1e3 * t_update, 3),
+            # update() (AoS -> SoA packing + sort of the P passes) is outside the timed region as SURVEY.md section 8d
+            # defines the metric; this is the rate with its wall time added to every step
+            "value_including_update": round(events_per_step * world / (elapsed / a.steps + t_update), 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
             "kernel_events_every": None if a.no_kernel_events else max(1, a.event_every),
             "roofline": roofline,
@@ -344,8 +360,22 @@ def main():
                 "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic.get("iwe_splat"),
                 "splats_per_launch": splats}
+        # whole loss against the HBM roofline by SURVEY.md section 8d's compulsory traffic: events and masks read once per
+        # direction, flow maps read twice and their gradients written once, everything else on chip
+        bpe = 48.0 + 24.0 * F * H * W / max(1, a.events + a.detached)
+        ach = (events_per_step / (elapsed / a.steps)) * bpe / 1e9          # per GPU
+        whole = {"bound": "hbm", "bytes_per_event": round(bpe, 1), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+        if traffic and all(k_ in traffic for k_ in kern if k_ in alg):
+            moved = sum(traffic[k_] for k_ in kern if k_ in traffic)
+            whole["hbm_bytes_per_step_pmc"] = int(moved)
+            whole["pmc_over_compulsory"] = round(moved / (bpe * events_per_step), 2)
+        out["roofline_whole_loss"] = whole
         if not a.no_cpu_baseline and a.warping == "Iterative" and world == 1:     # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
+            out["cpu_baseline_1thread"] = cpu_baseline(a, host_windows[0], threads=1, seconds=min(a.cpu_seconds, 6.0), batch=2)
+        if world == 1 and not a.no_train_extra and a.warping == "Iterative":
+            out["extra"] = train_extra(a, torch, dev)
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
@@ -559,20 +589,70 @@ def bench_eval(a, torch, dist, dev, rank, world, lib):
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, win):
+def train_extra(a, torch, dev):
+    """A short measurement of the full training window (the `--mode train --graph` workload, configs[2]) appended to
+    the default line so that the driver's own run carries it: ms per window and the conv contractions against the fp32
+    MFMA peak.  Never allowed to take the headline down: any failure is reported as a string."""
+    import copy
+
+    try:
+        from taming_event_flow_amd import _lib, train
+
+        lib = _lib.lib()
+        cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+        cfg["loader"].update(batch_size=a.batch, resolution=list(a.res), max_num_grad_events=a.events)
+        cfg["data"]["passes_loss"] = a.passes
+        cfg["optimizer"]["capturable"] = True
+        torch.manual_seed(1234)
+        tr = train.Trainer(cfg, dev)
+        src = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100)
+        tr.reset()
+        window = tr.capture_window([src.next() for _ in range(a.passes)], warmup=1)
+        window()
+        torch.cuda.synchronize()
+        n = 5
+        lib.tef_profile_enable(0)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            window()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / n
+        # the conv kernels' own time needs per-launch events, which a graph replay does not carry: one eager window
+        lib.tef_profile_enable(1)
+        for b in window.inputs:
+            tr.step({k: v.clone() for k, v in b.items()}, new_seq=False)
+        torch.cuda.synchronize()
+        lib.tef_profile_collect()
+        conv_ms = sum(lib.tef_profile_ms(s_) for s_ in range(lib.tef_profile_slots())
+                      if lib.tef_profile_name(s_).decode().startswith("conv_"))
+        lib.tef_profile_enable(0)
+        flops = 3 * conv_flops_per_pass(a.batch, a.res[0], a.res[1]) * a.passes
+        ev = a.batch * a.passes * (a.events + a.detached)
+        del tr, window
+        torch.cuda.empty_cache()
+        return {"workload": "training window as one hipGraph (bench.py --mode train --graph): RecEVFlowNet fwd + loss + BPTT "
+                            "+ clip + Adam, BASELINE configs[2]",
+                "train_window_ms": round(ms, 3), "train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": n,
+                "conv_ms_per_window_eager": round(conv_ms, 3), "conv_tflops": round(flops / (conv_ms * 1e-3) / 1e12, 2),
+                "conv_frac_of_fp32_mfma_peak": round(flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": repr(e)}
+
+
+def cpu_baseline(a, win, threads=None, seconds=None, batch=None):
     """The CPU restatement (oracle/, "port") on the host cores: one window of the same workload,
     all (head, sample) pairs in parallel over the available cores; bounded to ~10-30 s."""
     from oracle import oracle
 
     ncores = len(os.sched_getaffinity(0))
-    nthr = oracle.threads(ncores)
-    bs = a.cpu_batch or a.batch
+    nthr = oracle.threads(threads or ncores)
+    bs = batch or a.cpu_batch or a.batch
     sub = {k: ([[m[:bs] for m in row] for row in win["flows"]] if k == "flows" else [x[:bs] for x in win[k]])
            for k in win}
     w = oracle.Window(sub["flows"], sub["ev"], sub["pm"], sub["dev"], sub["dpm"], S=1, mode="two")
     w.iterative(backward=True)                      # untimed: thread pool start-up, page faults
     reps, dt = 0, 0.0
-    while dt < a.cpu_seconds and reps < 1000:
+    while dt < (seconds or a.cpu_seconds) and reps < 1000:
         t0 = time.perf_counter()
         loss, _ = w.iterative(backward=True)
         dt += time.perf_counter() - t0

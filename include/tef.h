@@ -78,15 +78,18 @@ typedef struct tef_loss_cfg {
     int M, Md;                /* total grad / detached slots per sample */
     int off[TEF_MAX_PASSES + 1];    /* grad slot offsets per pass */
     int doff[TEF_MAX_PASSES + 1];   /* detached slot offsets per pass */
+    int loss_scaling;               /* BaseEventWarping(loss_scaling=...), loss/flow.py:124-127: 1 = divide every image's sum
+                                       by its number of active pixels (the default), 0 = plain sum */
 } tef_loss_cfg;
 
 /* AoS -> SoA packing of one pass, replaces the bookkeeping of Iterative.update / Linear.update
  * (loss/flow.py:443-476, 233-288): adds `ts_shift` to ev[:, :, 0] IN PLACE (reference side effect,
- * :457-458) and appends the pass at slot `slot0` of the SoA arrays.  If ts_override >= 0 the stored
- * timestamp is that constant instead (round_ts, :461-463).  ev [B,N,4] (ts,y,x,p), pm [B,N,2].
+ * :457-458) and appends the pass at slot `slot0` of the SoA arrays.  If ts_override (a DEVICE pointer to one float) is
+ * not NULL the stored timestamp is that value instead (round_ts, :461-463: the caller computes min + 0.5 of the shifted
+ * list on the device, no host round trip).  ev [B,N,4] (ts,y,x,p), pm [B,N,2].
  * The events of the pass are stored sorted by (polarity, 8x8 pixel tile of the H x W frame): the loss is a sum over
  * events, so the order inside a pass is free, and coherent wavefronts halve the cost of the lookups. */
-int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
+int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx,
                     int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
                     uint8_t *bin, int *cls, void *stream);
 

@@ -230,6 +230,7 @@ typedef struct {
     const int *off, *doff;       /* [P+1] each */
     const float *flows;
     const float *ts, *y, *x, *mp, *mn;  /* [B][M+Md] */
+    int loss_scaling;            /* loss/flow.py:124-127: divide each image's sum by its number of active pixels */
 } tef_window;
 
 static inline const float *tef_map(const tef_window *wd, int t, int i, int b, int c)
@@ -284,7 +285,7 @@ static float tef_image_loss(const tef_window *wd, tef_imgbuf *ib, float *n_out)
         s += (double)(ib->A[p] * ib->A[p]) + (double)(ib->A[HW + p] * ib->A[HW + p]);
         nnz += ((c0 + c1) != 0.0f);
     }
-    *n_out = (float)nnz + TEF_EPS;
+    *n_out = wd->loss_scaling ? (float)nnz + TEF_EPS : 1.0f;
     return (float)s / *n_out;
 }
 

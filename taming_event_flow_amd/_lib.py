@@ -33,6 +33,7 @@ class LossCfg(ctypes.Structure):
         ("P", ctypes.c_int), ("F", ctypes.c_int), ("S", ctypes.c_int), ("mode_div", ctypes.c_int),
         ("M", ctypes.c_int), ("Md", ctypes.c_int),
         ("off", ctypes.c_int * (TEF_MAX_PASSES + 1)), ("doff", ctypes.c_int * (TEF_MAX_PASSES + 1)),
+        ("loss_scaling", ctypes.c_int),
     ]
 
 
@@ -61,7 +62,7 @@ SIGNATURES = {
     "tef_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tef_profile_ms": (ctypes.c_double, [ctypes.c_int]),
     "tef_profile_calls": (ctypes.c_long, [ctypes.c_int]),
-    "tef_pack_events": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+    "tef_pack_events": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _fp,
                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp,
                                        _fp, _fp, _fp, _fp, _fp]),
     "tef_pack_flow": (ctypes.c_int, [_fp, ctypes.c_long, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,

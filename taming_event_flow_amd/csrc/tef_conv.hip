@@ -51,12 +51,6 @@ struct Gather {
     long npix_src;       // B * SH * SW: elements per channel-of-all-images of a source (bounds of the 16-byte gather)
 };
 
-#ifdef TEF_CONV_STAMP
-__device__ unsigned long long *g_stamps = nullptr;      // experiment hook: per-workgroup phase clocks
-#define STAMP(i) do { if (g_stamps && threadIdx.x == 0) g_stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (i)] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
 
 struct GemmArgs {
     const float *A;       // A_PLAIN: [rows][lda];  A_NCHW: g [B][rows][hwA] read as A[r][kk = (b, p)]
@@ -155,8 +149,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     __shared__ __attribute__((aligned(16))) float As[NBUF][TR][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][BFLOATS];
     __shared__ __attribute__((aligned(16))) int soff[BM == B_GATHER ? 9 : 1][BM == B_GATHER ? TC : 4];
-
-    STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / (TC / WC), wc = wave % (TC / WC);
     const int row0 = blockIdx.y * TR, col0 = blockIdx.x * TC;
@@ -176,11 +168,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     float4 ra[AP];
     unsigned amask = 0;            // A_NCHW: bit 4p+e = element e of piece p is inside the reduction range
     auto load_a = [&](int k0) {
-#ifdef TEF_CONV_ABL_NOLOAD
-        for (int p = 0; p < AP; ++p) ra[p] = make_float4(1.f, 2.f, 3.f, (float)k0);
-        amask = 0xffffu;
-        return;
-#endif
         amask = 0;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
@@ -318,11 +305,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
         if (ok && gated && has_gate) bmask |= 1u << (16 + j);
     };
     auto load_b = [&](int k0) {
-#ifdef TEF_CONV_ABL_NOLOAD
-        for (int p = 0; p < BP; ++p) rb[p] = make_float4(1.f, 2.f, 3.f, (float)k0);
-        bmask = 0xffffu;
-        return;
-#endif
         bmask = 0;
         if (BM == B_GATHER) {
             int ci = ci0, rr = r0;
@@ -447,10 +429,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
             for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < MC; ++j) {
-#ifdef TEF_CONV_ABL_NOMFMA
-                    acc[i][j][0] += fa[i].x * fb[j].x + fa[i].y * fb[j].y + fa[i].z * fb[j].z + fa[i].w * fb[j].w;
-                    continue;
-#endif
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
@@ -479,7 +457,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
     store_a(0);
     store_b(0);
     __syncthreads();
-    STAMP(1);
     int buf = 0;
     for (int k0 = k_begin + BK; k0 < k_end; k0 += BK) {
         load_a(k0);                 // next stage in flight while this one is multiplied
@@ -493,7 +470,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
         buf ^= 1;
     }
     multiply(buf);
-    STAMP(2);
 
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
@@ -526,7 +502,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
                 }
             }
         }
-    STAMP(3);
 }
 
 // =====================================================================================================================
@@ -550,11 +525,7 @@ constexpr int HLDA = HS + 4;     // LDS row pitch of the A sub-tile (floats)
 // the halo columns hold real neighbours and are loaded with the patch, edge tiles are masked.
 // S = 2: the stride-2 encoder heads (forward only): the tile's R x W outputs read a (2R + 1) x (2W + 1) input patch with
 // stride-2 windows (padding 1: only the left / top halo exists, and it is zero).
-#ifdef TEF_HALO_ABL_NOBAR
-#define HALO_SYNC() __builtin_amdgcn_sched_barrier(0)
-#else
 #define HALO_SYNC() __syncthreads()
-#endif
 // S2D: input gradient of a STRIDE-2 layer as a stride-1 convolution over the output-gradient grid.  Input pixel
 // (2a + py, 2b + px) only sees g at (a + dy, b + dx), dy, dx in {0, 1}: rows = (parity class (py, px), input channel),
 // weights packed per class with zeros at the taps a class does not use (pack_s2d_kernel), those taps' MFMAs skipped
@@ -573,11 +544,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     // Three A buffers (one per sub-stage of a chunk) when they fit the 64 KiB of static LDS: a sub-stage's data is then
     // visible one barrier before it is needed, so its first operands are read BEFORE the barrier and no wave waits for
     // LDS right after it (PF3 loop below).  Otherwise two buffers and the plain store -> barrier -> read sequence.
-#ifndef TEF_HALO_NO_PF3
     constexpr bool PF3 = (3 * TR * HLDA + 2 * HC * PLANE) * 4 <= 65536;
-#else
-    constexpr bool PF3 = false;
-#endif
     constexpr int NA = PF3 ? 3 : 2;
     __shared__ __attribute__((aligned(16))) float As[NA][TR][HLDA];
     __shared__ __attribute__((aligned(16))) float Ps[2][HC][PLANE];
@@ -635,11 +602,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             int piece = min(tid + p * NT, TR * 6 - 1);
             int r = piece / 6, q4 = piece - r * 6;
             int rc = min(row0 + r, g.rows - 1);
-#ifdef TEF_HALO_ABL_NOLOAD
-            ra[p] = make_float4((float)rc, (float)chunk, (float)sub, (float)q4);
-#else
             ra[p] = *reinterpret_cast<const float4 *>(g.A + (size_t)rc * g.lda + (size_t)chunk * HK + sub * HS + q4 * 4);
-#endif
         }
     };
     auto store_a_from = [&](const float4 (&ra)[AP], int buf) {
@@ -703,11 +666,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             // pofs = (image of the tile) * HWi + offset inside the plane: move the image part to the channel stride
             int sub = IPT > 1 ? pofs[p] / HWi : 0;
             size_t o = ok ? ((size_t)(img + sub) * cs + clc) * HWi + (pofs[p] - sub * HWi) : 0;
-#ifdef TEF_HALO_ABL_NOLOAD
-            rp[p] = make_float4((float)o, 1.f, 2.f, 3.f);
-#else
             rp[p] = *reinterpret_cast<const float4 *>(src + o);
-#endif
             if (GATED) {
                 rq[p] = *reinterpret_cast<const float4 *>(g.G.gate1 + ((ok && second) ? o : 0));
                 if (ok && second) pmask |= 1u << (8 + p);
@@ -764,30 +723,19 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
     struct Ops { float4 fa[MR]; float4 fb; };
     auto read_ops = [&](int abuf, int pbuf, int tap, Ops &o) {
         const int ky = tap / 3, kx = tap - ky * 3;
-#ifdef TEF_HALO_ABL_NOLDS
-#pragma unroll
-        for (int i = 0; i < MR; ++i) o.fa[i] = make_float4((float)(lane + kx), (float)abuf, (float)i, 1.0f);
-        o.fb = make_float4((float)pbuf, (float)ky, (float)kx, (float)lane);
-#else
 #pragma unroll
         for (int i = 0; i < MR; ++i)
             o.fa[i] = *reinterpret_cast<const float4 *>(&As[abuf][wr * WR + i * 32 + (lane & 31)][kx * HC + 4 * h]);
         const float *bp = &Ps[pbuf][0][0] + pbase + ky * PP + kx;
         o.fb = make_float4(bp[0], bp[PLANE], bp[2 * PLANE], bp[3 * PLANE]);
-#endif
     };
     auto mfma_ops = [&](const Ops &o) {
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
-#ifdef TEF_HALO_ABL_NOMFMA
-            asm volatile("" :: "v"(o.fa[i].x), "v"(o.fa[i].y), "v"(o.fa[i].z), "v"(o.fa[i].w), "v"(o.fb.x), "v"(o.fb.y), "v"(o.fb.z), "v"(o.fb.w));
-            acc[i][0] += o.fa[i].x * o.fb.x;
-#else
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].x, o.fb.x, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].y, o.fb.y, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].z, o.fb.z, acc[i], 0, 0, 0);
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.fa[i].w, o.fb.w, acc[i], 0, 0, 0);
-#endif
         }
     };
     auto multiply = [&](int abuf, int pbuf, int sub) {
@@ -1110,30 +1058,6 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g, WgradPart
         }
     };
 
-#ifdef TEF_WGRAD_NO_PF
-    load_a(s_begin);
-    load_p(s_begin);
-    store_a(0);
-    store_p(0);
-    __syncthreads();
-    int buf = 0;
-    for (int st = s_begin + 1; st <= s_end; ++st) {
-        if (st < s_end) { load_a(st); load_p(st); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            Ops o;
-            read_ops(buf, kh, o);
-            mfma_ops(o);
-        }
-        if (st == s_end) break;
-        pin();
-        store_a(buf ^ 1);
-        store_p(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-    }
-#else
     // The barrier of a stage sits before its LAST k-step, whose operands are already in registers: the buffer is free
     // and the next stage (stored at the top of the iteration) visible when the barrier opens, and the first operands of
     // the next stage are read behind the last k-step's MFMAs instead of right after a barrier.  Stages st + 1 and st + 2
@@ -1167,7 +1091,6 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g, WgradPart
         cur = nxt;
         buf ^= 1;
     }
-#endif
 
     if (col >= g.valid_cols) return;
 #pragma unroll
@@ -1538,11 +1461,9 @@ inline int k_splits(int rows, int cols, int K)
 {
     int tr = rows > 64 ? 128 : (rows > 32 ? 64 : 32);
     int tiles = ((cols + 127) / 128) * ((rows + tr - 1) / tr);
-#ifndef TEF_CONV_WG_TARGET
-#define TEF_CONV_WG_TARGET 512          // two 512-thread workgroups per CU
-#endif
-    if (tiles >= TEF_CONV_WG_TARGET / 2 || K < 512) return 1;
-    int z = TEF_CONV_WG_TARGET / tiles;      // at or just below two full rounds of the chip, never just past them
+constexpr int kConvWgTarget = 512;          // two 512-thread workgroups per CU
+    if (tiles >= kConvWgTarget / 2 || K < 512) return 1;
+    int z = kConvWgTarget / tiles;      // at or just below two full rounds of the chip, never just past them
     int zmax = K / 128;
     if (z > zmax) z = zmax;
     if (z > 16) z = 16;
@@ -1608,12 +1529,10 @@ inline int halo_gen_logw(const tef_conv_desc *d)
 
 // Row tile of the halo forward / input-gradient kernel: 128 rows, 64 when there are few of them — or few pixels (the
 // 8 x 8 level: 64-row tiles double the workgroups per slice, i.e. half the slabs to write and reduce).
-#ifndef TEF_HALO_TR64_COLS
-#define TEF_HALO_TR64_COLS 0
-#endif
+constexpr int kHaloTr64Cols = 0;
 inline int halo_row_tile(int rows, int cols)
 {
-    if (rows > 64 && cols > TEF_HALO_TR64_COLS) return 128;
+    if (rows > 64 && cols > kHaloTr64Cols) return 128;
     return rows > 32 ? 64 : 32;
 }
 
@@ -1738,12 +1657,6 @@ inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
         ctiles = ((d->W + (1 << lw) - 1) >> lw) * ((d->H + (128 >> lw) - 1) / (128 >> lw)) * d->B;
     }
     int tiles = ctiles * ((rows + tr - 1) / tr);
-#ifdef TEF_HALO_SPLIT_ENV
-    if (const char *e = getenv("TEF_HALO_Z")) {         // experiment hook: force the split factor
-        int z = atoi(e);
-        if (z > 0 && nch >= 8) return std::max(1, std::min(z, std::min(nch / 2, 16)));
-    }
-#endif
     if (nch < 8 || tiles >= 1024) return 1;
     const int zmax = std::min(nch / 2, 16);
     int best = 1;
@@ -1761,9 +1674,6 @@ inline int halo_splits(const tef_conv_desc *d, int rows, int cols, int nch)
 // N inputs and 4 Ct outputs; returns its halo mode (0: not eligible).
 inline int s2d_mode(const tef_conv_desc *d, tef_conv_desc *gd)
 {
-#ifdef TEF_CONV_NO_S2D
-    return 0;
-#endif
     if (d->ksize != 3 || d->stride != 2 || d->C1 != 0 || (d->H & 1) || (d->W & 1) || d->C0 < 16) return 0;
     tef_conv_desc t = *d;
     t.C0 = d->N; t.C1 = 0; t.N = 4 * d->C0; t.H = d->H / 2; t.W = d->W / 2; t.stride = 1;
@@ -1791,11 +1701,7 @@ int launch_wgrad_halo_w(const GemmArgs &g, const WgradParts &wp, int z, hipStrea
 // stride-2 heads: logw = log2(output width) from halo_s2_logw
 inline int wgrad_s2_logw(const tef_conv_desc *d)
 {
-#ifdef TEF_CONV_NO_WGRAD_S2
-    return 0;
-#else
     return halo_s2_logw(d);
-#endif
 }
 
 template <int LOGW>
@@ -1883,19 +1789,12 @@ static int conv_wgrad(const tef_conv_desc *d, const Geo &q, const float *gsrc, c
     g.cols = q.Kp; g.K = Mp;
     g.C = dweight; g.C2 = dweight2; g.split = split_rows; g.ldc = q.K; g.valid_cols = q.K;
     int tiles = ((q.Kp + 127) / 128) * ((N + 127) / 128);
-#ifdef TEF_WGRAD_OLD_SPLIT
-    int want = std::max(1, 512 / std::max(1, tiles));
-    int ks = round_up((Mp + want - 1) / want, BK);
-    if (ks < 256) ks = std::min(256, Mp);
-#else
     // Slices of the pixel reduction: a launch runs ceil(workgroups / 256) rounds (one workgroup keeps a CU busy), a
     // round costs its slice's 32-pixel stages plus about three stages of prologue and atomics epilogue.
     // (32-row layers run 256-thread workgroups, one wave per SIMD each: four of them share a CU)
     const int stages = Mp / BK;
-#ifndef TEF_WGRAD_NARROW_SLOTS
-#define TEF_WGRAD_NARROW_SLOTS 1024
-#endif
-    const int slots = N <= 32 ? TEF_WGRAD_NARROW_SLOTS : 256, zcap = N <= 32 ? 256 : 64;
+constexpr int kWgradNarrowSlots = 1024;
+    const int slots = N <= 32 ? kWgradNarrowSlots : 256, zcap = N <= 32 ? 256 : 64;
     int want = 1;
     double best = 1e30;
     for (int zc = 1; zc <= zcap && zc * 4 <= std::max(4, stages); ++zc) {
@@ -1904,11 +1803,9 @@ static int conv_wgrad(const tef_conv_desc *d, const Geo &q, const float *gsrc, c
         if (cost < best - 1e-9) { best = cost; want = zz; }
     }
     int ks = round_up((Mp + want - 1) / want, BK);
-#endif
     g.ksplit = ks;
     int z = (Mp + ks - 1) / ks;
     tef::ProfScope ps(tef::PROF_CONV_WGRAD, st);
-#ifndef TEF_CONV_NO_WGRAD_HALO
     if (int logw = halo_logw(d)) {      // reduction in 32-pixel stages; ksplit counts stages
         g.cols = q.K; g.valid_cols = q.K;
         g.ksplit = ks / 32;
@@ -1919,7 +1816,6 @@ static int conv_wgrad(const tef_conv_desc *d, const Geo &q, const float *gsrc, c
         g.ksplit = ks / 32;
         return launch_wgrad_halo_s2(g, wp, logw, z, st);
     }
-#endif
     if (wp.n) return tef::fail("tef_conv_wgrad_parts: layer is not on the halo weight-gradient kernels"), TEF_ERR_INVALID;
     return launch_gemm<A_NCHW, B_GATHER_T, EPI_ATOMIC>(g, z, st);
 }
@@ -1928,12 +1824,6 @@ static int conv_wgrad(const tef_conv_desc *d, const Geo &q, const float *gsrc, c
 
 extern "C" {
 
-#ifdef TEF_CONV_STAMP
-int tef_debug_set_stamps(unsigned long long *p)
-{
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 size_t tef_conv_workspace_bytes(const tef_conv_desc *d)
 {
@@ -2016,7 +1906,6 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     g.cols = q.M; g.K = q.Kp;
     g.C = out; g.C2 = out2; g.split = out_split; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
-#ifndef TEF_CONV_NO_HALO
     if (int logw = halo_s2_logw(d)) {
         int nch = (q.Ct + HC - 1) / HC;
         g.A = wp + (size_t)d->N * q.Kp; g.lda = nch * HK;
@@ -2047,7 +1936,6 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
                            d->act, q.Ho * q.Wo, out_split, out, out2);
         return tef::check_launch("splitk_reduce_kernel");
     }
-#endif
     int z = k_splits(d->N, q.M, q.Kp);
     if (z == 1) return launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st);
     float *slab = (float *)(ws + L.slab);
@@ -2082,11 +1970,7 @@ int tef_conv_wgrad_parts_supported(const tef_conv_desc *d)
 {
     Geo q;
     if (!make_geo(d, &q)) return 0;
-#ifdef TEF_CONV_NO_WGRAD_HALO
-    return 0;
-#else
     return (halo_logw(d) || wgrad_s2_logw(d)) ? 1 : 0;
-#endif
 }
 
 int tef_conv_wgrad_parts(const tef_conv_desc *d, int nparts, const float *const *g, const float *const *x0,
@@ -2176,7 +2060,6 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
         g.cols = q.Min; g.K = q.K2p;
         g.C = dx0; g.C2 = dx1; g.split = d->C0; g.bias = nullptr; g.act = TEF_ACT_NONE; g.hw = d->H * d->W;
         tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
-#ifndef TEF_CONV_NO_HALO
         tef_conv_desc gd;
         if (int logw = s2d_mode(d, &gd)) {   // stride 2: four parity classes over the output-gradient grid (S2D)
             Geo gq;
@@ -2213,7 +2096,6 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
                                (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1);
             return tef::check_launch("splitk_reduce_kernel");
         }
-#endif
         int z = k_splits(q.Ct, q.Min, q.K2p);
         if (z == 1) {
             if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_FWD>(g, 1, st)) return rc;

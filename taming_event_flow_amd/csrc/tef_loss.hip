@@ -59,7 +59,7 @@ constexpr uint32_t kMetaNonUnit = 1u << 26;  // a mask value is neither 0 nor 1:
 // Window descriptor handed to kernels by value (kernarg segment).
 // ---------------------------------------------------------------------------------------------
 struct Win {
-    int kind, B, H, W, P, F, S, mode_div, M, Md, Mt, nplanes, nimg;
+    int kind, B, H, W, P, F, S, mode_div, M, Md, Mt, nplanes, nimg, scaling;
     int img_base[TEF_MAX_SCALES + 1];
     int off[TEF_MAX_PASSES + 1];
     int doff[TEF_MAX_PASSES + 1];
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
             s2 += part[((size_t)q * kStatParts + k) * 2];
             cnt += part[((size_t)q * kStatParts + k) * 2 + 1];
         }
-        float n = (float)cnt + kEps;
+        float n = w.scaling ? (float)cnt + kEps : 1.0f;      // loss/flow.py:124-127
         float term = (float)s2 / n;
         stats[(size_t)q * 2] = term;
         stats[(size_t)q * 2 + 1] = n;
@@ -1246,7 +1246,8 @@ __device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, in
 
 __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__restrict__ ev,
                                                                   const float *__restrict__ pm, int N, float ts_shift,
-                                                                  float ts_override, int pass_idx, int slot0, int cap,
+                                                                  const float *__restrict__ ts_override, int pass_idx,
+                                                                  int slot0, int cap,
                                                                   int H, int W, int tile, float *__restrict__ ts,
                                                                   float *__restrict__ y, float *__restrict__ x,
                                                                   float *__restrict__ mp, float *__restrict__ mn,
@@ -1295,7 +1296,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
         ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
         int pos = atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, tile, tw, ntiles)], 1);
         size_t o = (size_t)b * cap + slot0 + pos;
-        ts[o] = (ts_override >= 0.0f) ? ts_override : t;
+        ts[o] = ts_override ? ts_override[0] : t;
         y[o] = v.y;
         x[o] = v.z;
         mp[o] = m.x;
@@ -1343,6 +1344,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     memset(w, 0, sizeof(*w));
     w->kind = c->kind; w->B = c->B; w->H = c->H; w->W = c->W; w->P = c->P; w->F = c->F; w->S = c->S;
     w->mode_div = c->mode_div; w->M = c->M; w->Md = c->Md; w->Mt = c->M + c->Md;
+    w->scaling = c->loss_scaling ? 1 : 0;
     w->nplanes = (c->kind == TEF_KIND_ITERATIVE) ? c->P + 1 : 2 * c->S;
     if (c->M < 0 || c->Md < 0 || c->off[0] != 0 || c->doff[0] != 0 || c->off[c->P] != c->M || c->doff[c->P] != c->Md)
         return tef::fail("inconsistent slot offsets");
@@ -1444,7 +1446,7 @@ size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg)
     return make_layout(w).total;
 }
 
-int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, float ts_override, int pass_idx,
+int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx,
                     int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
                     uint8_t *bin, int *cls, void *stream)
 {

@@ -63,7 +63,8 @@ class _SoA:
                 src, shift = ev.to(torch.float32).contiguous(), 0.0
             pmc = pm.to(torch.float32).contiguous()
             rc = _lib.lib().tef_pack_events(
-                src.data_ptr(), pmc.data_ptr(), B, N, shift, ts_override, pass_idx, self.n, self.cap,
+                src.data_ptr(), pmc.data_ptr(), B, N, shift, None if ts_override is None else ts_override.data_ptr(),
+                pass_idx, self.n, self.cap,
                 self.res[0], self.res[1],
                 self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(), self.mn.data_ptr(),
                 self.bin.data_ptr(), self.cls.data_ptr(), _lib.stream_ptr(),
@@ -143,9 +144,9 @@ class BaseEventWarping(torch.nn.Module):
 
     def __init__(self, config, device, loss_scaling=True, border_compensation=True):
         super().__init__()
-        if not loss_scaling or not border_compensation:
-            raise NotImplementedError("the HIP path implements loss_scaling=True, border_compensation=True "
-                                      "(the only values the reference's training loop uses)")
+        if not border_compensation:       # (not reachable through Linear / Iterative: their constructors do not pass it on)
+            raise NotImplementedError("the HIP path implements border_compensation=True (reference loss/flow.py:221,421: "
+                                      "the only value Linear / Iterative can be built with)")
         self.device = torch.device(device)
         self.config = config
         self.loss_scaling = loss_scaling
@@ -212,12 +213,18 @@ class BaseEventWarping(torch.nn.Module):
         for name, t in (("event_list", event_list), ("pol_mask", pol_mask), ("d_event_list", d_event_list),
                         ("d_pol_mask", d_pol_mask)):
             _lib.require_device_tensor(t, name)
-        ovr = d_ovr = -1.0
+        ovr = d_ovr = None
         if self.config["loss"]["round_ts"]:
-            # event_ts[...] = event_ts.min() + 0.5 over the shifted list (loss/flow.py:461-463)
-            ovr = float(event_list[:, :, 0].min().item()) + self._passes + 0.5
+            # event_ts[...] = event_ts.min() + 0.5 over the shifted list (loss/flow.py:461-463), in fp32 on the device like
+            # the reference: min(ts + passes) = fl(min(ts) + passes) (rounding is monotone), then + 0.5.  No host sync.
+            def rounded(lst):
+                return ((lst[:, :, 0].min().to(torch.float32) + float(self._passes)) + 0.5).reshape(1).contiguous()
+
+            if event_list.shape[1] > 0:
+                ovr = rounded(event_list)
             if d_event_list.shape[1] > 0:
-                d_ovr = float(d_event_list[:, :, 0].min().item()) + self._passes + 0.5
+                d_ovr = rounded(d_event_list)
+            win.keep = getattr(win, "keep", []) + [ovr, d_ovr]       # alive until the pack kernels have run
         win.grad.append(event_list, pol_mask, self._passes, ovr)
         win.det.append(d_event_list, d_pol_mask, self._passes, d_ovr)
         self._passes += 1
@@ -236,6 +243,7 @@ class BaseEventWarping(torch.nn.Module):
         cfg.P, cfg.F, cfg.S = P, self._num_flows, len(self.passes_loss)
         cfg.mode_div = getattr(self, "_mode_div", 1)
         cfg.M, cfg.Md = win.grad.n, win.det.n
+        cfg.loss_scaling = 1 if self.loss_scaling else 0
         for t in range(P + 1):
             cfg.off[t] = win.grad.off[t]
             cfg.doff[t] = win.det.off[t]

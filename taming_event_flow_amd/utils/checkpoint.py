@@ -67,15 +67,6 @@ def load_model(prev_runid, model, device, curr_run=None, tb_writer=None):
     return model, starting_epoch
 
 
-def create_model_dir(path_results, runid):
-    """utils/utils.py:52-57."""
-    path_results += runid + "/"
-    if not os.path.exists(path_results):
-        os.makedirs(path_results)
-    print("Results stored at " + path_results + "\n")
-    return path_results
-
-
 def save_model(model, artifact_dir=None):
     """utils/utils.py:60-61: the whole module, pickled, at ``<artifact dir>/model/data/model.pth``."""
     if artifact_dir is None:

@@ -49,11 +49,11 @@ def make_config(H, W, B, P, S, mode="two", spat=None, temp=None, round_ts=False)
     }
 
 
-def run_loss(kind, cfg, win):
+def run_loss(kind, cfg, win, loss_scaling=True):
     """Feed a synthetic window through the reference loss; return loss + d loss / d flow."""
     P = len(win["flows"])
     F = len(win["flows"][0])
-    L = (Iterative if kind == "Iterative" else Linear)(cfg, torch.device("cpu"))
+    L = (Iterative if kind == "Iterative" else Linear)(cfg, torch.device("cpu"), loss_scaling=loss_scaling)
     flows = [[torch.tensor(win["flows"][t][i], requires_grad=True) for i in range(F)] for t in range(P)]
     for t in range(P):
         L.update(
@@ -71,13 +71,13 @@ def run_loss(kind, cfg, win):
 
 
 def save_loss_case(name, kind, H, W, B, P, F, S, mode, n_grad, n_det, seed, sigma=1.5, flow_kind="smooth",
-                   ragged=True, spat=None, temp=None, round_ts=False, integer_coords=True):
+                   ragged=True, spat=None, temp=None, round_ts=False, integer_coords=True, loss_scaling=True):
     rng = np.random.default_rng(seed)
     win = synth.make_window(rng, B, H, W, P, F, n_grad, n_det, sigma, flow_kind, ragged, integer_coords)
     cfg = make_config(H, W, B, P, S, mode, spat, temp, round_ts)
-    loss64, loss32, g = run_loss(kind, cfg, win)
+    loss64, loss32, g = run_loss(kind, cfg, win, loss_scaling)
     meta = dict(kind=kind, H=H, W=W, B=B, P=P, F=F, S=S, mode=mode, spat=spat, temp=temp, round_ts=round_ts,
-                seed=seed, loss=loss64)
+                seed=seed, loss=loss64, loss_scaling=loss_scaling)
     arrays = {"meta": np.array(json.dumps(meta)), "loss": loss32, "dflows": g,
               "flows": np.stack([np.stack(win["flows"][t]) for t in range(P)])}
     for t in range(P):
@@ -197,6 +197,10 @@ def main():
         # the BASELINE resolution and window (128x128, P = 10, 10 000 gradient + 2 000 detached events per pass), one sample
         save_seeded_case("it_two_128_p10", "Iterative", 128, 128, 1, 10, 2, 1, "two", 10000, 2000, seed=31)
         save_seeded_case("lin_128_p10", "Linear", 128, 128, 1, 10, 1, 1, "two", 10000, 2000, seed=32)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--unscaled":
+        save_loss_case("it_two_unscaled", "Iterative", 16, 20, 2, 6, 2, 1, "two", 180, 40, seed=14, loss_scaling=False)
+        save_loss_case("lin_unscaled", "Linear", 16, 20, 2, 4, 2, 1, "two", 150, 30, seed=25, loss_scaling=False)
         return
     save_primitives()
     save_encodings()

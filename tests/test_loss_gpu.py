@@ -20,11 +20,11 @@ def make_cfg(meta):
     }
 
 
-def run_hip(kind, cfg, win, dev, grad_scale=None):
+def run_hip(kind, cfg, win, dev, grad_scale=None, loss_scaling=True):
     from taming_event_flow_amd.loss.flow import Iterative, Linear
 
     P, F = len(win["flows"]), len(win["flows"][0])
-    L = (Iterative if kind == "Iterative" else Linear)(cfg, dev)
+    L = (Iterative if kind == "Iterative" else Linear)(cfg, dev, loss_scaling=loss_scaling)
     flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
     evs = []
     for t in range(P):
@@ -53,7 +53,7 @@ def dev():
 @pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES + FULL_RES_CASES)
 def test_golden_cases(name, dev):
     meta, win, loss, dflows = load_case(name)
-    l, g, evs = run_hip(meta["kind"], make_cfg(meta), win, dev)
+    l, g, evs = run_hip(meta["kind"], make_cfg(meta), win, dev, loss_scaling=meta.get("loss_scaling", True))
     assert abs(l - loss) <= TOL * abs(loss), (l, float(loss))
     assert rel_err(g, dflows) <= TOL
     for t in range(meta["P"]):
