@@ -104,7 +104,9 @@ def algorithmic_bytes(a, delta):
     splats = pairs * (N + Nd) * FB
     maps = P * FB * 2 * HW * 4
     return {
-        # 16 B per event-splat (position 8 + timestamp 4 + mask word 4)  [SURVEY.md §8d]; write-out excluded
+        # 16 B per event-splat (position 8 + timestamp 4 + mask word 4)  [SURVEY.md §8d]; the kernel also turns its
+        # images into (A, R) and the focus-loss sums (what image_stats did): that 8 B x 2 x HW write-out per image is
+        # NOT counted here (roofline_scatter reports it separately)
         "iwe_splat": splats * 16,
         # per (event, head): 12 B event + 8 B masks in, kept positions + 1 meta word out; flow maps once
         "warp": FB * (N + Nd) * (P * (20 + 4) + planes * 8) + maps,
@@ -112,7 +114,6 @@ def algorithmic_bytes(a, delta):
         "chain_bwd": FB * N * (P * 24 + planes * 8 + vecs * 8) + nimg * FB * 2 * HW * 8 + maps,
         # per (grad event, head, reachable map): vector 8 + position 8; gradient maps written once
         "dflow_splat": FB * N * vecs * 16 + maps,
-        "image_stats": nimg * FB * 2 * HW * (8 + 8),
     }, splats
 
 
@@ -359,7 +360,10 @@ def main():
                 "kernel": "iwe_splat", "bound": "hbm", "achieved": kernels["iwe_splat"]["GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic.get("iwe_splat"),
-                "splats_per_launch": splats}
+                "splats_per_launch": splats,
+                "note": "kernel = IWE scatter fused with the image statistics; with its (A, R) write-out (8 B x 2 polarities "
+                        "x H x W per image) counted as well: %.1f GB/s" % (
+                            (alg["iwe_splat"] + (P + 1) * F * B * 2 * H * W * 8) / (kernels["iwe_splat"]["ms"] * 1e-3) / 1e9)}
         # whole loss against the HBM roofline by SURVEY.md section 8d's compulsory traffic: events and masks read once per
         # direction, flow maps read twice and their gradients written once, everything else on chip
         bpe = 48.0 + 24.0 * F * H * W / max(1, a.events + a.detached)

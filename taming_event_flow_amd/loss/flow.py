@@ -52,8 +52,9 @@ class _SoA:
         B, N = ev.shape[0], ev.shape[1]
         if B != self.B:
             raise RuntimeError(f"event list batch {B} != config loader.batch_size {self.B}")
-        if self.n + N > self.cap:
-            self._grow(self.n + N)
+        Np = (N + 15) & ~15                 # passes start at multiples of 16 slots (include/tef.h tef_pack_events)
+        if self.n + Np > self.cap:
+            self._grow(self.n + Np)
         if N:
             in_place = ev.is_contiguous() and ev.dtype == torch.float32 and ev.data_ptr() % 16 == 0
             if in_place:
@@ -70,7 +71,7 @@ class _SoA:
                 self.bin.data_ptr(), self.cls.data_ptr(), _lib.stream_ptr(),
             )
             _lib.check(rc, "tef_pack_events")
-        self.n += N
+        self.n += Np
         self.off.append(self.n)
 
     def struct(self):

@@ -10,7 +10,7 @@ P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_AN
 P2="SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"
 i=1
 for P in "$P1" "$P2"; do
-  timeout 300 rocprofv3 --pmc $P --kernel-include-regex "$K" --output-format csv -d $O/p$i -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events > $O/p$i.json 2> $O/p$i.err
+  timeout 300 rocprofv3 --pmc $P --kernel-include-regex "$K" --output-format csv -d $O/p$i -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-events --no-train-extra > $O/p$i.json 2> $O/p$i.err
   i=$((i+1))
 done
 python3 - <<PY

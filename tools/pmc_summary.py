@@ -14,8 +14,8 @@ import json
 from collections import defaultdict
 
 KERNELS = {                      # kernel symbol prefix -> bench.py name
-    "iter_warp_kernel": "warp", "linear_warp_kernel": "warp", "splat_kernel": "iwe_splat",
-    "image_stats_kernel": "image_stats", "loss_reduce_kernel": "loss_reduce", "iter_chain_bwd_kernel": "chain_bwd",
+    "iter_warp_kernel": "warp", "linear_warp_kernel": "warp", "splat_stats_kernel": "iwe_splat",
+    "loss_reduce_kernel": "loss_reduce", "iter_chain_bwd_kernel": "chain_bwd",
     "linear_bwd_kernel": "chain_bwd", "dflow_splat_kernel": "dflow_splat", "pack_flow_kernel": "pack_flow",
 }
 
