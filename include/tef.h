@@ -53,8 +53,8 @@ double tef_profile_ms(int slot);
 long tef_profile_calls(int slot);
 
 /* Event list of one loss window in structure-of-arrays form, [B][cap] per array.
- * Slots of pass t occupy [off[t], off[t+1]) of every sample's row (see tef_loss_cfg); off[t] are multiples of 16 (the
- * kernels work in rows of 16 slots of one pass): tef_pack_events fills the slots up to the next multiple with empty events.
+ * Slots of pass t occupy [off[t], off[t+1]) of every sample's row (see tef_loss_cfg); off[t] are multiples of 64 (a
+ * wavefront of the chain kernels works on 64 slots of one pass): tef_pack_events fills the slots up to the next multiple with empty events.
  * ts already carries the "+ pass index" shift of loss/flow.py:457-458 (tef_pack_events adds it).
  * mp/mn = polarity mask columns (pos, neg) of dataloader/base.py:265-278.
  * bin[cap] = pass index of each slot (shared by all samples). */
@@ -87,8 +87,8 @@ typedef struct tef_loss_cfg {
  * (loss/flow.py:443-476, 233-288): adds `ts_shift` to ev[:, :, 0] IN PLACE (reference side effect,
  * :457-458) and appends the pass at slot `slot0` of the SoA arrays.  If ts_override (a DEVICE pointer to one float) is
  * not NULL the stored timestamp is that value instead (round_ts, :461-463: the caller computes min + 0.5 of the shifted
- * list on the device, no host round trip).  ev [B,N,4] (ts,y,x,p), pm [B,N,2].  slot0 must be a multiple of 16 and
- * cap >= slot0 + N rounded up to 16: the next pass starts there.
+ * list on the device, no host round trip).  ev [B,N,4] (ts,y,x,p), pm [B,N,2].  slot0 must be a multiple of 64 and
+ * cap >= slot0 + N rounded up to 64: the next pass starts there.
  * The events of the pass are stored sorted by (polarity, 8x8 pixel tile of the H x W frame): the loss is a sum over
  * events, so the order inside a pass is free, and coherent wavefronts halve the cost of the lookups. */
 int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx,

@@ -307,7 +307,7 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t bits, int kb, int kf, flo
 
 // ---------------------------------------------------------------------------------------------
 // Row ranges.  Slots are handled in ROWS of 16 consecutive slots (= one DPP row of a wavefront; pass boundaries are
-// multiples of 16 slots, so a row belongs to one pass).  For every trajectory plane K1 also records, per row, the
+// multiples of 64 slots, so a wavefront, and with it a row, belongs to one pass).  For every trajectory plane K1 also records, per row, the
 // interval [min y, max y] of the row's events that are still inside the frame there.  The scatter kernels split an
 // image into row bands: a band workgroup looks at a row's interval (8 bytes per 16 events) and loads the events only
 // if it can touch the band — events are sorted by 8x8 tile, so a row spans about one tile and its interval is tight.
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
     const bool valid = in_list && (mp != 0.0f || mn != 0.0f);
     const int H = w.H, W = w.W, P = w.P;
     float ts = E.ts[o], y0 = E.y[o], x0 = E.x[o];
-    const int t = E.bin[sl];                            // uniform over the 16-slot row
+    const int t = __builtin_amdgcn_readfirstlane((int)E.bin[sl]);      // passes start at multiples of 64 slots: wave-uniform
     float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
 
     // Bilinear flow lookup of map k at (y, x).  The kernel is VALU-bound (~135 vector instructions per chain step): when
@@ -1083,20 +1083,20 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     xcd_split(blockIdx.x, chunks, ib, chunk);
     if (ib >= w.F * w.B) return;
     int sl = chunk * blockDim.x + threadIdx.x;
-    if (sl >= w.M) return;
+    if (sl >= w.M) return;                              // (M is a multiple of 64: whole wavefronts)
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, P = w.P, M = w.M;
     float *coy = cy + (size_t)ib * P * M + sl, *cox = cx + (size_t)ib * P * M + sl;
     uint32_t mv = meta[(size_t)ib * w.Mt + sl];
     uint32_t bits = mv & 0xffu;
-    int t = g.bin[sl];
+    // Passes start at multiples of 64 slots, so a wavefront belongs to ONE pass: t, and with it the reference time k of
+    // every loop iteration below, is wave-uniform — map / image / plane base addresses and the image statistics are
+    // scalar-register arithmetic and scalar loads instead of per-lane 64-bit index math in a VALU-bound kernel.  Lanes
+    // whose chain has not started yet or has left the frame are masked per iteration.
+    const int t = __builtin_amdgcn_readfirstlane((int)g.bin[sl]);
     // map k receives something from pass t only if |k - t| < delta_passes[0] (largest window and reach); K7 reads
     // exactly those (pass, map) pairs, so only they need a value
     const int reach = P / w.mode_div;
-    if (bits == 0u) {
-        for (int k = max(0, t - reach + 1); k < min(P, t + reach); ++k) { NT_ST(&coy[(size_t)k * M], 0.0f); NT_ST(&cox[(size_t)k * M], 0.0f); }
-        return;
-    }
     int kb = (int)((mv >> 8) & 0xffu) - 1, kf = (int)((mv >> 16) & 0xffu);
     size_t o = (size_t)b * g.cap + sl;
     float ts = g.ts[o], mp = g.mp[o], mn = g.mn[o];
@@ -1104,12 +1104,9 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + sl;
     float c0y = 0.0f, c0x = 0.0f;
 
-    // Both sweeps keep the next trajectory position one iteration ahead (cur = p_k, nxt = the position the
-    // step into p_k was sampled at), so the IWE lookups at cur and the flow lookups at nxt of one iteration
-    // are all independent loads.
     // reference times that can carry a gradient for this event: tref k contributes at scale s iff the event's window is
-    // valid, lo_s <= k <= hi_s and k - delta_s <= t < k + delta_s; the sweeps start at the outermost such tref (beyond
-    // it the adjoint is still zero, so neither the IWE nor the flow Jacobian need to be looked up)
+    // valid, lo_s <= k <= hi_s and k - delta_s <= t < k + delta_s; a lane joins the sweeps at the outermost such tref
+    // (beyond it the adjoint is still zero, so neither the IWE nor the flow Jacobian need to be looked up)
     int k_top = t, k_bot = t + 1;
     for (int s = 0; s < w.S; ++s) {
         if (!((bits >> s) & 1u)) continue;
@@ -1117,6 +1114,8 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         k_top = max(k_top, min(hi, t + delta));
         k_bot = min(k_bot, max(lo, t - delta + 1));
     }
+    // first reference time of each sweep for this lane; an event without any valid window never joins
+    const int ks_f = bits ? min(min(P, kf - 1), k_top) : t, ks_b = bits ? max(max(0, kb + 1), k_bot) : t + 1;
     // gradient w.r.t. the position at tref = k
     const float one_kscale = gout * (1.0f / ((float)(1 << 0) * (float)(2 * reach + 1) * (float)w.S * (float)w.F));
     const float one_delta = (float)reach;
@@ -1125,9 +1124,9 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         if (t < k - reach || t >= k + reach) return make_float2(0.0f, 0.0f);      // window [0, P], delta = reach
         return image_grad<true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, p, ts, mp, mn);
     };
-    // One chain step when EVERY lane of the wavefront has all its flow taps (at `nxt`, map `km`) and image corners (at
-    // `cur`, tref k) inside the frame, adjacent, single polarity: plain 16-byte loads and no validity selects (~25 % fewer
-    // vector instructions; border events send their wavefront through the general code).  Same arithmetic, same order.
+    // One chain step when EVERY active lane of the wavefront has all its flow taps (at `nxt`, map `km`) and image corners
+    // (at `cur`, tref k) inside the frame, adjacent, single polarity: plain 16-byte loads and no validity selects (~25 %
+    // fewer vector instructions; border events send their wavefront through the general code).  Same arithmetic, same order.
     const bool one_pol = !((mp != 0.0f) & (mn != 0.0f));
     auto step_interior = [&](int k, int km, float2 cur, float2 nxt, float2 &gk, float &jyy, float &jyx, float &jxy,
                              float &jxx) -> bool {
@@ -1138,7 +1137,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (sp.iy[0] >= 0) & (sp.iy[1] < H) &
                             (sp.ix[0] >= 0) & (sp.ix[1] < W) & (sp.ix[1] == sp.ix[0] + 1);
         if (__builtin_amdgcn_ballot_w64(!inside) != 0) return false;
-        const int kmc = min(max(km, 0), P - 1);                   // lanes past their chain's end: any valid map
+        const int kmc = min(max(km, 0), P - 1);                   // (the jacobian of the last step is not used)
         Quad2 q = load_quad_interior(flow_map(w, flows, kmc, i, b), y0 * W + x0, W);
         gk = make_float2(0.0f, 0.0f);
         if (t >= k - reach && t < k + reach)
@@ -1147,36 +1146,37 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         return true;
     };
     float ay = 0.0f, ax = 0.0f;
-    {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = P .. t+1
-        int ks = min(min(P, kf - 1), k_top);
-        for (int k = min(P, t + reach); k > ks; --k)
-            if (k - 1 > t) { NT_ST(&coy[(size_t)(k - 1) * M], 0.0f); NT_ST(&cox[(size_t)(k - 1) * M], 0.0f); }
-        float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
-        if (ks > t) cur = NT_LD2(&tr[(size_t)ks * w.Mt]);
-        if (ks - 1 > t) nxt = NT_LD2(&tr[(size_t)(ks - 1) * w.Mt]);
-        for (int k = ks; k > t; --k) {
-            // every load of the step is unconditional (clamped plane / map, result masked): trajectory prefetch, the
-            // two flow rows and the two image rows are in flight together
+    {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = min(P, t + reach) .. t+1
+        const int k0 = min(P, t + reach);
+        // the positions of a step are loaded for every lane, one iteration ahead (planes a lane's chain never reached
+        // hold stale values: such lanes are inactive there)
+        float2 cur = NT_LD2(&tr[(size_t)max(k0, t + 1) * w.Mt]), nxt = NT_LD2(&tr[(size_t)max(k0 - 1, t + 1) * w.Mt]);
+        for (int k = k0; k > t; --k) {
             float2 nn = NT_LD2(&tr[(size_t)max(k - 2, t + 1) * w.Mt]);
-            float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
-            float2 gk;
-            if (!step_interior(k, k - 1, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
-                Taps tp = make_taps(nxt.x, nxt.y, H, W);
-                quad_jacobian(load_quad(flow_map(w, flows, k - 1, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-                gk = pos_grad(k, cur);
-            }
-            ay += gk.x;
-            ax += gk.y;
-            if (k - 1 == t) {
-                float c = (float)(t + 1) - ts;
-                c0y += c * ay;
-                c0x += c * ax;
-            } else {
-                NT_ST(&coy[(size_t)(k - 1) * M], ay);
-                NT_ST(&cox[(size_t)(k - 1) * M], ax);
-                float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
-                ay = ny;
-                ax = nx;
+            if (k <= ks_f) {
+                float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+                float2 gk;
+                if (!step_interior(k, k - 1, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
+                    Taps tp = make_taps(nxt.x, nxt.y, H, W);
+                    quad_jacobian(load_quad(flow_map(w, flows, max(k - 1, 0), i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
+                    gk = pos_grad(k, cur);
+                }
+                ay += gk.x;
+                ax += gk.y;
+                if (k - 1 == t) {
+                    float c = (float)(t + 1) - ts;
+                    c0y += c * ay;
+                    c0x += c * ax;
+                } else {
+                    NT_ST(&coy[(size_t)(k - 1) * M], ay);
+                    NT_ST(&cox[(size_t)(k - 1) * M], ax);
+                    float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
+                    ay = ny;
+                    ax = nx;
+                }
+            } else if (k - 1 > t) {          // the chain has not started yet: this map gets nothing from the event
+                NT_ST(&coy[(size_t)(k - 1) * M], 0.0f);
+                NT_ST(&cox[(size_t)(k - 1) * M], 0.0f);
             }
             cur = nxt;
             nxt = nn;
@@ -1184,34 +1184,35 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     }
     ay = 0.0f;
     ax = 0.0f;
-    {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = 0 .. t
-        int ks = max(max(0, kb + 1), k_bot);
-        for (int k = max(0, t - reach + 1); k < ks; ++k)
-            if (k < t) { NT_ST(&coy[(size_t)k * M], 0.0f); NT_ST(&cox[(size_t)k * M], 0.0f); }
-        float2 cur = make_float2(0.0f, 0.0f), nxt = cur;
-        if (ks <= t) cur = NT_LD2(&tr[(size_t)ks * w.Mt]);
-        if (ks + 1 <= t) nxt = NT_LD2(&tr[(size_t)(ks + 1) * w.Mt]);
-        for (int k = ks; k <= t; ++k) {
+    {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = max(0, t - reach + 1) .. t
+        const int k0 = max(0, t - reach + 1);
+        float2 cur = NT_LD2(&tr[(size_t)min(k0, t) * w.Mt]), nxt = NT_LD2(&tr[(size_t)min(k0 + 1, t) * w.Mt]);
+        for (int k = k0; k <= t; ++k) {
             float2 nn = NT_LD2(&tr[(size_t)min(k + 2, t) * w.Mt]);
-            float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
-            float2 gk;
-            if (!step_interior(k, k, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
-                Taps tp = make_taps(nxt.x, nxt.y, H, W);
-                quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-                gk = pos_grad(k, cur);
-            }
-            ay += gk.x;
-            ax += gk.y;
-            if (k == t) {
-                float c = (float)t - ts;
-                c0y += c * ay;
-                c0x += c * ax;
-            } else {
-                NT_ST(&coy[(size_t)k * M], -ay);
-                NT_ST(&cox[(size_t)k * M], -ax);
-                float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
-                ay = ny;
-                ax = nx;
+            if (k >= ks_b) {
+                float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+                float2 gk;
+                if (!step_interior(k, k, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
+                    Taps tp = make_taps(nxt.x, nxt.y, H, W);
+                    quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
+                    gk = pos_grad(k, cur);
+                }
+                ay += gk.x;
+                ax += gk.y;
+                if (k == t) {
+                    float c = (float)t - ts;
+                    c0y += c * ay;
+                    c0x += c * ax;
+                } else {
+                    NT_ST(&coy[(size_t)k * M], -ay);
+                    NT_ST(&cox[(size_t)k * M], -ax);
+                    float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
+                    ay = ny;
+                    ax = nx;
+                }
+            } else if (k < t) {
+                NT_ST(&coy[(size_t)k * M], 0.0f);
+                NT_ST(&cox[(size_t)k * M], 0.0f);
             }
             cur = nxt;
             nxt = nn;
@@ -1412,8 +1413,8 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
         mn[o] = m.y;
         if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
     }
-    // alignment slots up to the next multiple of 16 (K1 works in rows of 16 slots of one pass): empty events
-    for (int e = N + tid; e < ((N + 15) & ~15); e += kPackThreads) {
+    // alignment slots up to the next multiple of 64 (a wavefront of the chain kernels belongs to one pass): empty events
+    for (int e = N + tid; e < ((N + 63) & ~63); e += kPackThreads) {
         size_t o = (size_t)b * cap + slot0 + e;
         ts[o] = y[o] = x[o] = mp[o] = mn[o] = 0.0f;
         if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
@@ -1468,7 +1469,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
         w->off[t] = c->off[t];
         w->doff[t] = c->doff[t];
         if (t && (c->off[t] < c->off[t - 1] || c->doff[t] < c->doff[t - 1])) return tef::fail("offsets not monotone");
-        if ((c->off[t] | c->doff[t]) & 15) return tef::fail("pass offsets must be multiples of 16 slots (tef_pack_events pads)");
+        if ((c->off[t] | c->doff[t]) & 63) return tef::fail("pass offsets must be multiples of 64 slots (tef_pack_events pads)");
     }
     int n = 0;
     for (int s = 0; s < c->S; ++s) {
@@ -1582,9 +1583,9 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, co
                     int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
                     uint8_t *bin, int *cls, void *stream)
 {
-    if (B < 1 || N < 0 || slot0 < 0 || (slot0 & 15) || slot0 + ((N + 15) & ~15) > cap || pass_idx < 0 ||
+    if (B < 1 || N < 0 || slot0 < 0 || (slot0 & 63) || slot0 + ((N + 63) & ~63) > cap || pass_idx < 0 ||
         pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
-        return tef::fail("tef_pack_events: bad sizes (slot0 must be a multiple of 16, cap must hold N rounded up to 16)"), TEF_ERR_INVALID;
+        return tef::fail("tef_pack_events: bad sizes (slot0 must be a multiple of 64, cap must hold N rounded up to 64)"), TEF_ERR_INVALID;
     if (N == 0) return 0;
     int tile = 8;
     while (4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;

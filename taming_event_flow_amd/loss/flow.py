@@ -52,7 +52,7 @@ class _SoA:
         B, N = ev.shape[0], ev.shape[1]
         if B != self.B:
             raise RuntimeError(f"event list batch {B} != config loader.batch_size {self.B}")
-        Np = (N + 15) & ~15                 # passes start at multiples of 16 slots (include/tef.h tef_pack_events)
+        Np = (N + 63) & ~63                 # passes start at multiples of 64 slots (include/tef.h tef_pack_events)
         if self.n + Np > self.cap:
             self._grow(self.n + Np)
         if N:

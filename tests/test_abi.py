@@ -45,9 +45,9 @@ def test_version_and_size_queries(built):
     assert lib.tef_version() == 1
     cfg = built.LossCfg()
     cfg.kind, cfg.B, cfg.H, cfg.W, cfg.P, cfg.F, cfg.S, cfg.mode_div = 0, 2, 16, 20, 4, 2, 1, 2
-    cfg.M, cfg.Md = 64, 0
+    cfg.M, cfg.Md = 256, 0
     for t in range(5):
-        cfg.off[t] = 16 * t
+        cfg.off[t] = 64 * t
     assert lib.tef_loss_workspace_bytes(ctypes.byref(cfg)) > 0
     # invalid configurations are rejected with a message, not a crash
     cfg.mode_div = 4
