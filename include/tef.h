@@ -205,6 +205,12 @@ int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, c
 int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
                            const float *wp, const float *bias, float *out, float *out2, int out_split, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* The same with the ConvGRU state update folded into the epilogue (one output tensor, out_split = N): beside
+ * out = act(...) the kernel stores bl_out = bl_h * (1 - bl_u) + out * bl_u, all [B,N,Ho,Wo] (submodules.py:150: the out
+ * gate's convolution delivers the new state, no separate blend pass).  bl_* all NULL = tef_conv_forward_split. */
+int tef_conv_forward_blend(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
+                           const float *bias, float *out, float *out2, int out_split, const float *bl_h, const float *bl_u,
+                           float *bl_out, void *workspace, size_t workspace_bytes, void *stream);
 int tef_conv_backward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
                       const float *w2, const float *out, const float *dout, float *dx0, float *dx1, float *dweight,
                       float *dbias, void *workspace, size_t workspace_bytes, void *stream);

@@ -92,6 +92,8 @@ SIGNATURES = {
                                          ctypes.c_size_t, _fp]),
     "tef_conv_forward_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
                                               _fp, ctypes.c_size_t, _fp]),
+    "tef_conv_forward_blend": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int,
+                                              _fp, _fp, _fp, _fp, ctypes.c_size_t, _fp]),
     "tef_conv_backward_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp,
                                                ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, ctypes.c_int, _fp,
                                                ctypes.c_size_t, _fp]),

@@ -3,7 +3,7 @@
 //
 //   forward   update | reset = sigmoid(conv([x, h]))            one GEMM with 2C output rows, two output tensors
 //             out_inputs     = tanh(conv([x, h * reset]))       the product is formed inside the patch loads
-//             new_state      = h * (1 - update) + out_inputs * update
+//             new_state      = h * (1 - update) + out_inputs * update      in the epilogue of that same GEMM
 //
 //   backward  every gradient that has several consumers is SUMMED WHERE IT IS CONSUMED (the kernels below take up to four
 //             addend pointers), never accumulated by a separate pass, and the gate pre-activation gradients are formed
@@ -262,8 +262,8 @@ int tef_convgru_cell_fwd(const tef_gru_desc *d, const float *x, const float *h, 
     tef_conv_desc ur = gate_desc(d, 2 * d->C, TEF_ACT_SIGMOID), og = gate_desc(d, d->C, TEF_ACT_TANH);
     // update | reset share their input (submodules.py:146-148): one GEMM, two output tensors
     if (int rc = tef_conv_forward_split(&ur, x, h, nullptr, wp_ur, bias_ur, u, r, d->C, workspace, workspace_bytes, stream)) return rc;
-    if (int rc = tef_conv_forward(&og, x, h, r, wp_o, bias_o, o, workspace, workspace_bytes, stream)) return rc;
-    return tef_gru_blend(h, u, o, (size_t)d->B * d->C * d->H * d->W, hn, stream);      // :150
+    // out gate on [x, h * r] (the product is formed in the patch loads); its epilogue also writes the new state (:150)
+    return tef_conv_forward_blend(&og, x, h, r, wp_o, bias_o, o, nullptr, d->C, h, u, hn, workspace, workspace_bytes, stream);
 }
 
 int tef_convgru_cell_bwd(const tef_gru_desc *d, const float *x, const float *h, const float *u, const float *r,

@@ -64,7 +64,19 @@ struct GemmArgs {
     int ksplit;           // EPI_ATOMIC / EPI_SLAB: reduction range per blockIdx.z
     int valid_cols;
     int s2d_ct;           // stride-2 input gradient on the halo kernel: rows = 4 parity classes x s2d_ct channels
+    // ConvGRU state update fused into the out gate's epilogue (EPI_FWD, one output tensor): with v = act(...) the new
+    // state bl_out = bl_h * (1 - bl_u) + v * bl_u is stored beside v (reference submodules.py:150); all null otherwise
+    const float *bl_h, *bl_u;
+    float *bl_out;
 };
+
+__device__ __forceinline__ void store_blend(const GemmArgs &g, size_t idx, float v)
+{
+    if (g.bl_out) {
+        const float uu = g.bl_u[idx];
+        g.bl_out[idx] = g.bl_h[idx] * (1.0f - uu) + v * uu;
+    }
+}
 
 __device__ __forceinline__ float apply_act(float v, int act)
 {
@@ -493,8 +505,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmArgs g)
                 if (EPI == EPI_FWD) {
                     if (g.bias) v += g.bias[r];
                     v = apply_act(v, g.act);
-                    if (r < g.split) g.C[((size_t)img * g.split + r) * g.hw + px] = v;
-                    else g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
+                    if (r < g.split) {
+                        const size_t idx = ((size_t)img * g.split + r) * g.hw + px;
+                        g.C[idx] = v;
+                        store_blend(g, idx, v);
+                    } else {
+                        g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
+                    }
                 } else if (EPI == EPI_SLAB) {
                     g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + c] = v;
                 } else {        // rows < split accumulate into C, the rest into C2 (row-concatenated parameters)
@@ -853,8 +870,13 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
             } else if (EPI == EPI_FWD) {
                 if (g.bias) v += g.bias[r];
                 v = apply_act(v, g.act);
-                if (r < g.split) g.C[((size_t)img_l * g.split + r) * g.hw + px] = v;
-                else g.C2[((size_t)img_l * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
+                if (r < g.split) {
+                    const size_t idx = ((size_t)img_l * g.split + r) * g.hw + px;
+                    g.C[idx] = v;
+                    store_blend(g, idx, v);
+                } else {
+                    g.C2[((size_t)img_l * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
+                }
             } else {
                 g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + cc] = v;
             }
@@ -1107,7 +1129,9 @@ __global__ __launch_bounds__(NT) void wgrad3x3_halo_kernel(GemmArgs g, WgradPart
 // image) per thread when the geometry allows 16-byte accesses
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slab, int z, int rows, int cols,
                                                             const float *__restrict__ bias, int act, int hw, int split,
-                                                            float *__restrict__ out, float *__restrict__ out2)
+                                                            float *__restrict__ out, float *__restrict__ out2,
+                                                            const float *__restrict__ bl_h, const float *__restrict__ bl_u,
+                                                            float *__restrict__ bl_out)
 {
     const size_t plane = (size_t)rows * cols;
     if (((cols | hw) & 3) == 0) {
@@ -1127,6 +1151,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         float *o = r < split ? out + ((size_t)img * split + r) * hw + px
                              : out2 + ((size_t)img * (rows - split) + (r - split)) * hw + px;
         *reinterpret_cast<float4 *>(o) = v;
+        if (bl_out && r < split) {          // ConvGRU state update beside the out gate's activation (submodules.py:150)
+            const size_t idx = ((size_t)img * split + r) * hw + px;
+            const float4 hh = *reinterpret_cast<const float4 *>(bl_h + idx), uu = *reinterpret_cast<const float4 *>(bl_u + idx);
+            *reinterpret_cast<float4 *>(bl_out + idx) = make_float4(hh.x * (1.0f - uu.x) + v.x * uu.x, hh.y * (1.0f - uu.y) + v.y * uu.y,
+                                                                    hh.z * (1.0f - uu.z) + v.z * uu.z, hh.w * (1.0f - uu.w) + v.w * uu.w);
+        }
         return;
     }
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1136,8 +1166,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     for (int k = 0; k < z; ++k) v += slab[(size_t)k * plane + (size_t)r * cols + c];
     v = apply_act(v, act);
     int img = c / hw, px = c - img * hw;
-    if (r < split) out[((size_t)img * split + r) * hw + px] = v;
-    else out2[((size_t)img * (rows - split) + (r - split)) * hw + px] = v;
+    if (r < split) {
+        const size_t idx = ((size_t)img * split + r) * hw + px;
+        out[idx] = v;
+        if (bl_out) {
+            const float uu = bl_u[idx];
+            bl_out[idx] = bl_h[idx] * (1.0f - uu) + v * uu;
+        }
+    } else {
+        out2[((size_t)img * (rows - split) + (r - split)) * hw + px] = v;
+    }
 }
 
 // split-K epilogue of the stride-2 input gradient (conv3x3_halo_kernel, S2D): slab rows = (parity class, channel), slab
@@ -1885,6 +1923,14 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
                            const float *wp, const float *bias, float *out, float *out2, int out_split, void *workspace,
                            size_t workspace_bytes, void *stream)
 {
+    return tef_conv_forward_blend(d, x0, x1, gate1, wp, bias, out, out2, out_split, nullptr, nullptr, nullptr, workspace,
+                                  workspace_bytes, stream);
+}
+
+int tef_conv_forward_blend(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
+                           const float *bias, float *out, float *out2, int out_split, const float *bl_h, const float *bl_u,
+                           float *bl_out, void *workspace, size_t workspace_bytes, void *stream)
+{
     Geo q;
     if (!make_geo(d, &q)) return TEF_ERR_INVALID;
     if (!x0 || (d->C1 > 0 && !x1) || !wp || !out || !workspace) return tef::fail("tef_conv_forward: null pointer"), TEF_ERR_INVALID;
@@ -1894,7 +1940,9 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     if (workspace_bytes < L.total) return tef::fail("tef_conv_forward: workspace too small"), TEF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
-    if (pointwise_small(d) && out_split == d->N) {
+    if ((bl_out != nullptr) != (bl_h != nullptr && bl_u != nullptr) || (bl_out && out_split != d->N))
+        return tef::fail("tef_conv_forward_blend: bl_h, bl_u and bl_out go together, with a single output tensor"), TEF_ERR_INVALID;
+    if (pointwise_small(d) && out_split == d->N && !bl_out) {
         tef::ProfScope ps(tef::PROF_CONV_FWD, st);
         hipLaunchKernelGGL(pw_fwd_kernel, dim3((unsigned)((q.M + 31) / 32)), dim3(256), 0, st, x0, wp, bias, d->B, d->C0, d->N,
                            q.Ho * q.Wo, q.Kp, d->act, out);
@@ -1905,6 +1953,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     g.G = forward_gather(d, q, x0, x1, gate1);
     g.cols = q.M; g.K = q.Kp;
     g.C = out; g.C2 = out2; g.split = out_split; g.bias = bias; g.act = d->act; g.hw = q.Ho * q.Wo;
+    g.bl_h = bl_h; g.bl_u = bl_u; g.bl_out = bl_out;
     tef::ProfScope ps(tef::PROF_CONV_FWD, st);
     if (int logw = halo_s2_logw(d)) {
         int nch = (q.Ct + HC - 1) / HC;
@@ -1918,7 +1967,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
         if (int rc = launch_halo_s2<EPI_SLAB>(g, logw, z, st)) return rc;
         size_t n = (size_t)d->N * q.M;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
-                           d->act, q.Ho * q.Wo, out_split, out, out2);
+                           d->act, q.Ho * q.Wo, out_split, out, out2, bl_h, bl_u, bl_out);
         return tef::check_launch("splitk_reduce_kernel");
     }
     if (int logw = halo_mode(d)) {
@@ -1933,7 +1982,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
         if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
         size_t n = (size_t)d->N * q.M;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
-                           d->act, q.Ho * q.Wo, out_split, out, out2);
+                           d->act, q.Ho * q.Wo, out_split, out, out2, bl_h, bl_u, bl_out);
         return tef::check_launch("splitk_reduce_kernel");
     }
     int z = k_splits(d->N, q.M, q.Kp);
@@ -1945,7 +1994,7 @@ int tef_conv_forward_split(const tef_conv_desc *d, const float *x0, const float 
     if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_SLAB>(g, z, st)) return rc;
     size_t n = (size_t)d->N * q.M;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, d->N, q.M, bias,
-                       d->act, q.Ho * q.Wo, out_split, out, out2);
+                       d->act, q.Ho * q.Wo, out_split, out, out2, bl_h, bl_u, bl_out);
     return tef::check_launch("splitk_reduce_kernel");
 }
 
@@ -2093,7 +2142,8 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
             if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
             size_t n = (size_t)q.Ct * q.Min;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min,
-                               (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1);
+                               (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1, (const float *)nullptr, (const float *)nullptr,
+                               (float *)nullptr);
             return tef::check_launch("splitk_reduce_kernel");
         }
         int z = k_splits(q.Ct, q.Min, q.K2p);
@@ -2106,7 +2156,8 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
             if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_SLAB>(g, z, st)) return rc;
             size_t n = (size_t)q.Ct * q.Min;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min,
-                               (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1);
+                               (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1, (const float *)nullptr, (const float *)nullptr,
+                               (float *)nullptr);
             if (int rc = tef::check_launch("splitk_reduce_kernel")) return rc;
         }
     }
