@@ -321,6 +321,13 @@ int tef_val_average_flow(const float *maps_x, const float *maps_y, int P, int H,
  * flow [B][2][H][W] (ch0 = x), event_list [B][N][4] (ts in [0,1], y, x, p), pol_mask [B][N][2]; out [B][2][H][W]. */
 int tef_pol_iwe(const float *flow, const float *event_list, const float *pol_mask, int B, int N, int H, int W,
                 int round_idx, int round_flow, float *out, void *stream);
+/* Stand-alone forms of the interpolation primitives for callers that use them one by one (utils/iwe.py:63-113
+ * get_interpolation, :116-136 interpolate; forward only — the differentiable path is the fused loss).
+ * loc [B][n][2] = (y, x).  Bilinear: idx / weights [B][4n] (corner blocks TL, TR, BL, BR along the event axis, linear pixel
+ * index as a float like the reference, 0 with weight 0 outside the frame); round_idx: [B][n], nearest pixel, weight 1 / 0.
+ * tef_scatter_add: out [B][HW] = 0, then out[b][idx] += weights (* mask, [B][n'] or NULL). */
+int tef_interp_corners(const float *loc, int B, int n, int H, int W, int round_idx, float *idx, float *weights, void *stream);
+int tef_scatter_add(const float *idx, const float *weights, const float *mask, int B, int n, int HW, float *out, void *stream);
 /* average endpoint error over pixels with valid ground truth (and events).  flow_val.py:276-314 */
 int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int mask_passes, int H, int W, float *out,
                 void *stream);

@@ -328,6 +328,49 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+// ---- stand-alone forms of the reference's interpolation primitives (utils/iwe.py:63-136), forward only -----------------
+// get_interpolation: corners TL, TR, BL, BR as four blocks of n along the event axis; linear index iy * W + ix and bilinear
+// weight per corner, both zeroed for corners outside the frame; round_idx: nearest pixel (torch.round), weight 1.
+__global__ __launch_bounds__(256) void interp_corners_kernel(const float *__restrict__ loc, int B, int n, int H, int W,
+                                                             int round_idx, float *__restrict__ idx, float *__restrict__ wgt)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * n) return;
+    const int b = e / n, k = e - b * n;
+    const float y = loc[2 * (size_t)e], x = loc[2 * (size_t)e + 1];
+    if (round_idx) {
+        const float ry = rintf(y), rx = rintf(x);
+        const float m = (ry >= 0.0f && ry < (float)H && rx >= 0.0f && rx < (float)W) ? 1.0f : 0.0f;
+        idx[e] = (ry * m) * (float)W + rx * m;
+        wgt[e] = m;                                       // prod(ones) * mask
+        return;
+    }
+    const float cy[2] = {floorf(y), floorf(y + 1.0f)}, cx[2] = {floorf(x), floorf(x + 1.0f)};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float iy = cy[c >> 1], ix = cx[c & 1];
+        const float m = (iy >= 0.0f && iy < (float)H && ix >= 0.0f && ix < (float)W) ? 1.0f : 0.0f;
+        const float w = fmaxf(0.0f, 1.0f - fabsf(y - iy)) * fmaxf(0.0f, 1.0f - fabsf(x - ix));
+        const size_t o = ((size_t)b * 4 + c) * n + k;
+        idx[o] = (iy * m) * (float)W + ix * m;
+        wgt[o] = w * m;
+    }
+}
+
+// interpolate: out[b][idx] += w (* mask); out zeroed by the caller
+__global__ __launch_bounds__(256) void scatter_add_kernel(const float *__restrict__ idx, const float *__restrict__ wgt,
+                                                          const float *__restrict__ mask, int B, int n, int HW,
+                                                          float *__restrict__ out)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= B * n) return;
+    const int b = e / n;
+    float w = wgt[e];
+    if (mask) w *= mask[e];
+    const long p = (long)idx[e];
+    if (p >= 0 && p < HW) atomicAdd(out + (size_t)b * HW + p, w);
+}
+
 extern "C" {
 
 int tef_val_event_step(const float *fx, const float *fy, int H, int W, float *loc, float *ts, float *mask, int N,
@@ -435,6 +478,28 @@ int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int
     hipLaunchKernelGGL(val_aee_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, gt, event_mask, mask_passes, H * W,
                        out);
     return tef::check_launch("val_aee_kernel");
+}
+
+
+int tef_interp_corners(const float *loc, int B, int n, int H, int W, int round_idx, float *idx, float *weights, void *stream)
+{
+    if (B < 1 || n < 0 || H < 1 || W < 1 || !idx || !weights || (n > 0 && !loc))
+        return tef::fail("tef_interp_corners: bad arguments"), TEF_ERR_INVALID;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(interp_corners_kernel, dim3(nblk(B * n)), dim3(256), 0, (hipStream_t)stream, loc, B, n, H, W, round_idx,
+                       idx, weights);
+    return tef::check_launch("interp_corners_kernel");
+}
+
+int tef_scatter_add(const float *idx, const float *weights, const float *mask, int B, int n, int HW, float *out, void *stream)
+{
+    if (B < 1 || n < 0 || HW < 1 || !out || (n > 0 && (!idx || !weights)))
+        return tef::fail("tef_scatter_add: bad arguments"), TEF_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)B * HW, st) != hipSuccess) return tef::fail("memset failed"), TEF_ERR_LAUNCH;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_kernel, dim3(nblk(B * n)), dim3(256), 0, st, idx, weights, mask, B, n, HW, out);
+    return tef::check_launch("scatter_add_kernel");
 }
 
 }  // extern "C"

@@ -76,3 +76,30 @@ def test_compute_pol_iwe():
             assert rel_err(got, z[f"iwe_{int(ri)}{int(rf)}"]) <= 1e-5, (ri, rf)
     one = iwe.deblur_events(flow, ev, (H, W), polarity_mask=pm[:, :, 0:1]).cpu().numpy()
     assert rel_err(one, z["iwe_11"][:, 0:1]) <= 1e-5
+
+
+def test_iwe_primitives_standalone():
+    """utils.iwe's training-time primitives as importable functions (reference utils/iwe.py:5-136), forward values against
+    the reference's recorded outputs (tests/golden/primitives.npz)."""
+    import os
+
+    from conftest import GOLDEN, rel_err
+    from taming_event_flow_amd.utils import iwe
+
+    z = np.load(os.path.join(GOLDEN, "primitives.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.tensor(a, device=dev)      # noqa: E731
+    ef = iwe.get_event_flow(t(z["gef_fx"]), t(z["gef_fy"]), t(z["gef_loc"]))
+    assert rel_err(ef.cpu().numpy(), z["gef_out"]) < 1e-6
+    prop = iwe.event_propagation(t(z["prop_ts"]), t(z["gef_loc"]), t(z["gef_out"]), 1.0)
+    assert rel_err(prop.cpu().numpy(), z["prop_out"]) < 1e-6
+    ploc, ppm = iwe.purge_unfeasible(prop, t(z["purge_pm"]), (H, W))
+    assert np.array_equal(ploc.cpu().numpy(), z["purge_loc"]) and np.array_equal(ppm.cpu().numpy(), z["purge_mask"])
+    idx, w = iwe.get_interpolation(t(z["gef_loc"]), (H, W))
+    assert np.array_equal(idx.cpu().numpy(), z["gi_idx"]) and rel_err(w.cpu().numpy(), z["gi_w"]) < 1e-6
+    pm4 = torch.cat([t(z["purge_pm"])[:, :, 0:1]] * 4, 1)
+    img = iwe.interpolate(idx, w, (H, W), polarity_mask=pm4)
+    assert img.shape == z["interp_img"].shape and rel_err(img.cpu().numpy(), z["interp_img"]) < 1e-6
+    idx_r, w_r = iwe.get_interpolation(t(z["gef_loc"]), (H, W), round_idx=True)
+    assert np.array_equal(idx_r.cpu().numpy(), z["gi_round_idx"]) and np.array_equal(w_r.cpu().numpy(), z["gi_round_w"])
