@@ -797,6 +797,8 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
                 return rg;
             };
             struct Quad { uint32_t mv; float2 p; float ts; int c; };
+            // list entry of a hit row: x = first slot of the row, y = [lo | hi << 8 | polarity << 16 | detached << 17] with
+            // [lo, hi) the lanes of the row that belong to the run (everything a quad needs, decided once per row)
             auto load_quad_rows = [&](int s, int h) -> Quad {      // events of list entries s .. s + 3, 16 lanes each
                 Quad qd;
                 qd.mv = 0u;
@@ -805,17 +807,20 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
                 qd.c = 0;
                 const int e = s + (lane >> 4);
                 if (e < h) {
-                    const int2 en = list[e];              // (row, run)
-                    const int u = en.x * 16 + (lane & 15), r = en.y;
-                    const int u0 = run_u0[r];
-                    qd.c = r & 1;
-                    if (u >= u0 && u < u0 + run_len[r]) {
+                    const int2 en = list[e];
+                    const int l16 = lane & 15, u = en.x + l16;
+                    qd.c = (en.y >> 16) & 1;
+                    if (l16 >= (en.y & 0xff) && l16 < ((en.y >> 8) & 0xff)) {
                         qd.mv = mt[u];
                         qd.p = pl[u];
-                        qd.ts = ((r >> 1) >= nb ? tsd : tsg)[u];
+                        qd.ts = ((en.y >> 17) ? tsd : tsg)[u];
                     }
                 }
                 return qd;
+            };
+            auto list_entry = [&](int row, int r) {
+                const int u0 = run_u0[r], u1 = u0 + run_len[r], ub = row * 16;
+                return make_int2(ub, max(u0 - ub, 0) | (min(u1 - ub, 16) << 8) | ((r & 1) << 16) | (((r >> 1) >= nb ? 1 : 0) << 17));
             };
             // groups of 128 rows (two intervals per lane); the hit rows are worked through in batches of 16 (four quads of
             // 4 x 16 lanes), the next batch's events in flight while a batch is processed
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
                 for (int hh = 0; hh < 2; ++hh) {
                     const bool hit = rg_cur[hh].y >= band_lo && rg_cur[hh].x < band_hi;      // (NaN for an empty / absent row)
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    if (hit) list[h + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] = make_int2(row_cur[hh], r_cur[hh]);
+                    if (hit) list[h + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] = list_entry(row_cur[hh], r_cur[hh]);
                     h += __builtin_popcountll(mask);
                 }
                 __builtin_amdgcn_wave_barrier();
