@@ -94,6 +94,9 @@ class MultiResUNetRecurrent(nn.Module):
                                              bias=plan.final_bias) for r in plan.of("pred"))
         self.states = [None] * self.num_states
         self._engine = None
+        # extra factor on the full-resolution flows of the fused pass: a training loop that multiplies the network's
+        # output by loss.flow_scaling (reference train_flow.py:107-108) can have the pass do it in its last kernel
+        self.flow_scale = 1.0
 
     # -- switches train.Trainer flips on every PackedWeights of the tree (submodules.enable_*): read them where they live
     @property

@@ -227,9 +227,10 @@ class PassEngine:
             d = self.conv_fwd(dec._packed, (dec.conv2d.weight,), (dec.conv2d.bias,), x0, x1, 1, "relu")
             p = self.conv_fwd(head._packed, (head.conv2d.weight,), (head.conv2d.bias,), d, None, 1, plan.final_activation)
             s = 2 ** (nlev - 1 - k)
-            flows.append(self.upsample(p, None, s, mul=float(s), crop=(ph, pw)))
+            mul = float(s) * a.flow_scale          # resolution factor (model.py:76-81) x the caller's flow scaling
+            flows.append(self.upsample(p, None, s, mul=mul, crop=(ph, pw)))
             if keep:
-                tape.dec.append((cur.shape, x0, x1, d, p, s))
+                tape.dec.append((cur.shape, x0, x1, d, p, s, mul))
             cur, pred = d, p
         if keep:
             tape.geom = (ph, pw)
@@ -245,10 +246,10 @@ class PassEngine:
         d_feat = None                       # gradient arriving at decoder k's output from decoder k + 1
         for k in range(nlev - 1, -1, -1):
             dec, head = a.decoders[k], a.preds[k]
-            src_shape, x0, x1, d, p, s = tape.dec[k]
+            src_shape, x0, x1, d, p, s, mul = tape.dec[k]
             srcs = []
             if dflows[k] is not None:
-                srcs.append(self.upsample_bwd(dflows[k].contiguous(), p.shape, s, mul=float(s), crop=(ph, pw)))
+                srcs.append(self.upsample_bwd(dflows[k].contiguous(), p.shape, s, mul=mul, crop=(ph, pw)))
             if d_prev_pred is not None:
                 srcs.append(d_prev_pred)
             feat_srcs = [d_feat] if d_feat is not None else []

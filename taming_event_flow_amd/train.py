@@ -201,8 +201,14 @@ class Trainer:
     def _forward_update(self, inputs):
         """train_flow.py:101-118: forward, scale, hand the pass to the loss.  True when the window is complete."""
         cfg = self.cfg
-        x = self.model(inputs["net_input"])
-        flows = [f * cfg["loss"]["flow_scaling"] for f in x["flow"]]
+        # flow_scaling (train_flow.py:107-108) rides on the pass's final up-sampling kernel when the model offers it
+        arch = getattr(self.model, "arch", None)
+        if hasattr(arch, "flow_scale"):
+            arch.flow_scale = float(cfg["loss"]["flow_scaling"])
+            flows = self.model(inputs["net_input"])["flow"]
+            arch.flow_scale = 1.0
+        else:
+            flows = [f * cfg["loss"]["flow_scaling"] for f in self.model(inputs["net_input"])["flow"]]
         self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
                                   inputs["d_event_list_pol_mask"])
         return self.loss_function.num_passes >= cfg["data"]["passes_loss"]
