@@ -49,13 +49,13 @@ def parse():
     ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
                     help="experiment: pre-sort the synthetic events of each pass on the host")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--step-graph", action="store_true",
+    ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
                     help="loss mode: replay a captured hipGraph of the step (for hosts too slow to enqueue 0.8 ms steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-extra", action="store_true",
                     help="loss mode at 1 GPU: skip the short training-window measurement appended as `extra`")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
-    ap.add_argument("--event-every", type=int, default=4,
+    ap.add_argument("--event-every", type=int, default=16,
                     help="per-kernel HIP events are recorded on every K-th timed step (each pair costs a few us of stream time)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: repeat the window this long")
     return ap.parse_args()
@@ -246,12 +246,13 @@ def main():
     for k in range(a.warmup):
         step(k)
     barrier()
-    # One step is six kernel launches behind ~0.3 ms of Python (autograd + ctypes), enqueued asynchronously: the GPU sets
-    # the pace unless the host is unusually slow (1.1-1.2 ms per step seen on some boxes against 0.82).  --step-graph
-    # replays a hipGraph of the same step instead (same launches, same buffers; ~0.1 ms of graph launch per replay, so it
-    # only pays on such hosts); every `event_every`-th step stays eager because its launches carry HIP events.
-    graphs = []
-    if a.step_graph:
+    # One step is five kernel launches behind ~0.3-0.5 ms of Python (autograd + ctypes), enqueued asynchronously: the GPU
+    # sets the pace unless the host is slow (0.9-1.1 ms per step seen on some boxes against 0.75 of kernels).  The step is
+    # therefore also captured as a hipGraph (same launches, same buffers) and, by default, a short probe decides which of
+    # the two launch paths the timed region uses (`--step-graph on|off` forces one); every `event_every`-th step stays
+    # eager because its launches carry HIP events.
+    graphs, probe = [], None
+    if a.step_graph != "off":
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -269,6 +270,24 @@ def main():
             print(f"[bench] step graph capture failed ({e!r}); running every step eagerly", file=sys.stderr)
             graphs = []
         torch.cuda.synchronize()
+    if graphs and a.step_graph == "auto":
+        # which launch path does this host sustain?  a short untimed probe of both; the graph is used when it is faster
+        def probe_ms(fn, n=24):
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for k in range(n):
+                fn(k)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0_) / n
+
+        probe = {"eager_ms": round(probe_ms(step), 4), "graph_ms": round(probe_ms(lambda k: graphs[k % len(graphs)][0].replay()), 4)}
+        use = probe["graph_ms"] < 0.97 * probe["eager_ms"]
+        if dist:                                                  # every rank takes the same path
+            flag = torch.tensor([1 if use else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            use = bool(flag.item())
+        if not use:
+            graphs = []
     # per-kernel HIP events (start / stop of each launch, on the launch stream) on every `event_every`-th timed step
     lib.tef_profile_enable(0 if a.no_kernel_events else 1)
     if not a.no_kernel_events:
@@ -351,6 +370,7 @@ def main():
             # defines the metric; this is the rate with its wall time added to every step
             "value_including_update": round(events_per_step * world / (elapsed / a.steps + t_update), 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
+            "launch_probe": probe,
             "kernel_events_every": None if a.no_kernel_events else max(1, a.event_every),
             "roofline": roofline,
             "kernels": kernels,
