@@ -558,25 +558,6 @@ __device__ __forceinline__ float acc_value(double a)
     return FX ? (float)((double)__double_as_longlong(a) * 0x1p-46) : (float)a;
 }
 
-template <bool FX = false>
-__device__ __forceinline__ void lds_plane_store(const double *img, int rows, int W, int WP, float *__restrict__ o)
-{
-    const int half = W >> 1;
-    if (!(W & 1) && !(WP & 1) && half > 0 && (int)blockDim.x % half == 0) {
-        const int rstep = blockDim.x / half;
-        int r = threadIdx.x / half, c = (threadIdx.x - r * half) * 2;
-        for (; r < rows; r += rstep) {
-            double2 d = *reinterpret_cast<const double2 *>(img + r * WP + c);
-            *reinterpret_cast<float2 *>(o + (size_t)r * W + c) = make_float2(acc_value<FX>(d.x), acc_value<FX>(d.y));
-        }
-    } else {
-        for (int p = threadIdx.x; p < rows * W; p += blockDim.x) {
-            int r = p / W;
-            o[p] = acc_value<FX>(img[r * WP + (p - r * W)]);
-        }
-    }
-}
-
 // =============================================================================================
 // K2: images of warped events + their focus-loss statistics.
 //   loss/flow.py:81-110 iwe_formatting = utils/iwe.py:63-136 get_interpolation + 4x interpolate (scatter_add_), then
@@ -1064,6 +1045,31 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
 // =============================================================================================
 // Streaming accesses of K6 (trajectory planes in, per-map vectors out) carry the non-temporal hint so that they do not
 // push the (A, R) images and flow maps — the gathered, re-used data — out of the XCD's L2.
+// Largest magnitude among the flow-gradient vectors of one (head, sample), as the bit pattern of |c| (orders like an
+// unsigned integer; NaN / infinity sort above every finite value): K7 scales its integer accumulators by it.
+__device__ __forceinline__ void track_mag(uint32_t &m, float a, float b)
+{
+    m = max(m, max(__float_as_uint(a) & 0x7fffffffu, __float_as_uint(b) & 0x7fffffffu));
+}
+// One plain store per wavefront into wmax[(head, sample)][wavefront]; mag_reduce_kernel folds them.  (4e5 wavefronts on
+// 32 words: an atomicMax each doubled K6's time, 0.23 -> 0.50 ms; guarded by a coherent read of the word still 0.28.)
+__device__ __forceinline__ void commit_mag(uint32_t m, uint32_t *__restrict__ wave_slot)
+{
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft, 64));
+    if ((threadIdx.x & 63) == 0) *wave_slot = m;
+}
+
+__global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restrict__ wmax, int nwaves, uint32_t *__restrict__ cmax)
+{
+    __shared__ uint32_t red[4];
+    uint32_t m = 0u;
+    for (int k = threadIdx.x; k < nwaves; k += blockDim.x) m = max(m, wmax[(size_t)blockIdx.x * nwaves + k]);
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) cmax[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+}
+
 typedef float f32x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 NT_LD2(const float2 *p)
 {
@@ -1082,13 +1088,15 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                                                              const float2 *__restrict__ ar,
                                                              const float *__restrict__ stats,
                                                              const float *__restrict__ grad_out,
-                                                             float *__restrict__ cy, float *__restrict__ cx, int chunks)
+                                                             float *__restrict__ cy, float *__restrict__ cx,
+                                                             uint32_t *__restrict__ cmax, int chunks)
 {
     int ib, chunk;
     xcd_split(blockIdx.x, chunks, ib, chunk);
     if (ib >= w.F * w.B) return;
     int sl = chunk * blockDim.x + threadIdx.x;
     if (sl >= w.M) return;                              // (M is a multiple of 64: whole wavefronts)
+    uint32_t mag = 0u;
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, P = w.P, M = w.M;
     float *coy = cy + (size_t)ib * P * M + sl, *cox = cx + (size_t)ib * P * M + sl;
@@ -1175,6 +1183,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                 } else {
                     NT_ST(&coy[(size_t)(k - 1) * M], ay);
                     NT_ST(&cox[(size_t)(k - 1) * M], ax);
+                    track_mag(mag, ay, ax);
                     float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
                     ay = ny;
                     ax = nx;
@@ -1211,6 +1220,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                 } else {
                     NT_ST(&coy[(size_t)k * M], -ay);
                     NT_ST(&cox[(size_t)k * M], -ax);
+                    track_mag(mag, ay, ax);
                     float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
                     ay = ny;
                     ax = nx;
@@ -1225,6 +1235,8 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     }
     NT_ST(&coy[(size_t)t * M], c0y);
     NT_ST(&cox[(size_t)t * M], c0x);
+    track_mag(mag, c0y, c0x);
+    commit_mag(mag, cmax + (size_t)ib * (M >> 6) + (sl >> 6));       // (here: the per-wavefront slots)
 }
 
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
@@ -1233,7 +1245,7 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
                                                          const float2 *__restrict__ ar,
                                                          const float *__restrict__ stats,
                                                          const float *__restrict__ grad_out, float *__restrict__ cy,
-                                                         float *__restrict__ cx, int chunks)
+                                                         float *__restrict__ cx, uint32_t *__restrict__ cmax, int chunks)
 {
     int ib, chunk;
     xcd_split(blockIdx.x, chunks, ib, chunk);
@@ -1266,43 +1278,60 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
     }
     cy[(size_t)ib * w.M + sl] = gy;
     cx[(size_t)ib * w.M + sl] = gx;
+    uint32_t mag = 0u;
+    track_mag(mag, gy, gx);
+    commit_mag(mag, cmax + (size_t)ib * (w.M >> 6) + (sl >> 6));
 }
 
 // =============================================================================================
 // K7: flow-map gradient = bilinear splat (grid_sample backward w.r.t. input) of the per-event vectors.
-// One workgroup per (pass k, head, sample, component[, band]); LDS holds one fp64 gradient plane.
+// One workgroup per (pass k, head, sample, component[, band]); LDS holds one gradient plane.
 // Sample position of event (bin t) on map k: t < k -> trajectory plane k, t > k -> plane k+1,
 // t == k -> original location.  Linear: only the events of pass k sample map k.
 //   dflows [P][F][B][2][H][W] (channel 0 = x, 1 = y) is fully overwritten.
+// This kernel IS bound by its LDS atomics (230 M per launch: at ds_add_f64's 31 cycles per wave-instruction on a sorted
+// wavefront's footprint that is the whole 0.18 ms), so it accumulates integers like K2 (ds_add_u64: 18 cycles) in a
+// block-floating format: K6 publishes the largest magnitude among the vectors of each (head, sample), 2^e >= max |c|,
+// and a contribution c * w (|w| <= 1) is accumulated as RN(c * w * 2^(46 - e)).  Sums are exact and order-independent
+// (bitwise reproducible gradients); a contribution is resolved to 2^-46 of the largest vector of its (head, sample).
+// fp64 accumulators remain for non-finite vectors and for 2^17 or more events per map.
 // =============================================================================================
-__global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
-                                                                    const float *__restrict__ cy,
-                                                                    const float *__restrict__ cx,
-                                                                    float *__restrict__ dflows, int rows_per_band,
-                                                                    int nbands)
+template <bool FX>
+__device__ __forceinline__ float dflow_value(double a, double unscale)
 {
-    extern __shared__ double lds_img[];
-    const int FB = w.F * w.B;
-    int item, sub;
-    xcd_split(blockIdx.x, 2 * nbands, item, sub);      // item = (pass k, head, sample); sub = (band, component)
-    if (item >= w.P * FB) return;
-    int ib = item % FB, k = item / FB;
-    int comp = sub & 1, band = sub >> 1;               // comp 0 = d/d flow_x (channel 0), 1 = d/d flow_y
-    int i = ib / w.B, b = ib - i * w.B;
-    const int H = w.H, W = w.W, M = w.M;
-    int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
-    const int WP = W + kRowPad;
-    int nlds = (r1 - r0) * WP;
-    lds_plane_zero(lds_img, nlds);
-    __syncthreads();
-    const bool iter = (w.kind == TEF_KIND_ITERATIVE);
-    const float *co = (comp ? cy : cx) + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
-    const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
+    return FX ? (float)((double)__double_as_longlong(a) * unscale) : (float)a;
+}
+
+template <bool FX>
+__device__ __forceinline__ void dflow_plane_store(const double *img, int rows, int W, int WP, double unscale,
+                                                  float *__restrict__ o)
+{
+    const int half = W >> 1;
+    if (!(W & 1) && !(WP & 1) && half > 0 && (int)blockDim.x % half == 0) {
+        const int rstep = blockDim.x / half;
+        int r = threadIdx.x / half, c = (threadIdx.x - r * half) * 2;
+        for (; r < rows; r += rstep) {
+            double2 d = *reinterpret_cast<const double2 *>(img + r * WP + c);
+            *reinterpret_cast<float2 *>(o + (size_t)r * W + c) = make_float2(dflow_value<FX>(d.x, unscale), dflow_value<FX>(d.y, unscale));
+        }
+    } else {
+        for (int p = threadIdx.x; p < rows * W; p += blockDim.x) {
+            int r = p / W;
+            o[p] = dflow_value<FX>(img[r * WP + (p - r * W)], unscale);
+        }
+    }
+}
+
+template <bool FX>
+__device__ __forceinline__ void dflow_accumulate(const Win &w, const Events &g, const float2 *__restrict__ tr,
+                                                 const float *__restrict__ co, int b, int k, int t_lo, int t_hi, int e,
+                                                 double *img, int r0, int r1)
+{
+    const int H = w.H, W = w.W, WP = W + kRowPad;
     const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
     const int stride = blockDim.x;
     // pass by pass: the position source (trajectory plane or original location) is uniform inside a pass
-    const int reach = w.P / max(1, w.mode_div);     // Iterative: pass t feeds map k only if |k - t| < delta_passes[0]
-    for (int t = iter ? max(0, k - reach + 1) : k; t < (iter ? min(w.P, k + reach) : k + 1); ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         const int s0 = w.off[t], s1 = w.off[t + 1];
         const float2 *pl = tr + (size_t)(t < k ? k : k + 1) * w.Mt;
         for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
@@ -1330,14 +1359,51 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
                 for (int c = 0; c < 4; ++c) {
                     int iy = y0 + (c >> 1), ix = x0 + (c & 1);
                     if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
-                    atomicAdd(lds_img + (iy - r0) * WP + ix, (double)(cv[q] * wt[c]));
+                    const float v = cv[q] * wt[c];
+                    if (FX) atomicAdd(reinterpret_cast<unsigned long long *>(img + (iy - r0) * WP + ix), to_fixed(ldexpf(v, -e)));
+                    else atomicAdd(img + (iy - r0) * WP + ix, (double)v);
                 }
             }
         }
     }
+}
+
+__global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
+                                                                    const float *__restrict__ cy,
+                                                                    const float *__restrict__ cx,
+                                                                    const uint32_t *__restrict__ cmax,
+                                                                    float *__restrict__ dflows, int rows_per_band,
+                                                                    int nbands)
+{
+    extern __shared__ double lds_img[];
+    const int FB = w.F * w.B;
+    int item, sub;
+    xcd_split(blockIdx.x, 2 * nbands, item, sub);      // item = (pass k, head, sample); sub = (band, component)
+    if (item >= w.P * FB) return;
+    int ib = item % FB, k = item / FB;
+    int comp = sub & 1, band = sub >> 1;               // comp 0 = d/d flow_x (channel 0), 1 = d/d flow_y
+    int i = ib / w.B, b = ib - i * w.B;
+    const int H = w.H, W = w.W, M = w.M;
+    int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
+    const int WP = W + kRowPad;
+    int nlds = (r1 - r0) * WP;
+    lds_plane_zero(lds_img, nlds);
+    __syncthreads();
+    const bool iter = (w.kind == TEF_KIND_ITERATIVE);
+    const float *co = (comp ? cy : cx) + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
+    const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
+    const int reach = w.P / max(1, w.mode_div);     // Iterative: pass t feeds map k only if |k - t| < delta_passes[0]
+    const int t_lo = iter ? max(0, k - reach + 1) : k, t_hi = iter ? min(w.P, k + reach) : k + 1;
+    const uint32_t mbits = cmax[ib];                // bit pattern of max |c| over this (head, sample), from K6
+    const int nev = w.off[t_hi] - w.off[t_lo];
+    const bool fixed = mbits < 0x7f800000u && nev < kFxMaxEvents;
+    const int e = (int)(mbits >> 23) - 127 + 1;     // 2^e > max |c| (a denormal or zero maximum: any small exponent does)
+    if (fixed) dflow_accumulate<true>(w, g, tr, co, b, k, t_lo, t_hi, e, lds_img, r0, r1);
+    else dflow_accumulate<false>(w, g, tr, co, b, k, t_lo, t_hi, 0, lds_img, r0, r1);
     __syncthreads();
     float *o = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2 + (comp ? 1 : 0)) * (size_t)(H * W) + (size_t)r0 * W;
-    lds_plane_store(lds_img, r1 - r0, W, WP, o);
+    if (fixed) dflow_plane_store<true>(lds_img, r1 - r0, W, WP, __builtin_ldexp(1.0, e - 46), o);
+    else dflow_plane_store<false>(lds_img, r1 - r0, W, WP, 1.0, o);
 }
 
 // K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473),
@@ -1444,7 +1510,7 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const float *__restrict_
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, yr, ar, stats, parts, queue, cy, cx, total;
+    size_t traj, meta, yr, ar, stats, parts, queue, cmax, wmax, cy, cx, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1529,7 +1595,9 @@ Layout make_layout(const Win &w)
         band_geometry(w, 4, &rows, &nbands, &lds);
         L.parts = o;  o += align_up((size_t)w.nimg * FB * nbands * 2 * sizeof(double));
     }
-    L.queue = o;  o += align_up(kQueueInts * sizeof(int));
+    L.queue = o;  o += align_up((kQueueInts + FB) * sizeof(int));      // + one magnitude word per (head, sample) for K6 -> K7
+    L.cmax = L.queue + kQueueInts * sizeof(int);
+    L.wmax = o;   o += align_up(FB * (size_t)(w.M / 64 + 1) * sizeof(uint32_t));
     L.cy = o;     o += align_up(nc * sizeof(float));
     L.cx = o;     o += align_up(nc * sizeof(float));
     L.total = o;
@@ -1654,7 +1722,7 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     int rows, nbands;
     size_t lds;
     band_geometry(w, 4, &rows, &nbands, &lds);
-    if (w.Mt == 0 && hipMemsetAsync(queue, 0, kQueueInts * sizeof(int), st) != hipSuccess)      // (K1 clears them otherwise)
+    if (w.Mt == 0 && hipMemsetAsync(queue, 0, (kQueueInts + FB) * sizeof(int), st) != hipSuccess)      // (K1 clears them otherwise)
         return tef::fail("hipMemsetAsync(queue)"), TEF_ERR_LAUNCH;
     {
         // persistent workgroups, one per CU (the four planes fill its LDS), a multiple of 8 so that every XCD queue is served
@@ -1687,6 +1755,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
     float *cy = (float *)(ws + L.cy), *cx = (float *)(ws + L.cx);
+    uint32_t *cmax = (uint32_t *)(ws + L.cmax), *wmax = (uint32_t *)(ws + L.wmax);
     const float2 *fl = (const float2 *)flows_yx;
     Events g = to_events(grad);
     const int FB = w.F * w.B;
@@ -1695,20 +1764,22 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
         dim3 grid(xcd_grid(FB, chunks));
         if (w.kind == TEF_KIND_ITERATIVE && w.S == 1)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cy, cx, chunks);
+                             stats, grad_out, cy, cx, wmax, chunks);
         else if (w.kind == TEF_KIND_ITERATIVE)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cy, cx, chunks);
+                             stats, grad_out, cy, cx, wmax, chunks);
         else
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
-                             grad_out, cy, cx, chunks);
+                             grad_out, cy, cx, wmax, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
+    hipLaunchKernelGGL(mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax);      // M = 0: writes zeros
+    if (int rc = tef::check_launch("mag_reduce_kernel")) return rc;
     int rows, nbands;
     size_t lds;
     band_geometry(w, 1, &rows, &nbands, &lds);
     TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(xcd_grid(w.P * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w,
-                     g, traj, cy, cx, dflows, rows, nbands);
+                     g, traj, cy, cx, cmax, dflows, rows, nbands);
     return tef::check_launch("dflow_splat_kernel");
 }
 

@@ -196,3 +196,17 @@ def test_randomised_sweep(dev):
     # odd P at cases 122, 136, 216 — they caught a reciprocal in the backward's tau
     bad, worst = fuzz.sweep(220, seed=5150, verbose=False)
     assert bad == 0 and worst <= TOL
+
+
+def test_bitwise_reproducible(dev):
+    """Both scatter kernels accumulate exact integers (Q17.46 / block-floating) and the chain kernels have no atomics:
+    loss and gradients of a window are bit-identical from run to run, whatever order the atomics arrive in."""
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(77)
+    win = synth.make_window(rng, 2, 64, 80, 6, 2, 4000, 1000, sigma=2.0, ragged=True)
+    meta = dict(H=64, W=80, B=2, P=6, S=1, mode="two", spat=None, temp=None, round_ts=False)
+    runs = [run_hip("Iterative", make_cfg(meta), win, dev) for _ in range(3)]
+    for l, g, _ in runs[1:]:
+        assert l == runs[0][0]
+        assert np.array_equal(g, runs[0][1])
