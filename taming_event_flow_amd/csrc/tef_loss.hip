@@ -67,6 +67,7 @@ struct Win {
     int off[TEF_MAX_PASSES + 1];
     int doff[TEF_MAX_PASSES + 1];
     uint16_t order[kMaxImages];      // images sorted by decreasing number of bins (longest workgroups first)
+    uint8_t korder[TEF_MAX_PASSES];  // flow maps sorted by decreasing number of passes that feed them (K7's items)
 };
 
 struct Events {
@@ -1059,9 +1060,11 @@ __device__ __forceinline__ void commit_mag(uint32_t m, uint32_t *__restrict__ wa
     if ((threadIdx.x & 63) == 0) *wave_slot = m;
 }
 
-__global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restrict__ wmax, int nwaves, uint32_t *__restrict__ cmax)
+__global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restrict__ wmax, int nwaves, uint32_t *__restrict__ cmax,
+                                                         int *__restrict__ queue7)
 {
     __shared__ uint32_t red[4];
+    if (blockIdx.x == 0 && threadIdx.x < 8) queue7[threadIdx.x] = 0;      // K7's work queues, once per backward call
     uint32_t m = 0u;
     for (int k = threadIdx.x; k < nwaves; k += blockDim.x) m = max(m, wmax[(size_t)blockIdx.x * nwaves + k]);
     for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft, 64));
@@ -1322,88 +1325,199 @@ __device__ __forceinline__ void dflow_plane_store(const double *img, int rows, i
     }
 }
 
+// one event's contribution to both gradient planes of a band (planes: [d/d flow_y | d/d flow_x], each nrows x WP)
 template <bool FX>
-__device__ __forceinline__ void dflow_accumulate(const Win &w, const Events &g, const float2 *__restrict__ tr,
-                                                 const float *__restrict__ co, int b, int k, int t_lo, int t_hi, int e,
-                                                 double *img, int r0, int r1)
+__device__ __forceinline__ void dflow_one(float2 p, float cvy, float cvx, int H, int W, int WP, int e, double *img_y,
+                                          double *img_x, int r0, int nrows)
 {
-    const int H = w.H, W = w.W, WP = W + kRowPad;
-    const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
-    const int stride = blockDim.x;
-    // pass by pass: the position source (trajectory plane or original location) is uniform inside a pass
-    for (int t = t_lo; t < t_hi; ++t) {
-        const int s0 = w.off[t], s1 = w.off[t + 1];
-        const float2 *pl = tr + (size_t)(t < k ? k : k + 1) * w.Mt;
-        for (int sl0 = s0 + threadIdx.x; sl0 < s1; sl0 += kUnroll * stride) {
-            float cv[kUnroll];
-            float2 p[kUnroll];
+    // same taps as the forward lookup (make_taps), kept as (row, column) to address the padded LDS planes
+    float fiy = unnormalize(p.x, H), fix = unnormalize(p.y, W);
+    float fy0 = floorf(fiy), fx0 = floorf(fix);
+    float tn = fiy - fy0, tw = fix - fx0, tsv = 1.0f - tn, te = 1.0f - tw;
+    int y0 = (int)fy0, x0 = (int)fx0;
+    const float wt[4] = {tsv * te, tsv * tw, tn * te, tn * tw};
 #pragma unroll
-            for (int q = 0; q < kUnroll; ++q) {
-                int sl = sl0 + q * stride;
-                bool ok = sl < s1;
-                sl = ok ? sl : s0;
-                cv[q] = ok ? co[sl] : 0.0f;
-                // position this event had when it sampled map k
-                p[q] = (t == k) ? make_float2(ey[sl], ex[sl]) : pl[sl];
-            }
-#pragma unroll
-            for (int q = 0; q < kUnroll; ++q) {
-                if (cv[q] == 0.0f) continue;
-                // same taps as the forward lookup (make_taps), kept as (row, column) to address the padded LDS plane
-                float fiy = unnormalize(p[q].x, H), fix = unnormalize(p[q].y, W);
-                float fy0 = floorf(fiy), fx0 = floorf(fix);
-                float tn = fiy - fy0, tw = fix - fx0, tsv = 1.0f - tn, te = 1.0f - tw;
-                int y0 = (int)fy0, x0 = (int)fx0;
-                const float wt[4] = {tsv * te, tsv * tw, tn * te, tn * tw};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    int iy = y0 + (c >> 1), ix = x0 + (c & 1);
-                    if (iy < r0 || iy >= r1 || ix < 0 || ix >= W) continue;
-                    const float v = cv[q] * wt[c];
-                    if (FX) atomicAdd(reinterpret_cast<unsigned long long *>(img + (iy - r0) * WP + ix), to_fixed(ldexpf(v, -e)));
-                    else atomicAdd(img + (iy - r0) * WP + ix, (double)v);
-                }
-            }
+    for (int c = 0; c < 4; ++c) {
+        const int iy = y0 + (c >> 1) - r0, ix = x0 + (c & 1);
+        if (iy < 0 || iy >= nrows || ix < 0 || ix >= W) continue;
+        const int cell = iy * WP + ix;
+        const float vy = cvy * wt[c], vx = cvx * wt[c];
+        if (FX) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(img_y + cell), to_fixed(ldexpf(vy, -e)));
+            atomicAdd(reinterpret_cast<unsigned long long *>(img_x + cell), to_fixed(ldexpf(vx, -e)));
+        } else {
+            atomicAdd(img_y + cell, (double)vy);
+            atomicAdd(img_x + cell, (double)vx);
         }
     }
 }
 
+// Persistent like K2: one workgroup per CU pulls (map k, head, sample, row band) items from the per-XCD queues
+// [8, 16); the band holds BOTH components of the map's gradient (2 planes x 64 rows at 128x128), so an event's position,
+// taps and weights are computed once for its eight accumulations, and per 16-slot row the workgroup reads K1's interval
+// of the plane the events sampled the map at (plane k for earlier passes, k + 1 for later ones, the original locations
+// for pass k) and loads the row only if it can touch the band.
 __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
+                                                                    const float2 *__restrict__ yr,
                                                                     const float *__restrict__ cy,
                                                                     const float *__restrict__ cx,
                                                                     const uint32_t *__restrict__ cmax,
                                                                     float *__restrict__ dflows, int rows_per_band,
-                                                                    int nbands)
+                                                                    int nbands, int *__restrict__ queue)
 {
     extern __shared__ double lds_img[];
-    const int FB = w.F * w.B;
-    int item, sub;
-    xcd_split(blockIdx.x, 2 * nbands, item, sub);      // item = (pass k, head, sample); sub = (band, component)
-    if (item >= w.P * FB) return;
-    int ib = item % FB, k = item / FB;
-    int comp = sub & 1, band = sub >> 1;               // comp 0 = d/d flow_x (channel 0), 1 = d/d flow_y
-    int i = ib / w.B, b = ib - i * w.B;
-    const int H = w.H, W = w.W, M = w.M;
-    int r0 = band * rows_per_band, r1 = min(H, r0 + rows_per_band);
-    const int WP = W + kRowPad;
-    int nlds = (r1 - r0) * WP;
-    lds_plane_zero(lds_img, nlds);
-    __syncthreads();
+    __shared__ int run_u0[TEF_MAX_PASSES], run_len[TEF_MAX_PASSES], run_src[TEF_MAX_PASSES], run_cum[TEF_MAX_PASSES + 1], s_item;
+    __shared__ int2 hit_list[2 * kSplatThreads];   // 128 (row, source) entries per wavefront
+    const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad, M = w.M;
+    const int xcd = blockIdx.x & 7;
+    const int nitems = w.P * FB;
     const bool iter = (w.kind == TEF_KIND_ITERATIVE);
-    const float *co = (comp ? cy : cx) + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
-    const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
     const int reach = w.P / max(1, w.mode_div);     // Iterative: pass t feeds map k only if |k - t| < delta_passes[0]
-    const int t_lo = iter ? max(0, k - reach + 1) : k, t_hi = iter ? min(w.P, k + reach) : k + 1;
-    const uint32_t mbits = cmax[ib];                // bit pattern of max |c| over this (head, sample), from K6
-    const int nev = w.off[t_hi] - w.off[t_lo];
-    const bool fixed = mbits < 0x7f800000u && nev < kFxMaxEvents;
-    const int e = (int)(mbits >> 23) - 127 + 1;     // 2^e > max |c| (a denormal or zero maximum: any small exponent does)
-    if (fixed) dflow_accumulate<true>(w, g, tr, co, b, k, t_lo, t_hi, e, lds_img, r0, r1);
-    else dflow_accumulate<false>(w, g, tr, co, b, k, t_lo, t_hi, 0, lds_img, r0, r1);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
     __syncthreads();
-    float *o = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2 + (comp ? 1 : 0)) * (size_t)(H * W) + (size_t)r0 * W;
-    if (fixed) dflow_plane_store<true>(lds_img, r1 - r0, W, WP, __builtin_ldexp(1.0, e - 46), o);
-    else dflow_plane_store<false>(lds_img, r1 - r0, W, WP, 1.0, o);
+    for (;;) {
+        const int q = s_item;
+        const int it = xcd + 8 * (q / nbands), band = q - (q / nbands) * nbands;
+        if (it >= nitems) break;
+        const int k = w.korder[it / FB], ib = it % FB, i = ib / w.B, b = ib - i * w.B;
+        const int r0 = band * rows_per_band, nrows = min(H, r0 + rows_per_band) - r0;
+        const size_t plane_sz = (size_t)nrows * WP;
+        double *img_y = lds_img, *img_x = lds_img + plane_sz;
+        lds_plane_zero(lds_img, 2 * nrows * WP);
+        const int t_lo = iter ? max(0, k - reach + 1) : k, t_hi = iter ? min(w.P, k + reach) : k + 1, nruns = t_hi - t_lo;
+        __syncthreads();                                  // (everybody has read s_item)
+        int next_item = 0;
+        if (threadIdx.x == 0) next_item = atomicAdd(&queue[xcd], 1);      // in flight while this item is worked on
+        if (threadIdx.x < 64) {       // run = the slots of one pass (multiples of 64: whole rows); rows as a running total
+            int carry = 0;
+            for (int base_r = 0; base_r < nruns; base_r += 64) {
+                const int r = base_r + (int)threadIdx.x, t = t_lo + r;
+                int cnt = 0;
+                if (r < nruns) {
+                    run_u0[r] = w.off[t];
+                    run_len[r] = w.off[t + 1] - w.off[t];
+                    run_src[r] = t < k ? k : (t > k ? k + 1 : w.nplanes);      // plane the events sampled map k at
+                    cnt = run_len[r] >> 4;
+                }
+                int incl = cnt;
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    int up = __shfl_up(incl, sft, 64);
+                    if ((int)threadIdx.x >= sft) incl += up;
+                }
+                if (r < nruns) run_cum[r] = carry + incl - cnt;
+                carry += __shfl(incl, 63, 64);
+            }
+            if (threadIdx.x == 0) run_cum[nruns] = carry;
+        }
+        __syncthreads();
+        const uint32_t mbits = cmax[ib];                // bit pattern of max |c| over this (head, sample), from K6
+        const int nev = w.off[t_hi] - w.off[t_lo];
+        const bool fixed = mbits < 0x7f800000u && nev < kFxMaxEvents;
+        const int e = (int)(mbits >> 23) - 127 + 1;     // 2^e > max |c| (a denormal or zero maximum: any small exponent does)
+        const float *coy = cy + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M), *cox = cx + (coy - cy);
+        const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
+        const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
+        // lookup rows are floor(unnormalize(y)) and the next one; unnormalize(y) is y up to a few ulps: a hundredth of a
+        // pixel of slack keeps the test a superset
+        const float band_lo = (float)(r0 - 1) - 0.01f, band_hi = (float)(r0 + nrows) + 0.01f;
+        if (fixed) {
+            const float2 *rows = yr + (size_t)ib * (w.nplanes + 1) * w.nrow;
+            const int total_rows = run_cum[nruns];
+            int2 *list = hit_list + wid * 128;
+            int run_hint = 0;
+            auto load_range = [&](int grp64, int &r_out, int &row_out) -> float2 {
+                const int fr = grp64 * 64 + lane;
+                float2 rg = make_float2(__uint_as_float(0xffffffffu), 0.0f);
+                r_out = row_out = 0;
+                if (grp64 * 64 < total_rows) {
+                    while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= grp64 * 64) ++run_hint;
+                }
+                if (fr < total_rows) {
+                    int r = run_hint;
+                    while (run_cum[r + 1] <= fr) ++r;
+                    r_out = r;
+                    row_out = (run_u0[r] >> 4) + (fr - run_cum[r]);
+                    rg = rows[(size_t)run_src[r] * w.nrow + row_out];
+                }
+                return rg;
+            };
+            struct Quad { float cvy, cvx; float2 p; };
+            auto load_quad_rows = [&](int s, int h) -> Quad {      // events of list entries s .. s + 3, 16 lanes each
+                Quad qd;
+                qd.cvy = qd.cvx = 0.0f;
+                qd.p = make_float2(0.0f, 0.0f);
+                const int en_i = s + (lane >> 4);
+                if (en_i < h) {
+                    const int2 en = list[en_i];              // (first slot of the row, source plane)
+                    const int u = en.x + (lane & 15);
+                    qd.cvy = coy[u];
+                    qd.cvx = cox[u];
+                    qd.p = en.y == w.nplanes ? make_float2(ey[u], ex[u]) : tr[(size_t)en.y * w.Mt + u];
+                }
+                return qd;
+            };
+            constexpr int kQ = 4;
+            int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
+            float2 rg_cur[2], rg_nxt[2];
+            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(2 * wid + hh, r_cur[hh], row_cur[hh]);
+            for (int grp = wid; grp * 128 < total_rows; grp += nwaves) {
+                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(2 * (grp + nwaves) + hh, r_nxt[hh], row_nxt[hh]);
+                int h = 0;
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const bool hit = rg_cur[hh].y >= band_lo && rg_cur[hh].x < band_hi;      // (NaN for an empty / absent row)
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (hit) list[h + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] = make_int2(row_cur[hh] * 16, run_src[r_cur[hh]]);
+                    h += __builtin_popcountll(mask);
+                }
+                __builtin_amdgcn_wave_barrier();
+                Quad cur[kQ], nxt[kQ];
+#pragma unroll
+                for (int kq = 0; kq < kQ; ++kq) cur[kq] = load_quad_rows(4 * kq, h);
+                for (int sidx = 0; sidx < h; sidx += 4 * kQ) {
+#pragma unroll
+                    for (int kq = 0; kq < kQ; ++kq) nxt[kq] = load_quad_rows(sidx + 4 * (kQ + kq), h);
+#pragma unroll
+                    for (int kq = 0; kq < kQ; ++kq)
+                        if (cur[kq].cvy != 0.0f || cur[kq].cvx != 0.0f)
+                            dflow_one<true>(cur[kq].p, cur[kq].cvy, cur[kq].cvx, H, W, WP, e, img_y, img_x, r0, nrows);
+#pragma unroll
+                    for (int kq = 0; kq < kQ; ++kq) cur[kq] = nxt[kq];
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int hh = 0; hh < 2; ++hh) {
+                    rg_cur[hh] = rg_nxt[hh];
+                    r_cur[hh] = r_nxt[hh];
+                    row_cur[hh] = row_nxt[hh];
+                }
+            }
+        } else {
+            for (int t = t_lo; t < t_hi; ++t) {
+                const int src = t < k ? k : (t > k ? k + 1 : w.nplanes);
+                for (int sl = w.off[t] + threadIdx.x; sl < w.off[t + 1]; sl += blockDim.x) {
+                    const float cvy = coy[sl], cvx = cox[sl];
+                    if (cvy == 0.0f && cvx == 0.0f) continue;
+                    const float2 p = src == w.nplanes ? make_float2(ey[sl], ex[sl]) : tr[(size_t)src * w.Mt + sl];
+                    dflow_one<false>(p, cvy, cvx, H, W, WP, 0, img_y, img_x, r0, nrows);
+                }
+            }
+        }
+        __syncthreads();
+        // dflows [P][F][B][2][H][W]: channel 0 = d/d flow_x, 1 = d/d flow_y
+        float *ox = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2) * (size_t)(H * W) + (size_t)r0 * W, *oy = ox + (size_t)H * W;
+        const double unscale = __builtin_ldexp(1.0, e - 46);
+        if (fixed) {
+            dflow_plane_store<true>(img_x, nrows, W, WP, unscale, ox);
+            dflow_plane_store<true>(img_y, nrows, W, WP, unscale, oy);
+        } else {
+            dflow_plane_store<false>(img_x, nrows, W, WP, 1.0, ox);
+            dflow_plane_store<false>(img_y, nrows, W, WP, 1.0, oy);
+        }
+        __syncthreads();                                  // the planes have been read: the next item may clear them
+        if (threadIdx.x == 0) s_item = next_item;
+        __syncthreads();
+    }
 }
 
 // K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473),
@@ -1564,12 +1678,26 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     }
     std::stable_sort(idx, idx + n, [&](int a, int b) { return work[a] > work[b]; });
     for (int j = 0; j < n; ++j) w->order[j] = (uint16_t)idx[j];
+    {   // the same for the flow-gradient maps: map k is fed by the passes within the reach
+        const int reach = (c->kind == TEF_KIND_ITERATIVE) ? c->P / c->mode_div : 1;
+        int kidx[TEF_MAX_PASSES];
+        long kwork[TEF_MAX_PASSES];
+        for (int k = 0; k < c->P; ++k) {
+            const int lo = (c->kind == TEF_KIND_ITERATIVE) ? std::max(0, k - reach + 1) : k;
+            const int hi = (c->kind == TEF_KIND_ITERATIVE) ? std::min(c->P, k + reach) : k + 1;
+            kidx[k] = k;
+            kwork[k] = w->off[hi] - w->off[lo];
+        }
+        std::stable_sort(kidx, kidx + c->P, [&](int a, int b) { return kwork[a] > kwork[b]; });
+        for (int k = 0; k < c->P; ++k) w->korder[k] = (uint8_t)kidx[k];
+    }
     return true;
 }
 
 inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds)
 {
-    int rows = (int)((planes == 4 ? kSplatLdsBudget : kLdsBudget) / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
+    int rows = (int)(kSplatLdsBudget / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
+    (void)kLdsBudget;
     if (rows > w.H) rows = w.H;
     *nbands = (w.H + rows - 1) / rows;
     rows = (w.H + *nbands - 1) / *nbands;            // equal bands
@@ -1636,7 +1764,7 @@ bool ensure_attrs()
     static const hipError_t e1 = hipFuncSetAttribute((const void *)splat_stats_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
     static const hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
     if (e1 != hipSuccess || e2 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e1 != hipSuccess ? e1 : e2);
     return true;
 }
@@ -1773,13 +1901,18 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
                              grad_out, cy, cx, wmax, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
-    hipLaunchKernelGGL(mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax);      // M = 0: writes zeros
+    hipLaunchKernelGGL(mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax, (int *)(ws + L.queue) + 8);      // (M = 0: writes zeros)
     if (int rc = tef::check_launch("mag_reduce_kernel")) return rc;
     int rows, nbands;
     size_t lds;
-    band_geometry(w, 1, &rows, &nbands, &lds);
-    TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(xcd_grid(w.P * FB, 2 * nbands)), dim3(kSplatThreads), lds, st, w,
-                     g, traj, cy, cx, cmax, dflows, rows, nbands);
+    band_geometry(w, 2, &rows, &nbands, &lds);
+    {
+        const long items = (long)w.P * FB * nbands;
+        unsigned grid = (unsigned)std::min<long>(items, num_cus());
+        grid = std::max(8u, (grid + 7u) & ~7u);
+        TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(grid), dim3(kSplatThreads), lds, st, w, g, traj,
+                         (const float2 *)(ws + L.yr), cy, cx, cmax, dflows, rows, nbands, (int *)(ws + L.queue) + 8);
+    }
     return tef::check_launch("dflow_splat_kernel");
 }
 
