@@ -29,30 +29,29 @@ class RecEVFlowNet(torch.nn.Module):
         cfg.update({k: v for k, v in kwargs.items() if k != "name"})
         if "activations" in cfg:
             cfg["activations"] = tuple(cfg["activations"])
-        self.key = key
         self.arch = MultiResUNetRecurrent(cfg)
-        self.num_encoders = self.arch.num_encoders
+        self.key, self.num_encoders = key, self.arch.num_encoders
         self.image_padder = ImagePadder(min_size=min_size)      # geometry record; see model_util.py
 
     def __str__(self):
         n = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
         return super().__str__() + f"\nTrainable parameters: {n}"
 
-    # ---- recurrent state (reference :42-63) ------------------------------------------------------------------------
-    @property
-    def states(self):
+    # ---- recurrent state (reference :42-63): `states` reads copies and assigns a new list ------------------------------
+    def _read_states(self):
         return copy_states(self.arch.states)
 
-    @states.setter
-    def states(self, states):
-        self.arch.states = list(states)
+    def _assign_states(self, new_states):
+        self.arch.states = list(new_states)
+
+    states = property(_read_states, _assign_states)
 
     def detach_states(self):
         """Truncated BPTT: keep the values, cut the graph."""
         self.arch.states = [None if s is None else s.detach() for s in self.arch.states]
 
     def reset_states(self):
-        self.arch.states = [None] * self.arch.num_states
+        self.arch.states = [None for _ in range(self.arch.num_states)]
 
     def forward(self, x):
         return {self.key: self.arch.step(x)}
