@@ -102,6 +102,11 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, co
 int tef_pack_flow(const float *flow, long stride_b, long stride_c, int B, int H, int W, float *planar, float *yx,
                   void *stream);
 
+/* The same for all F heads of one pass in one launch: flows / stride_b / stride_c are HOST arrays of F entries; planar and
+ * yx point at slot [t][0] of the window buffers (head i lands at slot [t][i]). */
+int tef_pack_flows(const float *const *flows, const long *stride_b, const long *stride_c, int F, int B, int H, int W,
+                   float *planar, float *yx, void *stream);
+
 /* Workspace (bytes) needed by tef_loss_forward + tef_loss_backward for this window. */
 size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg);
 

@@ -1620,6 +1620,26 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(const float *__restrict_
     yx[(size_t)b * HW + p] = make_float2(fy, fx);
 }
 
+// the F heads of one pass in one launch (blockIdx.z = head)
+constexpr int kMaxHeads = 16;
+struct FlowHeads {
+    const float *src[kMaxHeads];
+    long sb[kMaxHeads], sc[kMaxHeads];
+};
+__global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, int HW, float *__restrict__ planar,
+                                                         float2 *__restrict__ yx)
+{
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const int b = blockIdx.y, i = blockIdx.z;
+    const float *src = hd.src[i];
+    float fx = src[(size_t)b * hd.sb[i] + p], fy = src[(size_t)b * hd.sb[i] + hd.sc[i] + p];
+    float *pl = planar + (size_t)i * B * 2 * HW;
+    pl[((size_t)b * 2) * HW + p] = fx;
+    pl[((size_t)b * 2 + 1) * HW + p] = fy;
+    yx[((size_t)i * B + b) * HW + p] = make_float2(fy, fx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
@@ -1813,6 +1833,25 @@ int tef_pack_flow(const float *flow, long stride_b, long stride_c, int B, int H,
                            (float2 *)yx);
     }
     return tef::check_launch("pack_flow_kernel");
+}
+
+int tef_pack_flows(const float *const *flows, const long *stride_b, const long *stride_c, int F, int B, int H, int W,
+                   float *planar, float *yx, void *stream)
+{
+    if (!flows || !stride_b || !stride_c || !planar || !yx || F < 1 || F > kMaxHeads || B < 1 || H < 1 || W < 1)
+        return tef::fail("tef_pack_flows: bad arguments (1..16 heads)"), TEF_ERR_INVALID;
+    FlowHeads hd{};
+    for (int i = 0; i < F; ++i) {
+        if (!flows[i]) return tef::fail("tef_pack_flows: null flow map"), TEF_ERR_INVALID;
+        hd.src[i] = flows[i]; hd.sb[i] = stride_b[i]; hd.sc[i] = stride_c[i];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((H * W + 255) / 256, B, F);
+    {
+        tef::ProfScope ps(tef::PROF_PACK, st);
+        hipLaunchKernelGGL(pack_flows_kernel, grid, dim3(256), 0, st, hd, B, H * W, planar, (float2 *)yx);
+    }
+    return tef::check_launch("pack_flows_kernel");
 }
 
 int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,

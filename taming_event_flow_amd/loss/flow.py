@@ -189,19 +189,28 @@ class BaseEventWarping(torch.nn.Module):
             _lib.require_device_tensor(flow_list[0], "flow map")
             win.flows = torch.empty((P, F, B, 2, H, W), dtype=torch.float32, device=flow_list[0].device)
             win.flows_yx = torch.empty((P, F, B, H, W, 2), dtype=torch.float32, device=flow_list[0].device)
-        refs = []
-        lib = _lib.lib()
+        refs, srcs = [], []
         for i, flow in enumerate(flow_list):
             if tuple(flow.shape) != (B, 2, H, W):
                 raise RuntimeError(f"flow map {i} has shape {tuple(flow.shape)}, expected {(B, 2, H, W)}")
             src = _lib.require_device_tensor(flow.detach(), "flow map")
             if src.dtype != torch.float32 or src.stride(3) != 1 or src.stride(2) != W:
                 src = src.to(torch.float32).contiguous()
-            rc = lib.tef_pack_flow(src.data_ptr(), src.stride(0), src.stride(1), B, H, W,
-                                   win.flows[self._passes, i].data_ptr(), win.flows_yx[self._passes, i].data_ptr(),
-                                   _lib.stream_ptr())
-            _lib.check(rc, "tef_pack_flow")
+            srcs.append(src)
             refs.append(flow)
+        if F <= 16:       # all heads of the pass in one launch
+            ptrs = (ctypes.c_void_p * F)(*[t.data_ptr() for t in srcs])
+            sb = (ctypes.c_long * F)(*[t.stride(0) for t in srcs])
+            sc = (ctypes.c_long * F)(*[t.stride(1) for t in srcs])
+            rc = _lib.lib().tef_pack_flows(ptrs, sb, sc, F, B, H, W, win.flows[self._passes].data_ptr(),
+                                           win.flows_yx[self._passes].data_ptr(), _lib.stream_ptr())
+            _lib.check(rc, "tef_pack_flows")
+        else:
+            for i, src in enumerate(srcs):
+                rc = _lib.lib().tef_pack_flow(src.data_ptr(), src.stride(0), src.stride(1), B, H, W,
+                                              win.flows[self._passes, i].data_ptr(), win.flows_yx[self._passes, i].data_ptr(),
+                                              _lib.stream_ptr())
+                _lib.check(rc, "tef_pack_flow")
         win.flow_refs.append(refs)
 
     def reset_base(self):
