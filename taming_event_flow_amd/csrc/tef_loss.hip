@@ -1006,6 +1006,44 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     return make_float2(gy, gx);
 }
 
+// The same gradient when the position is STRICTLY inside its pixel cell and the cell inside the frame (decided per
+// wavefront by the caller), one polarity, one temporal scale: the hat slopes are exactly -1 (near corner) and +1 (far
+// corner), so the sign / tie logic of hat() and the slope products drop out.  Same operations on the same values in the
+// same order as image_grad<true, true> (a product with +-1 is exact).
+__device__ __forceinline__ float2 image_grad_cell(const Win &w, const float2 *__restrict__ ar,
+                                                  const float *__restrict__ stats, int ib, int j, float kscale, float tref,
+                                                  float delta, int cell, float wy0, float wy1, float wx0, float wx1,
+                                                  float ts, float mp, float mn)
+{
+    const int HW = w.H * w.W;
+    const size_t q = (size_t)j * (w.F * w.B) + ib;
+    const float kimg = kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]);
+    const float2 *pl = ar + q * 2 * HW + ((mp != 0.0f) ? 0 : HW);
+    const float m1 = (mp != 0.0f) ? mp : mn;
+    const float tau = 1.0f - div_by_const(fabsf(tref - ts), 1.0 / (double)delta);
+    const f32x4_a8 r0 = *reinterpret_cast<const f32x4_a8 *>(pl + cell), r1 = *reinterpret_cast<const f32x4_a8 *>(pl + cell + w.W);
+    float gy = 0.0f, gx = 0.0f;
+    {
+        float dw0 = m1 * (2.0f * r0.x * (tau - r0.x) * r0.y), dw1 = m1 * (2.0f * r0.z * (tau - r0.z) * r0.w);
+        dw0 *= kimg;
+        dw1 *= kimg;
+        gy += dw0 * (-wx0);
+        gx += dw0 * (-wy0);
+        gy += dw1 * (-wx1);
+        gx += dw1 * wy0;
+    }
+    {
+        float dw0 = m1 * (2.0f * r1.x * (tau - r1.x) * r1.y), dw1 = m1 * (2.0f * r1.z * (tau - r1.z) * r1.w);
+        dw0 *= kimg;
+        dw1 *= kimg;
+        gy += dw0 * wx0;
+        gx += dw0 * (-wy1);
+        gy += dw1 * wx1;
+        gx += dw1 * wy1;
+    }
+    return make_float2(gy, gx);
+}
+
 template <bool FAST = false>
 __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
                                              const float *__restrict__ stats, int ib, int j, float kscale, float tref,
@@ -1149,15 +1187,22 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         if (!ONE) return false;
         int y0, x0;
         Taps tp = taps_core(nxt.x, nxt.y, H, W, y0, x0);
-        Splat sp = make_splat(cur.x, cur.y);
-        const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (sp.iy[0] >= 0) & (sp.iy[1] < H) &
-                            (sp.ix[0] >= 0) & (sp.ix[1] < W) & (sp.ix[1] == sp.ix[0] + 1);
+        // bilinear cell of `cur` (utils/iwe.py:85-107): near weights 1 - d with d = p - floor(p) in [0, 1), far weights
+        // 1 - |p - floor(p + 1)|; "strictly inside" = no weight is 0 or 1 (ties take the general path: hat() splits them)
+        const float fy = floorf(cur.x), fx = floorf(cur.y);
+        const float dy = cur.x - fy, dx = cur.y - fx;
+        const float wy0 = 1.0f - dy, wx0 = 1.0f - dx;
+        const float wy1 = 1.0f - fabsf(cur.x - floorf(cur.x + 1.0f)), wx1 = 1.0f - fabsf(cur.y - floorf(cur.y + 1.0f));
+        const int iy0 = (int)fy, ix0 = (int)fx;
+        const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (iy0 >= 0) & (iy0 < H - 1) &
+                            (ix0 >= 0) & (ix0 < W - 1) & (dy > 0.0f) & (dx > 0.0f) & (wy1 > 0.0f) & (wx1 > 0.0f);
         if (__builtin_amdgcn_ballot_w64(!inside) != 0) return false;
         const int kmc = min(max(km, 0), P - 1);                   // (the jacobian of the last step is not used)
         Quad2 q = load_quad_interior(flow_map(w, flows, kmc, i, b), y0 * W + x0, W);
         gk = make_float2(0.0f, 0.0f);
         if (t >= k - reach && t < k + reach)
-            gk = image_grad<true, true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, sp, ts, mp, mn);
+            gk = image_grad_cell(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, iy0 * W + ix0, wy0, wy1,
+                                 wx0, wx1, ts, mp, mn);
         quad_jacobian(q, tp, jyy, jyx, jxy, jxx);
         return true;
     };
