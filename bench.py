@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--no-train-extra", action="store_true",
                     help="loss mode at 1 GPU: skip the short training-window measurement appended as `extra`")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
-    ap.add_argument("--event-every", type=int, default=16,
+    ap.add_argument("--event-every", type=int, default=24,
                     help="per-kernel HIP events are recorded on every K-th timed step (each pair costs a few us of stream time)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: repeat the window this long")
     return ap.parse_args()

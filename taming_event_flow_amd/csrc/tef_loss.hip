@@ -1985,7 +1985,8 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
                              grad_out, cy, cx, wmax, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
-    hipLaunchKernelGGL(mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax, (int *)(ws + L.queue) + 8);      // (M = 0: writes zeros)
+    TEF_LAUNCH_TIMED(tef::PROF_STATS, mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax,
+                     (int *)(ws + L.queue) + 8);      // (M = 0: writes zeros)
     if (int rc = tef::check_launch("mag_reduce_kernel")) return rc;
     int rows, nbands;
     size_t lds;
