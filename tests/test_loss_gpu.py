@@ -198,6 +198,23 @@ def test_randomised_sweep(dev):
     assert bad == 0 and worst <= TOL
 
 
+def test_long_runs_take_fp64_accumulators(dev):
+    """>= 2^17 events feeding one flow map (K7) / one polarity of one image (K2): the integer accumulators could overflow,
+    the workgroups fall back to fp64 planes.  P = 2, 140 000 events per pass: K7 takes the fallback for every map (280 000
+    events each), K2 for the images that see both passes."""
+    from oracle import oracle
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(31)
+    win = synth.make_window(rng, 1, 48, 64, 2, 1, 140000, 0, sigma=1.0)
+    meta = dict(H=48, W=64, B=1, P=2, S=1, mode="one", spat=None, temp=None, round_ts=False)
+    l, g, _ = run_hip("Iterative", make_cfg(meta), win, dev)
+    ow = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=1, mode="one")
+    ol, od = ow.loss("Iterative")
+    assert abs(l - ol) <= TOL * abs(ol), (l, float(ol))
+    assert rel_err(g, od) <= TOL
+
+
 def test_bitwise_reproducible(dev):
     """Both scatter kernels accumulate exact integers (Q17.46 / block-floating) and the chain kernels have no atomics:
     loss and gradients of a window are bit-identical from run to run, whatever order the atomics arrive in."""
