@@ -640,21 +640,19 @@ __device__ __forceinline__ void splat_run_general(const Win &w, const Img &im, d
     }
 }
 
-constexpr int kMaxRuns = 4 * TEF_MAX_PASSES;      // (pos, neg) x (grad, detached) per pass
 
-// band pixels -> (A, R) + focus-loss partial sums.  planes: [pos C | pos T | neg C | neg T], each nrows x WP
+// band pixels of one polarity -> (A, R), the polarity's share of the focus-loss sum, and one byte per pixel "C != 0" (the
+// count of active pixels needs both polarities: image_count_kernel).  planes: [C | T], each nrows x WP
 template <bool FX>
-__device__ __forceinline__ void band_stats(const double *planes, int nrows, int W, int WP, float2 *__restrict__ ar_pos,
-                                           float2 *__restrict__ ar_neg, float &acc, int &nnz)
+__device__ __forceinline__ void band_stats(const double *planes, int nrows, int W, int WP, float2 *__restrict__ ar,
+                                           uint8_t *__restrict__ nz, float &acc)
 {
-    const double *cp = planes, *tp = planes + (size_t)nrows * WP, *cn = planes + (size_t)2 * nrows * WP,
-                 *tn = planes + (size_t)3 * nrows * WP;
-    auto pixel = [&](float c0, float t0, float c1, float t1, float2 &o0, float2 &o1) {
-        float a0 = t0 / (c0 + kEps), a1 = t1 / (c1 + kEps);           // :727
-        o0 = make_float2(a0, 1.0f / (c0 + kEps));
-        o1 = make_float2(a1, 1.0f / (c1 + kEps));
-        acc += a0 * a0 + a1 * a1;                                       // :122-123
-        nnz += ((c0 + c1) != 0.0f);                                     // :125
+    const double *cp = planes, *tp = planes + (size_t)nrows * WP;
+    auto pixel = [&](float c, float t, float2 &o) {
+        float a = t / (c + kEps);                     // :727
+        o = make_float2(a, 1.0f / (c + kEps));
+        acc += a * a;                                 // :122-123
+        return (uint8_t)(c != 0.0f);                  // :125 (masks are non-negative: C_pos + C_neg != 0 <=> either is)
     };
     const int half = W >> 1;
     if (!(W & 1) && !(WP & 1) && half > 0 && (int)blockDim.x % half == 0) {
@@ -662,69 +660,92 @@ __device__ __forceinline__ void band_stats(const double *planes, int nrows, int 
         int r = threadIdx.x / half, c = (threadIdx.x - r * half) * 2;
         for (; r < nrows; r += rstep) {
             const int i = r * WP + c;
-            double2 dc0 = *reinterpret_cast<const double2 *>(cp + i), dt0 = *reinterpret_cast<const double2 *>(tp + i);
-            double2 dc1 = *reinterpret_cast<const double2 *>(cn + i), dt1 = *reinterpret_cast<const double2 *>(tn + i);
-            float2 p0, n0, p1, n1;
-            pixel(acc_value<FX>(dc0.x), acc_value<FX>(dt0.x), acc_value<FX>(dc1.x), acc_value<FX>(dt1.x), p0, n0);
-            pixel(acc_value<FX>(dc0.y), acc_value<FX>(dt0.y), acc_value<FX>(dc1.y), acc_value<FX>(dt1.y), p1, n1);
+            double2 dc = *reinterpret_cast<const double2 *>(cp + i), dt = *reinterpret_cast<const double2 *>(tp + i);
+            float2 p0, p1;
+            const uint8_t z0 = pixel(acc_value<FX>(dc.x), acc_value<FX>(dt.x), p0), z1 = pixel(acc_value<FX>(dc.y), acc_value<FX>(dt.y), p1);
             const size_t o = (size_t)r * W + c;
-            *reinterpret_cast<float4 *>(ar_pos + o) = make_float4(p0.x, p0.y, p1.x, p1.y);
-            *reinterpret_cast<float4 *>(ar_neg + o) = make_float4(n0.x, n0.y, n1.x, n1.y);
+            *reinterpret_cast<float4 *>(ar + o) = make_float4(p0.x, p0.y, p1.x, p1.y);
+            *reinterpret_cast<uchar2 *>(nz + o) = make_uchar2(z0, z1);
         }
     } else {
         for (int q = threadIdx.x; q < nrows * W; q += blockDim.x) {
             const int r = q / W, i = r * WP + (q - r * W);
-            float2 p0, n0;
-            pixel(acc_value<FX>(cp[i]), acc_value<FX>(tp[i]), acc_value<FX>(cn[i]), acc_value<FX>(tn[i]), p0, n0);
-            ar_pos[q] = p0;
-            ar_neg[q] = n0;
+            float2 p0;
+            nz[q] = pixel(acc_value<FX>(cp[i]), acc_value<FX>(tp[i]), p0);
+            ar[q] = p0;
         }
     }
 }
 
-__global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Events g, Events d,
-                                                                    const float2 *__restrict__ traj,
-                                                                    const uint32_t *__restrict__ meta,
-                                                                    const float2 *__restrict__ yr,
-                                                                    float2 *__restrict__ ar, double *__restrict__ part,
-                                                                    int rows_per_band, int nbands, int *__restrict__ queue)
+// number of pixels of each image that hold events of either polarity (loss/flow.py:125-127), from K2's per-polarity bytes
+__global__ __launch_bounds__(256) void image_count_kernel(const uint8_t *__restrict__ nz, int HW, double *__restrict__ cnt)
+{
+    __shared__ int red[4];
+    const uint8_t *p = nz + (size_t)blockIdx.x * 2 * HW, *n = p + HW;
+    int c = 0;
+    if ((HW & 3) == 0) {
+        for (int k = threadIdx.x; k < (HW >> 2); k += blockDim.x) {
+            const uint32_t v = reinterpret_cast<const uint32_t *>(p)[k] | reinterpret_cast<const uint32_t *>(n)[k];
+            c += __popc(v & 0x01010101u);
+        }
+    } else {
+        for (int k = threadIdx.x; k < HW; k += blockDim.x) c += (p[k] | n[k]) & 1;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) c += __shfl_down(c, sft, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = (double)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+constexpr int kSplat2Threads = 512;             // K2: two such workgroups per CU
+constexpr size_t kSplat2LdsBudget = 70 * 1024;  // planes of one K2 workgroup (beside ~6 KiB of run tables and row lists)
+
+__global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Events g, Events d,
+                                                                     const float2 *__restrict__ traj,
+                                                                     const uint32_t *__restrict__ meta,
+                                                                     const float2 *__restrict__ yr,
+                                                                     float2 *__restrict__ ar, uint8_t *__restrict__ nz,
+                                                                     double *__restrict__ part, int rows_per_band,
+                                                                     int nbands, int *__restrict__ queue)
 {
     extern __shared__ double lds_img[];
-    __shared__ int run_u0[kMaxRuns], run_len[kMaxRuns], run_cum[kMaxRuns + 1], s_item, s_flags[3];
-    __shared__ int2 hit_list[2 * kSplatThreads];   // 128 (row, run) entries per wavefront
-    __shared__ double red_s[kSplatThreads / 64];
-    __shared__ int red_n[kSplatThreads / 64];
+    constexpr int kRuns = 2 * TEF_MAX_PASSES;      // (grad, detached) per pass, one polarity
+    __shared__ int run_u0[kRuns], run_len[kRuns], run_cum[kRuns + 1], s_item, s_flags[2];
+    __shared__ int2 hit_list[2 * kSplat2Threads];  // 128 (row, lanes) entries per wavefront
+    __shared__ double red_s[kSplat2Threads / 64];
     const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad, HW = H * W;
     const int xcd = blockIdx.x & 7;
-    const int nitems = w.nimg * FB;
-    const int stride = blockDim.x, step = kUnroll * stride;
+    const int nitems = w.nimg * FB, nsub = 2 * nbands;
     if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
     __syncthreads();
     for (;;) {
         const int q = s_item;
-        const int it = xcd + 8 * (q / nbands), band = q - (q / nbands) * nbands;
+        const int it = xcd + 8 * (q / nsub), sub = q - (q / nsub) * nsub;
         if (it >= nitems) break;
+        const int c = sub & 1, band = sub >> 1;          // polarity, row band
         const int j = w.order[it / FB], ib = it % FB, b = ib % w.B;
         const int r0 = band * rows_per_band, nrows = min(H, r0 + rows_per_band) - r0;
         const Img im = decode_image(w, j);
         const double rdelta = 1.0 / (double)im.delta;
         const float band_lo = (float)(r0 - 1), band_hi = (float)(r0 + nrows);     // rows floor(y), floor(y) + 1 of an event
-        lds_plane_zero(lds_img, 4 * nrows * WP);         // all-zero bits: 0.0 and integer 0 alike
-        // run list of the integer path ([pos-only] and [neg-only] slots of every pass / list) + accumulator choice
-        const int nb = im.he - im.le, nlists = w.Md > 0 ? 2 : 1, nruns = 2 * nb * nlists;
-        if (threadIdx.x < 3) s_flags[threadIdx.x] = 0;
+        const size_t plane_sz = (size_t)nrows * WP;
+        double *img_c = lds_img, *img_t = lds_img + plane_sz;
+        lds_plane_zero(lds_img, 2 * nrows * WP);         // all-zero bits: 0.0 and integer 0 alike
+        // run list of the integer path (the [pos-only] or [neg-only] slots of every pass / list) + accumulator choice
+        const int nb = im.he - im.le, nlists = w.Md > 0 ? 2 : 1, nruns = nb * nlists;
+        if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
         __syncthreads();                                  // (also: everybody has read s_item)
         int next_item = 0;
         if (threadIdx.x == 0) next_item = atomicAdd(&queue[xcd], 1);      // in flight while this item is worked on
         if ((int)threadIdx.x < nruns) {
-            const int r = threadIdx.x, c = r & 1, k = r >> 1;
-            const bool isd = k >= nb;
-            const int t = im.le + (isd ? k - nb : k);
+            const int r = threadIdx.x;
+            const bool isd = r >= nb;
+            const int t = im.le + (isd ? r - nb : r);
             const int *cl = (isd ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
             run_u0[r] = (isd ? w.M + w.doff[t] : w.off[t]) + (c ? cl[0] : 0);
             run_len[r] = c ? cl[1] - cl[0] : cl[0];
             if (cl[2] != cl[1]) atomicOr(&s_flags[0], 1);                  // general masks present
-            atomicAdd(&s_flags[1 + c], run_len[r]);                         // events per polarity plane pair
+            atomicAdd(&s_flags[1], run_len[r]);
         }
         __syncthreads();
         if (threadIdx.x < 64) {       // rows (16 slots) spanned by every run, as a running total: one wavefront scans
@@ -744,16 +765,15 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
             if (threadIdx.x == 0) run_cum[nruns] = carry;
         }
         __syncthreads();
-        const bool fixed = s_flags[0] == 0 && s_flags[1] < kFxMaxEvents && s_flags[2] < kFxMaxEvents;
+        const bool fixed = s_flags[0] == 0 && s_flags[1] < kFxMaxEvents;
         const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
         const uint32_t *mt = meta + (size_t)ib * w.Mt;
-        const size_t plane_sz = (size_t)nrows * WP;
         if (fixed) {
             // Wave-centric sweep.  The rows (16 slots) of all runs form one flattened sequence; a wavefront takes groups of
-            // 64 consecutive rows: every lane reads ONE row interval (a coalesced 512-byte load), the rows that can touch
-            // the band are compacted into the wavefront's list, and the wavefront then works through the list four rows
-            // (4 x 16 lanes) at a time with the next four rows' events already in flight.  Iterations are dense in work
-            // whatever the fraction of rows that hit (a workgroup-wide chunk loop spent a memory round trip per mostly
+            // 128 consecutive rows: every lane reads two row intervals (coalesced 512-byte loads), the rows that can touch
+            // the band are compacted into the wavefront's list, and the wavefront then works through the list in batches of
+            // 16 rows (four quads of 4 x 16 lanes) with the next batch's events already in flight.  Iterations are dense in
+            // work whatever the fraction of rows that hit (a workgroup-wide chunk loop spent a memory round trip per mostly
             // skipped chunk: 0.30 ms instead of 0.21).
             const float2 *rows = yr + ((size_t)ib * (w.nplanes + 1) + im.plane) * w.nrow;
             const float *tsg = g.ts + (size_t)b * g.cap;                                   // indexed by unified slot
@@ -778,34 +798,30 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
                 }
                 return rg;
             };
-            struct Quad { uint32_t mv; float2 p; float ts; int c; };
-            // list entry of a hit row: x = first slot of the row, y = [lo | hi << 8 | polarity << 16 | detached << 17] with
-            // [lo, hi) the lanes of the row that belong to the run (everything a quad needs, decided once per row)
-            auto load_quad_rows = [&](int s, int h) -> Quad {      // events of list entries s .. s + 3, 16 lanes each
+            struct Quad { uint32_t mv; float2 p; float ts; };
+            // list entry of a hit row: x = first slot of the row, y = [lo | hi << 8 | detached << 16] with [lo, hi) the lanes
+            // of the row that belong to the run (everything a quad needs, decided once per row)
+            auto load_quad_rows = [&](int s_, int h) -> Quad {      // events of list entries s_ .. s_ + 3, 16 lanes each
                 Quad qd;
                 qd.mv = 0u;
                 qd.p = make_float2(0.0f, 0.0f);
                 qd.ts = 0.0f;
-                qd.c = 0;
-                const int e = s + (lane >> 4);
+                const int e = s_ + (lane >> 4);
                 if (e < h) {
                     const int2 en = list[e];
                     const int l16 = lane & 15, u = en.x + l16;
-                    qd.c = (en.y >> 16) & 1;
                     if (l16 >= (en.y & 0xff) && l16 < ((en.y >> 8) & 0xff)) {
                         qd.mv = mt[u];
                         qd.p = pl[u];
-                        qd.ts = ((en.y >> 17) ? tsd : tsg)[u];
+                        qd.ts = ((en.y >> 16) ? tsd : tsg)[u];
                     }
                 }
                 return qd;
             };
             auto list_entry = [&](int row, int r) {
                 const int u0 = run_u0[r], u1 = u0 + run_len[r], ub = row * 16;
-                return make_int2(ub, max(u0 - ub, 0) | (min(u1 - ub, 16) << 8) | ((r & 1) << 16) | (((r >> 1) >= nb ? 1 : 0) << 17));
+                return make_int2(ub, max(u0 - ub, 0) | (min(u1 - ub, 16) << 8) | ((r >= nb ? 1 : 0) << 16));
             };
-            // groups of 128 rows (two intervals per lane); the hit rows are worked through in batches of 16 (four quads of
-            // 4 x 16 lanes), the next batch's events in flight while a batch is processed
             constexpr int kQ = 4;
             int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
             float2 rg_cur[2], rg_nxt[2];
@@ -829,10 +845,8 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
                     for (int k = 0; k < kQ; ++k) nxt[k] = load_quad_rows(sidx + 4 * (kQ + k), h);
 #pragma unroll
                     for (int k = 0; k < kQ; ++k)
-                        if ((cur[k].mv >> im.s) & 1u) {           // shared border mask (:671-681)
-                            double *img_c = lds_img + (size_t)cur[k].c * 2 * plane_sz;
-                            splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_c + plane_sz, r0, nrows, WP);
-                        }
+                        if ((cur[k].mv >> im.s) & 1u)            // shared border mask (:671-681)
+                            splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
 #pragma unroll
                     for (int k = 0; k < kQ; ++k) cur[k] = nxt[k];
                 }
@@ -844,46 +858,33 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
                 }
             }
         } else {
-            for (int c = 0; c < 2; ++c) {
-                double *img_c = lds_img + (size_t)c * 2 * plane_sz, *img_t = img_c + plane_sz;
-                for (int li = 0; li < nlists; ++li)
-                    for (int t = im.le; t < im.he; ++t) {
-                        const int *cl = (li ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
-                        const int s0 = li ? w.M + w.doff[t] : w.off[t];
-                        const int n0 = cl[0], n01 = cl[1], n012 = cl[2];
-                        if (c == 0) {
-                            splat_run_general(w, im, rdelta, g, d, b, c, s0, n0, pl, mt, img_c, img_t, r0, nrows);
-                            splat_run_general(w, im, rdelta, g, d, b, c, s0 + n01, n012 - n01, pl, mt, img_c, img_t, r0, nrows);
-                        } else {
-                            splat_run_general(w, im, rdelta, g, d, b, c, s0 + n0, n012 - n0, pl, mt, img_c, img_t, r0, nrows);
-                        }
+            for (int li = 0; li < nlists; ++li)
+                for (int t = im.le; t < im.he; ++t) {
+                    const int *cl = (li ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
+                    const int s0 = li ? w.M + w.doff[t] : w.off[t];
+                    const int n0 = cl[0], n01 = cl[1], n012 = cl[2];
+                    if (c == 0) {
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0, n0, pl, mt, img_c, img_t, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n01, n012 - n01, pl, mt, img_c, img_t, r0, nrows);
+                    } else {
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n0, n012 - n0, pl, mt, img_c, img_t, r0, nrows);
                     }
-            }
+                }
         }
         __syncthreads();
-        // ---- band statistics (what image_stats did in a separate launch over the stored images) ----
+        // ---- band statistics of this polarity (round 1: a separate launch over the stored images) ----
         float acc = 0.0f;
-        int nnz = 0;
-        const size_t qimg = (size_t)j * FB + ib;
-        float2 *ar_pos = ar + qimg * 2 * HW + (size_t)r0 * W, *ar_neg = ar_pos + HW;
-        if (fixed) band_stats<true>(lds_img, nrows, W, WP, ar_pos, ar_neg, acc, nnz);
-        else band_stats<false>(lds_img, nrows, W, WP, ar_pos, ar_neg, acc, nnz);
+        const size_t qpol = ((size_t)j * FB + ib) * 2 + c, o = qpol * HW + (size_t)r0 * W;
+        if (fixed) band_stats<true>(lds_img, nrows, W, WP, ar + o, nz + o, acc);
+        else band_stats<false>(lds_img, nrows, W, WP, ar + o, nz + o, acc);
         double dacc = (double)acc;
-        for (int sft = 32; sft > 0; sft >>= 1) {
-            dacc += __shfl_down(dacc, sft, 64);
-            nnz += __shfl_down(nnz, sft, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            red_s[threadIdx.x >> 6] = dacc;
-            red_n[threadIdx.x >> 6] = nnz;
-        }
+        for (int sft = 32; sft > 0; sft >>= 1) dacc += __shfl_down(dacc, sft, 64);
+        if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = dacc;
         __syncthreads();                                  // (also: the planes have been read, the next item may clear them)
         if (threadIdx.x == 0) {
             double s2 = 0.0;
-            int cnt = 0;
-            for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { s2 += red_s[k]; cnt += red_n[k]; }      // fixed order
-            part[(qimg * nbands + band) * 2] = s2;
-            part[(qimg * nbands + band) * 2 + 1] = (double)cnt;
+            for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s2 += red_s[k];      // fixed order
+            part[qpol * nbands + band] = s2;
             s_item = next_item;
         }
         __syncthreads();
@@ -893,17 +894,16 @@ __global__ __launch_bounds__(kSplatThreads) void splat_stats_kernel(Win w, Event
 // K4: per-image statistics from the band parts of K2, stats[q] = (sum A^2 / n, n = #active pixels + 1e-9), and
 // loss = sum_images coef * (sum over samples of the per-sample term); fixed summation order.
 __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *__restrict__ part, int nparts,
-                                                          float *__restrict__ stats, float *__restrict__ loss_out)
+                                                          const double *__restrict__ counts, float *__restrict__ stats,
+                                                          float *__restrict__ loss_out)
 {
     __shared__ double ssum[256];
     const int FB = w.F * w.B;
     double acc = 0.0;
     for (int q = threadIdx.x; q < w.nimg * FB; q += blockDim.x) {
         double s2 = 0.0, cnt = 0.0;
-        for (int k = 0; k < nparts; ++k) {
-            s2 += part[((size_t)q * nparts + k) * 2];
-            cnt += part[((size_t)q * nparts + k) * 2 + 1];
-        }
+        for (int k = 0; k < 2 * nparts; ++k) s2 += part[(size_t)q * 2 * nparts + k];      // (polarity, band), fixed order
+        cnt = counts[q];
         float n = w.scaling ? (float)cnt + kEps : 1.0f;      // loss/flow.py:124-127
         float term = (float)s2 / n;
         stats[(size_t)q * 2] = term;
@@ -1689,7 +1689,7 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, yr, ar, stats, parts, queue, cmax, wmax, cy, cx, total;
+    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cy, cx, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1701,7 +1701,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     if (c->B < 1 || c->H < 2 || c->W < 2 || c->F < 1) return tef::fail("bad B/H/W/F");
     if (c->P < 1 || c->P > TEF_MAX_PASSES) return tef::fail("passes_loss out of range [1, 64]");
     if (c->S < 1 || c->S > TEF_MAX_SCALES) return tef::fail("scales_loss out of range [1, 6]");
-    if (4 * (size_t)(c->W + kRowPad) * sizeof(double) > kSplatLdsBudget) return tef::fail("image row does not fit the LDS band");
+    if (2 * (size_t)(c->W + kRowPad) * sizeof(double) > kSplat2LdsBudget) return tef::fail("image row does not fit the LDS band");
     if (c->kind == TEF_KIND_ITERATIVE) {
         // iterative_mode "four" raises TypeError in the reference itself (loss/flow.py:666-692); only one/two exist here
         if (c->mode_div != 1 && c->mode_div != 2) return tef::fail("iterative_mode must be 'one' or 'two'");
@@ -1759,9 +1759,9 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     return true;
 }
 
-inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds)
+inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds, size_t budget = kSplatLdsBudget)
 {
-    int rows = (int)(kSplatLdsBudget / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
+    int rows = (int)(budget / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
     (void)kLdsBudget;
     if (rows > w.H) rows = w.H;
     *nbands = (w.H + rows - 1) / rows;
@@ -1782,10 +1782,12 @@ Layout make_layout(const Win &w)
     L.yr = o;     o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.nrow * sizeof(float2));
     L.ar = o;     o += align_up(img * sizeof(float2));
     L.stats = o;  o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
+    L.nz = o;     o += align_up(img * sizeof(uint8_t));
+    L.counts = o; o += align_up((size_t)w.nimg * FB * sizeof(double));
     {
         int rows, nbands;
         size_t lds;
-        band_geometry(w, 4, &rows, &nbands, &lds);
+        band_geometry(w, 2, &rows, &nbands, &lds, kSplat2LdsBudget);
         L.parts = o;  o += align_up((size_t)w.nimg * FB * nbands * 2 * sizeof(double));
     }
     L.queue = o;  o += align_up((kQueueInts + FB) * sizeof(int));      // + one magnitude word per (head, sample) for K6 -> K7
@@ -1827,7 +1829,7 @@ inline int num_cus()
 bool ensure_attrs()
 {
     static const hipError_t e1 = hipFuncSetAttribute((const void *)splat_stats_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplat2LdsBudget);
     static const hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
     if (e1 != hipSuccess || e2 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e1 != hipSuccess ? e1 : e2);
@@ -1933,20 +1935,25 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
     size_t lds;
-    band_geometry(w, 4, &rows, &nbands, &lds);
+    band_geometry(w, 2, &rows, &nbands, &lds, kSplat2LdsBudget);
     if (w.Mt == 0 && hipMemsetAsync(queue, 0, (kQueueInts + FB) * sizeof(int), st) != hipSuccess)      // (K1 clears them otherwise)
         return tef::fail("hipMemsetAsync(queue)"), TEF_ERR_LAUNCH;
+    uint8_t *nz = (uint8_t *)(ws + L.nz);
+    double *counts = (double *)(ws + L.counts);
     {
-        // persistent workgroups, one per CU (the four planes fill its LDS), a multiple of 8 so that every XCD queue is served
-        const long items = (long)w.nimg * FB * nbands;
-        unsigned grid = (unsigned)std::min<long>(items, num_cus());
+        // persistent workgroups, two per CU (each holds the two planes of one polarity of a 32-row band at 128 x 128), a
+        // multiple of 8 so that every XCD queue is served
+        const long items = (long)w.nimg * FB * nbands * 2;
+        unsigned grid = (unsigned)std::min<long>(items, 2 * num_cus());
         grid = std::max(8u, (grid + 7u) & ~7u);
-        TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel, dim3(grid), dim3(kSplatThreads), lds, st, w, g, d, traj, meta, yr,
-                         ar, (double *)(ws + L.parts), rows, nbands, queue);
+        TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel, dim3(grid), dim3(kSplat2Threads), lds, st, w, g, d, traj, meta, yr,
+                         ar, nz, (double *)(ws + L.parts), rows, nbands, queue);
     }
     if (int rc = tef::check_launch("splat_stats_kernel")) return rc;
+    hipLaunchKernelGGL(image_count_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, nz, w.H * w.W, counts);
+    if (int rc = tef::check_launch("image_count_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_REDUCE, loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), nbands,
-                     stats, loss_out);
+                     counts, stats, loss_out);
     return tef::check_launch("loss_reduce_kernel");
 }
 
