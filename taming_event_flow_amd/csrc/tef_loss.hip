@@ -1950,7 +1950,7 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
                          ar, nz, (double *)(ws + L.parts), rows, nbands, queue);
     }
     if (int rc = tef::check_launch("splat_stats_kernel")) return rc;
-    hipLaunchKernelGGL(image_count_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, nz, w.H * w.W, counts);
+    TEF_LAUNCH_TIMED(tef::PROF_COUNT, image_count_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, nz, w.H * w.W, counts);
     if (int rc = tef::check_launch("image_count_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_REDUCE, loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), nbands,
                      counts, stats, loss_out);
