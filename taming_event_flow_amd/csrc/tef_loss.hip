@@ -35,6 +35,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "tef.h"
 #include "tef_common.h"
@@ -172,6 +173,40 @@ __device__ __forceinline__ Taps taps_core(float y, float x, int H, int W, int &y
 {
     Taps t;
     float iy = unnormalize<IEEE>(y, H), ix = unnormalize<IEEE>(x, W);
+    float fy = floorf(iy), fx = floorf(ix);
+    t.n = iy - fy;
+    t.w = ix - fx;
+    t.s = 1.0f - t.n;
+    t.e = 1.0f - t.w;
+    y0 = (int)fy;
+    x0 = (int)fx;
+    return t;
+}
+
+// The lookup's constants of one axis as wave-uniform (scalar-register) values: the exact reciprocal of size - 1 for
+// div_by_const and (size - 1) / 2.  (Computed in the kernel they would sit in vector registers of every lane.)
+struct AxisConst { double rinv; float half; };
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint64_t r = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u) |
+                       ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32)) << 32);
+    return __longlong_as_double((long long)r);
+}
+__device__ __forceinline__ float uniform_f32(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ AxisConst axis_const(int size)
+{
+    AxisConst a;
+    a.rinv = uniform_f64(1.0 / (double)(size - 1));
+    a.half = uniform_f32((float)(size - 1) / 2.0f);
+    return a;
+}
+// taps_core<false> with the constants handed in (same operations, same bits)
+__device__ __forceinline__ Taps taps_core(float y, float x, const AxisConst &ah, const AxisConst &aw, int &y0, int &x0)
+{
+    Taps t;
+    float iy = (div_by_const(2.0f * y, ah.rinv) - 1.0f + 1.0f) * ah.half;
+    float ix = (div_by_const(2.0f * x, aw.rinv) - 1.0f + 1.0f) * aw.half;
     float fy = floorf(iy), fx = floorf(ix);
     t.n = iy - fy;
     t.w = ix - fx;
@@ -931,17 +966,14 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
 // (a reciprocal there leaves ulp-sized gradients where the true one is zero: tests/fuzz_loss.py, mode "one", odd P).
 // INTERIOR (decided per wavefront by the caller): all four corners inside the image, the right column adjacent to the
 // left one and a single polarity — the validity selects, the fp32 corner case and the second-polarity branch drop out.
+// pos: the image's positive-polarity (A, R) plane (the negative one follows it); kimg = K / n of the image
 template <bool FAST = false, bool INTERIOR = false>
-__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
-                                             const float *__restrict__ stats, int ib, int j, float kscale, float tref,
-                                             float delta, const Splat &sp, float ts, float mp, float mn)
+__device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__restrict__ pos, float kimg, float tref,
+                                                float delta, const Splat &sp, float ts, float mp, float mn)
 {
-    const int HW = w.H * w.W;
-    const int FB = w.F * w.B;
-    size_t q = (size_t)j * FB + ib;
-    float kimg = FAST ? kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]) : kscale / stats[q * 2 + 1];
-    const float2 *pos = ar + q * 2 * HW;
+    const int HW = H * W;
     const float2 *neg = pos + HW;
+    struct { int H, W; } w = {H, W};
     // (FAST: delta is kernel-invariant there, an integer number of passes: the same bits from the cheaper exact form)
     float tau = FAST ? 1.0f - div_by_const(fabsf(tref - ts), 1.0 / (double)delta) : 1.0f - fabsf(tref - ts) / delta;
     float gy = 0.0f, gx = 0.0f;
@@ -1006,22 +1038,24 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     return make_float2(gy, gx);
 }
 
+template <bool FAST = false, bool INTERIOR = false>
+__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar,
+                                             const float *__restrict__ stats, int ib, int j, float kscale, float tref,
+                                             float delta, const Splat &sp, float ts, float mp, float mn)
+{
+    const size_t q = (size_t)j * (w.F * w.B) + ib;
+    const float kimg = FAST ? kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]) : kscale / stats[q * 2 + 1];
+    return image_grad_at<FAST, INTERIOR>(w.H, w.W, ar + q * 2 * (size_t)(w.H * w.W), kimg, tref, delta, sp, ts, mp, mn);
+}
+
 // The same gradient when the position is STRICTLY inside its pixel cell and the cell inside the frame (decided per
 // wavefront by the caller), one polarity, one temporal scale: the hat slopes are exactly -1 (near corner) and +1 (far
 // corner), so the sign / tie logic of hat() and the slope products drop out.  Same operations on the same values in the
-// same order as image_grad<true, true> (a product with +-1 is exact).
-__device__ __forceinline__ float2 image_grad_cell(const Win &w, const float2 *__restrict__ ar,
-                                                  const float *__restrict__ stats, int ib, int j, float kscale, float tref,
-                                                  float delta, int cell, float wy0, float wy1, float wx0, float wx1,
-                                                  float ts, float mp, float mn)
+// same order as image_grad<true, true> (a product with +-1 is exact).  r0 / r1: the (A, R) pairs of the cell's upper and
+// lower pixel rows (loaded by the caller, one chain step ahead); kimg = K / n of the image; m1 = the event's mask value.
+__device__ __forceinline__ float2 cell_grad(const f32x4_a8 r0, const f32x4_a8 r1, float kimg, float tau, float m1,
+                                            float wy0, float wy1, float wx0, float wx1)
 {
-    const int HW = w.H * w.W;
-    const size_t q = (size_t)j * (w.F * w.B) + ib;
-    const float kimg = kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]);
-    const float2 *pl = ar + q * 2 * HW + ((mp != 0.0f) ? 0 : HW);
-    const float m1 = (mp != 0.0f) ? mp : mn;
-    const float tau = 1.0f - div_by_const(fabsf(tref - ts), 1.0 / (double)delta);
-    const f32x4_a8 r0 = *reinterpret_cast<const f32x4_a8 *>(pl + cell), r1 = *reinterpret_cast<const f32x4_a8 *>(pl + cell + w.W);
     float gy = 0.0f, gx = 0.0f;
     {
         float dw0 = m1 * (2.0f * r0.x * (tau - r0.x) * r0.y), dw1 = m1 * (2.0f * r0.z * (tau - r0.z) * r0.w);
@@ -1111,6 +1145,21 @@ __global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restr
     if (threadIdx.x == 0) cmax[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
+// wave-uniform base + 32-bit byte offset per lane: the form the scalar-base global loads / stores take
+// (the uniform element offset goes through readfirstlane so that loop strength reduction cannot turn base + k * stride +
+// lane into a 64-bit per-lane induction pointer)
+__device__ __forceinline__ size_t uniform_off(size_t v)
+{
+    return (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+           ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+template <class T>
+__device__ __forceinline__ T *at_bytes(T *base, uint32_t off)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    return reinterpret_cast<T *>(reinterpret_cast<B *>(base) + off);
+}
+
 typedef float f32x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 NT_LD2(const float2 *p)
 {
@@ -1178,107 +1227,183 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         if (t < k - reach || t >= k + reach) return make_float2(0.0f, 0.0f);      // window [0, P], delta = reach
         return image_grad<true>(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, p, ts, mp, mn);
     };
-    // One chain step when EVERY active lane of the wavefront has all its flow taps (at `nxt`, map `km`) and image corners
-    // (at `cur`, tref k) inside the frame, adjacent, single polarity: plain 16-byte loads and no validity selects (~25 %
-    // fewer vector instructions; border events send their wavefront through the general code).  Same arithmetic, same order.
     const bool one_pol = !((mp != 0.0f) & (mn != 0.0f));
-    auto step_interior = [&](int k, int km, float2 cur, float2 nxt, float2 &gk, float &jyy, float &jyx, float &jxy,
-                             float &jxx) -> bool {
-        if (!ONE) return false;
-        int y0, x0;
-        Taps tp = taps_core(nxt.x, nxt.y, H, W, y0, x0);
-        // bilinear cell of `cur` (utils/iwe.py:85-107): near weights 1 - d with d = p - floor(p) in [0, 1), far weights
-        // 1 - |p - floor(p + 1)|; "strictly inside" = no weight is 0 or 1 (ties take the general path: hat() splits them)
-        const float fy = floorf(cur.x), fx = floorf(cur.y);
-        const float dy = cur.x - fy, dx = cur.y - fx;
-        const float wy0 = 1.0f - dy, wx0 = 1.0f - dx;
-        const float wy1 = 1.0f - fabsf(cur.x - floorf(cur.x + 1.0f)), wx1 = 1.0f - fabsf(cur.y - floorf(cur.y + 1.0f));
-        const int iy0 = (int)fy, ix0 = (int)fx;
-        const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (iy0 >= 0) & (iy0 < H - 1) &
-                            (ix0 >= 0) & (ix0 < W - 1) & (dy > 0.0f) & (dx > 0.0f) & (wy1 > 0.0f) & (wx1 > 0.0f);
-        if (__builtin_amdgcn_ballot_w64(!inside) != 0) return false;
-        const int kmc = min(max(km, 0), P - 1);                   // (the jacobian of the last step is not used)
-        Quad2 q = load_quad_interior(flow_map(w, flows, kmc, i, b), y0 * W + x0, W);
-        gk = make_float2(0.0f, 0.0f);
-        if (t >= k - reach && t < k + reach)
-            gk = image_grad_cell(w, ar, stats, ib, w.img_base[0] + k, one_kscale, (float)k, one_delta, iy0 * W + ix0, wy0, wy1,
-                                 wx0, wx1, ts, mp, mn);
-        quad_jacobian(q, tp, jyy, jyx, jxy, jxx);
-        return true;
-    };
+    const float m1 = (mp != 0.0f) ? mp : mn;
+    const int FB = w.F * w.B;
     float ay = 0.0f, ax = 0.0f;
-    {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = min(P, t + reach) .. t+1
-        const int k0 = min(P, t + reach);
-        // the positions of a step are loaded for every lane, one iteration ahead (planes a lane's chain never reached
-        // hold stale values: such lanes are inactive there)
-        float2 cur = NT_LD2(&tr[(size_t)max(k0, t + 1) * w.Mt]), nxt = NT_LD2(&tr[(size_t)max(k0 - 1, t + 1) * w.Mt]);
-        for (int k = k0; k > t; --k) {
-            float2 nn = NT_LD2(&tr[(size_t)max(k - 2, t + 1) * w.Mt]);
-            if (k <= ks_f) {
-                float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
-                float2 gk;
-                if (!step_interior(k, k - 1, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
-                    Taps tp = make_taps(nxt.x, nxt.y, H, W);
-                    quad_jacobian(load_quad(flow_map(w, flows, max(k - 1, 0), i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-                    gk = pos_grad(k, cur);
-                }
-                ay += gk.x;
-                ax += gk.y;
-                if (k - 1 == t) {
-                    float c = (float)(t + 1) - ts;
-                    c0y += c * ay;
-                    c0x += c * ax;
-                } else {
-                    NT_ST(&coy[(size_t)(k - 1) * M], ay);
-                    NT_ST(&cox[(size_t)(k - 1) * M], ax);
-                    track_mag(mag, ay, ax);
-                    float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
-                    ay = ny;
-                    ax = nx;
-                }
-            } else if (k - 1 > t) {          // the chain has not started yet: this map gets nothing from the event
-                NT_ST(&coy[(size_t)(k - 1) * M], 0.0f);
-                NT_ST(&cox[(size_t)(k - 1) * M], 0.0f);
+    // ---- ONE: both sweeps as straight-line loop bodies ---------------------------------------------------------------
+    // The reference time k of an iteration is wave-uniform, so everything that depends on it alone (map / image / plane /
+    // output base addresses, the image's pixel count, "is tref k within reach of pass t") lives in scalar registers, the
+    // gathers take the scalar-base form with a 32-bit lane offset, and lanes whose chain has not started yet or has left
+    // the frame are handled by selects instead of divergent branches.
+    // The fast form of a step needs EVERY active lane of the wavefront to have its four flow taps and its four image
+    // corners inside the frame, adjacent, strictly inside the pixel cell, one polarity (~25 % fewer vector instructions;
+    // border events and exact ties send their wavefront through the general code).  Same arithmetic in the same order
+    // either way.
+    const AxisConst ach = axis_const(H), acw = axis_const(W);
+    const double rdelta = uniform_f64(1.0 / (double)one_delta);
+    // D = -1: forward chain, newest tref first (k = min(P, t + reach) .. t + 1, map k - 1, p_k = p_{k-1} + dt f_{k-1});
+    // D = +1: backward chain, oldest first (k = max(0, t - reach + 1) .. t, map k, p_k = p_{k+1} - f_k(p_{k+1})).
+    auto sweep = [&](auto dir) {
+        constexpr int D = decltype(dir)::value;
+        const int k0 = D < 0 ? min(P, t + reach) : max(0, t - reach + 1);
+        const int kend = D < 0 ? t + 1 : t;                       // last reference time of the sweep
+        auto plane = [&](int k) {
+            const float2 *pb = traj + uniform_off(((size_t)ib * w.nplanes + (D < 0 ? max(k, kend) : min(k, kend))) * w.Mt);
+            return NT_LD2(at_bytes(pb, (uint32_t)sl * 8u));
+        };
+        auto active = [&](int k) { return D < 0 ? k <= ks_f : k >= ks_b; };
+        auto in_reach = [&](int k) { return t >= k - reach && t < k + reach; };      // window [0, P], delta = reach
+        // the adjoint through step k: (ay, ax) += gk, then either the pass's own map (last step) or store + (I +- J^T)
+        auto advance = [&](int k, bool act, float2 gk, float jyy, float jyx, float jxy, float jxx) {
+            const int km = D < 0 ? k - 1 : k;
+            // lanes whose chain has not started yet or has left the frame carry a zero adjoint
+            ay += act ? gk.x : 0.0f;
+            ax += act ? gk.y : 0.0f;
+            if (km == t) {
+                const float c = (float)kend - ts;
+                c0y += c * ay;
+                c0x += c * ax;
+            } else {
+                const size_t co = uniform_off(((size_t)ib * P + km) * M);
+                NT_ST(at_bytes(cy + co, (uint32_t)sl * 4u), D < 0 ? ay : -ay);
+                NT_ST(at_bytes(cx + co, (uint32_t)sl * 4u), D < 0 ? ax : -ax);
+                track_mag(mag, ay, ax);
+                const float uy = ay * jyy + ax * jxy, ux = ay * jyx + ax * jxx;
+                const float ny = D < 0 ? ay + uy : ay - uy, nx = D < 0 ? ax + ux : ax - ux;
+                ay = act ? ny : 0.0f;
+                ax = act ? nx : 0.0f;
             }
+        };
+        auto step = [&](int k, float2 cur, float2 nxt) {
+            const bool act = active(k);
+            const int km = D < 0 ? k - 1 : k;
+            float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+            float2 gk = make_float2(0.0f, 0.0f);
+            int y0, x0;
+            Taps tp = taps_core(nxt.x, nxt.y, ach, acw, y0, x0);
+            // bilinear cell of `cur` (utils/iwe.py:85-107): near weights 1 - d with d = p - floor(p) in [0, 1), far weights
+            // 1 - |p - floor(p + 1)|; "strictly inside" = no weight is 0 or 1 (ties take the general path: hat() splits them)
+            const float fy = floorf(cur.x), fx = floorf(cur.y);
+            const float dy = cur.x - fy, dx = cur.y - fx;
+            const float wy1 = 1.0f - fabsf(cur.x - floorf(cur.x + 1.0f)), wx1 = 1.0f - fabsf(cur.y - floorf(cur.y + 1.0f));
+            const int iy0 = (int)fy, ix0 = (int)fx;
+            const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (iy0 >= 0) & (iy0 < H - 1) &
+                                (ix0 >= 0) & (ix0 < W - 1) & (dy > 0.0f) & (dx > 0.0f) & (wy1 > 0.0f) & (wx1 > 0.0f);
+            if (__builtin_amdgcn_ballot_w64(act & !inside) == 0) {
+                const int kmc = min(max(km, 0), P - 1);               // (the jacobian of the last step is not used)
+                const float2 *fm = flows + uniform_off((((size_t)kmc * w.F + i) * w.B + b) * (size_t)(H * W));
+                const uint32_t fo = act ? (uint32_t)(__mul24(y0, W) + x0) : 0u;
+                const f32x4_a8 q0 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(fm, fo * 8u));
+                const f32x4_a8 q1 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(fm, (fo + (uint32_t)W) * 8u));
+                if (in_reach(k)) {
+                    const size_t q = (size_t)(w.img_base[0] + k) * FB + ib;
+                    const float kimg = one_kscale * __builtin_amdgcn_rcpf(stats[q * 2 + 1]);
+                    const float2 *pl = ar + uniform_off(q * 2 * (size_t)(H * W));
+                    const uint32_t po = ((mp != 0.0f) ? 0u : (uint32_t)(H * W)) + (act ? (uint32_t)(__mul24(iy0, W) + ix0) : 0u);
+                    const f32x4_a8 r0 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(pl, po * 8u));
+                    const f32x4_a8 r1 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(pl, (po + (uint32_t)W) * 8u));
+                    const float tau = 1.0f - div_by_const(fabsf((float)k - ts), rdelta);
+                    gk = cell_grad(r0, r1, kimg, tau, m1, 1.0f - dy, wy1, 1.0f - dx, wx1);
+                }
+                Quad2 q;
+                q.v00 = make_float2(q0.x, q0.y); q.v01 = make_float2(q0.z, q0.w);
+                q.v10 = make_float2(q1.x, q1.y); q.v11 = make_float2(q1.z, q1.w);
+                quad_jacobian(q, tp, jyy, jyx, jxy, jxx);
+            } else if (act) {
+                Taps tg = make_taps(nxt.x, nxt.y, H, W);
+                quad_jacobian(load_quad(flow_map(w, flows, max(km, 0), i, b), tg, H * W), tg, jyy, jyx, jxy, jxx);
+                gk = pos_grad(k, cur);
+            }
+            advance(k, act, gk, jyy, jyx, jxy, jxx);
+        };
+        // the positions of a step are loaded one iteration ahead (planes a lane's chain never reached hold stale values:
+        // such lanes are inactive there)
+        float2 cur = plane(k0), nxt = plane(k0 + D);
+        // (wait for the two planes HERE: with loads pending at loop entry the compiler's wait-count merge makes every
+        // iteration wait for the previous iteration's stores before it touches `nxt`)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
+        for (int k = k0;; k += D) {
+            const float2 nn = plane(k + 2 * D);
+            step(k, cur, nxt);
+            if (k == kend) break;
             cur = nxt;
             nxt = nn;
         }
-    }
-    ay = 0.0f;
-    ax = 0.0f;
-    {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = max(0, t - reach + 1) .. t
-        const int k0 = max(0, t - reach + 1);
-        float2 cur = NT_LD2(&tr[(size_t)min(k0, t) * w.Mt]), nxt = NT_LD2(&tr[(size_t)min(k0 + 1, t) * w.Mt]);
-        for (int k = k0; k <= t; ++k) {
-            float2 nn = NT_LD2(&tr[(size_t)min(k + 2, t) * w.Mt]);
-            if (k >= ks_b) {
-                float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
-                float2 gk;
-                if (!step_interior(k, k, cur, nxt, gk, jyy, jyx, jxy, jxx)) {
+    };
+    if (ONE) {
+        sweep(std::integral_constant<int, -1>());
+        ay = 0.0f;
+        ax = 0.0f;
+        sweep(std::integral_constant<int, 1>());
+    } else {
+        {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = min(P, t + reach) .. t+1
+            const int k0 = min(P, t + reach);
+            // the positions of a step are loaded for every lane, one iteration ahead (planes a lane's chain never reached
+            // hold stale values: such lanes are inactive there)
+            float2 cur = NT_LD2(&tr[(size_t)max(k0, t + 1) * w.Mt]), nxt = NT_LD2(&tr[(size_t)max(k0 - 1, t + 1) * w.Mt]);
+            for (int k = k0; k > t; --k) {
+                float2 nn = NT_LD2(&tr[(size_t)max(k - 2, t + 1) * w.Mt]);
+                if (k <= ks_f) {
+                    float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
+                    Taps tp = make_taps(nxt.x, nxt.y, H, W);
+                    quad_jacobian(load_quad(flow_map(w, flows, max(k - 1, 0), i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
+                    float2 gk = pos_grad(k, cur);
+                    ay += gk.x;
+                    ax += gk.y;
+                    if (k - 1 == t) {
+                        float c = (float)(t + 1) - ts;
+                        c0y += c * ay;
+                        c0x += c * ax;
+                    } else {
+                        NT_ST(&coy[(size_t)(k - 1) * M], ay);
+                        NT_ST(&cox[(size_t)(k - 1) * M], ax);
+                        track_mag(mag, ay, ax);
+                        float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
+                        ay = ny;
+                        ax = nx;
+                    }
+                } else if (k - 1 > t) {          // the chain has not started yet: this map gets nothing from the event
+                    NT_ST(&coy[(size_t)(k - 1) * M], 0.0f);
+                    NT_ST(&cox[(size_t)(k - 1) * M], 0.0f);
+                }
+                cur = nxt;
+                nxt = nn;
+            }
+        }
+        ay = 0.0f;
+        ax = 0.0f;
+        {   // backward chain, oldest first: p_k = p_{k+1} - f_k(p_{k+1}), k = max(0, t - reach + 1) .. t
+            const int k0 = max(0, t - reach + 1);
+            float2 cur = NT_LD2(&tr[(size_t)min(k0, t) * w.Mt]), nxt = NT_LD2(&tr[(size_t)min(k0 + 1, t) * w.Mt]);
+            for (int k = k0; k <= t; ++k) {
+                float2 nn = NT_LD2(&tr[(size_t)min(k + 2, t) * w.Mt]);
+                if (k >= ks_b) {
+                    float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
                     Taps tp = make_taps(nxt.x, nxt.y, H, W);
                     quad_jacobian(load_quad(flow_map(w, flows, k, i, b), tp, H * W), tp, jyy, jyx, jxy, jxx);
-                    gk = pos_grad(k, cur);
+                    float2 gk = pos_grad(k, cur);
+                    ay += gk.x;
+                    ax += gk.y;
+                    if (k == t) {
+                        float c = (float)t - ts;
+                        c0y += c * ay;
+                        c0x += c * ax;
+                    } else {
+                        NT_ST(&coy[(size_t)k * M], -ay);
+                        NT_ST(&cox[(size_t)k * M], -ax);
+                        track_mag(mag, ay, ax);
+                        float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
+                        ay = ny;
+                        ax = nx;
+                    }
+                } else if (k < t) {
+                    NT_ST(&coy[(size_t)k * M], 0.0f);
+                    NT_ST(&cox[(size_t)k * M], 0.0f);
                 }
-                ay += gk.x;
-                ax += gk.y;
-                if (k == t) {
-                    float c = (float)t - ts;
-                    c0y += c * ay;
-                    c0x += c * ax;
-                } else {
-                    NT_ST(&coy[(size_t)k * M], -ay);
-                    NT_ST(&cox[(size_t)k * M], -ax);
-                    track_mag(mag, ay, ax);
-                    float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
-                    ay = ny;
-                    ax = nx;
-                }
-            } else if (k < t) {
-                NT_ST(&coy[(size_t)k * M], 0.0f);
-                NT_ST(&cox[(size_t)k * M], 0.0f);
+                cur = nxt;
+                nxt = nn;
             }
-            cur = nxt;
-            nxt = nn;
         }
     }
     NT_ST(&coy[(size_t)t * M], c0y);
@@ -1572,29 +1697,36 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 // polarity-uniform (a splat workgroup skips the other polarity a wavefront at a time).
 // One workgroup per sample.  Order inside a (class, tile) bucket follows LDS-atomic arrival.
 constexpr int kPackThreads = 1024;
-constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x tiles)
+constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x tiles x rows)
 
-__device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, int H, int W, int tile, int tw,
-                                        int ntiles)
+// Sort geometry of a pass: tiles of tw x th pixels in row-major order of the frame and, inside a tile, its `sub` pixel
+// rows (sub == th, or 1 when the frame has too many tiles for the LDS counters).  A tile is 16 pixels wide — one 128-byte
+// line of an interleaved flow map or (A, R) image per pixel row — so events that follow each other in a pass start on
+// the same line: the 4 lanes the texture path handles per cycle of a 16-byte gather then ask for one or two lines
+// instead of three or four (the chain kernels are bound by the L1's line lookups: DESIGN.md section 9b).
+struct SortGeom { int tw, th, ntx, nty, sub; };
+__device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, int H, int W, const SortGeom &g)
 {
     // pos-only (mask exactly (1, 0)), neg-only ((0, 1)), general (both polarities or other values), collate padding
     int cls = (mp != 0.0f) ? (mn != 0.0f ? 2 : 0) : (mn != 0.0f ? 1 : 3);
     if ((mp != 0.0f && mp != 1.0f) || (mn != 0.0f && mn != 1.0f)) cls = 2;     // general mask values: fp64 splat path
-    int ty = min(max((int)y, 0), H - 1) / tile, tx = min(max((int)x, 0), W - 1) / tile;
-    return cls * ntiles + ty * tw + tx;
+    const int yi = min(max((int)y, 0), H - 1), xi = min(max((int)x, 0), W - 1);
+    const int ty = yi / g.th, tx = xi / g.tw;
+    const int row = g.sub > 1 ? yi - ty * g.th : 0;
+    return ((cls * g.nty + ty) * g.ntx + tx) * g.sub + row;
 }
 
 __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__restrict__ ev,
                                                                   const float *__restrict__ pm, int N, float ts_shift,
                                                                   const float *__restrict__ ts_override, int pass_idx,
                                                                   int slot0, int cap,
-                                                                  int H, int W, int tile, float *__restrict__ ts,
+                                                                  int H, int W, SortGeom geo, float *__restrict__ ts,
                                                                   float *__restrict__ y, float *__restrict__ x,
                                                                   float *__restrict__ mp, float *__restrict__ mn,
                                                                   uint8_t *__restrict__ bin, int *__restrict__ cls)
 {
     extern __shared__ int cnt[];          // [nbins] counters, then [kPackThreads] scan scratch
-    const int tw = (W + tile - 1) / tile, th = (H + tile - 1) / tile, ntiles = tw * th, nbins = 4 * ntiles;
+    const int ntiles = geo.ntx * geo.nty * geo.sub, nbins = 4 * ntiles;       // (bins per event class)
     int *part = cnt + nbins;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float4 *evb = reinterpret_cast<const float4 *>(ev) + (size_t)b * N;
@@ -1604,7 +1736,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
     for (int e = tid; e < N; e += kPackThreads) {
         float4 v = evb[e];
         float2 m = pmb[e];
-        atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, tile, tw, ntiles)], 1);
+        atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, geo)], 1);
     }
     __syncthreads();
     // exclusive scan of the counters: per-thread run of consecutive bins + scan of the run totals
@@ -1634,7 +1766,7 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
         float2 m = pmb[e];
         float t = v.x + ts_shift;
         ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
-        int pos = atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, tile, tw, ntiles)], 1);
+        int pos = atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, geo)], 1);
         size_t o = (size_t)b * cap + slot0 + pos;
         ts[o] = ts_override ? ts_override[0] : t;
         y[o] = v.y;
@@ -1855,15 +1987,24 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, co
         pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
         return tef::fail("tef_pack_events: bad sizes (slot0 must be a multiple of 64, cap must hold N rounded up to 64)"), TEF_ERR_INVALID;
     if (N == 0) return 0;
-    int tile = 8;
-    while (4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile) > kMaxSortBins) tile *= 2;
-    int nbins = 4 * ((H + tile - 1) / tile) * ((W + tile - 1) / tile);
+    SortGeom geo;
+    geo.tw = 16;
+    geo.th = 8;
+    for (;;) {
+        geo.ntx = (W + geo.tw - 1) / geo.tw;
+        geo.nty = (H + geo.th - 1) / geo.th;
+        const int tiles4 = 4 * geo.ntx * geo.nty;
+        geo.sub = (tiles4 * geo.th <= kMaxSortBins) ? geo.th : 1;
+        if (tiles4 * geo.sub <= kMaxSortBins) break;
+        if (geo.tw <= geo.th) geo.tw *= 2; else geo.th *= 2;
+    }
+    int nbins = 4 * geo.ntx * geo.nty * geo.sub;
     size_t lds = (size_t)(nbins + kPackThreads) * sizeof(int);
     hipStream_t st = (hipStream_t)stream;
     {
         tef::ProfScope ps(tef::PROF_PACK, st);
         hipLaunchKernelGGL(pack_events_kernel, dim3(B), dim3(kPackThreads), lds, st, ev, pm, N, ts_shift, ts_override,
-                           pass_idx, slot0, cap, H, W, tile, ts, y, x, mp, mn, bin, cls);
+                           pass_idx, slot0, cap, H, W, geo, ts, y, x, mp, mn, bin, cls);
     }
     return tef::check_launch("pack_events_kernel");
 }
