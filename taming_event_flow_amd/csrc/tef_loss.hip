@@ -1697,6 +1697,8 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 // polarity-uniform (a splat workgroup skips the other polarity a wavefront at a time).
 // One workgroup per sample.  Order inside a (class, tile) bucket follows LDS-atomic arrival.
 constexpr int kPackThreads = 1024;
+constexpr int kPackBatch = 4;           // events per thread in flight
+constexpr int kPackSlices = 8;          // workgroups per sample
 constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x tiles x rows)
 
 // Sort geometry of a pass: tiles of tw x th pixels in row-major order of the frame and, inside a tile, its `sub` pixel
@@ -1716,6 +1718,12 @@ __device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, in
     return ((cls * g.nty + ty) * g.ntx + tx) * g.sub + row;
 }
 
+// kPackSlices workgroups per sample.  Every one of them counts ALL events of the sample into the bins (the list is a
+// few hundred KB, read from L2) and, in a second set of counters, the events of the slices before its own; the scan of
+// the first gives a bin's first slot, the second the part of the bin that belongs to earlier slices.  So no workgroup
+// needs another's result: one launch, no scratch memory, and the scattered stores — about one cache-line access per
+// stored word, which is what paces this kernel: 42 us per pass with one workgroup per sample — are spread over eight
+// compute units per sample.
 __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__restrict__ ev,
                                                                   const float *__restrict__ pm, int N, float ts_shift,
                                                                   const float *__restrict__ ts_override, int pass_idx,
@@ -1725,18 +1733,36 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
                                                                   float *__restrict__ mp, float *__restrict__ mn,
                                                                   uint8_t *__restrict__ bin, int *__restrict__ cls)
 {
-    extern __shared__ int cnt[];          // [nbins] counters, then [kPackThreads] scan scratch
+    extern __shared__ int cnt[];          // [nbins] all events, [nbins] events of earlier slices, [kPackThreads] scan scratch
     const int ntiles = geo.ntx * geo.nty * geo.sub, nbins = 4 * ntiles;       // (bins per event class)
-    int *part = cnt + nbins;
+    int *before = cnt + nbins, *part = before + nbins;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const float4 *evb = reinterpret_cast<const float4 *>(ev) + (size_t)b * N;
+    const int per_slice = (N + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int e_lo = min((int)blockIdx.y * per_slice, N), e_hi = min(e_lo + per_slice, N);
+    const float *evf = ev + (size_t)b * N * 4;
     const float2 *pmb = reinterpret_cast<const float2 *>(pm) + (size_t)b * N;
-    for (int k = tid; k < nbins; k += kPackThreads) cnt[k] = 0;
+    for (int k = tid; k < 2 * nbins; k += kPackThreads) cnt[k] = 0;
     __syncthreads();
-    for (int e = tid; e < N; e += kPackThreads) {
-        float4 v = evb[e];
-        float2 m = pmb[e];
-        atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, geo)], 1);
+    // (the sweeps take kPackBatch events per thread at a time, all loads issued before the first use; this one reads the
+    // coordinates only: the time stamps are being shifted in place by the slices' owners)
+    for (int e0 = tid; e0 < N; e0 += kPackThreads * kPackBatch) {
+        float vy[kPackBatch], vx[kPackBatch];
+        float2 m[kPackBatch];
+#pragma unroll
+        for (int j = 0; j < kPackBatch; ++j) {
+            const int e = min(e0 + j * kPackThreads, N - 1);
+            vy[j] = evf[(size_t)e * 4 + 1];
+            vx[j] = evf[(size_t)e * 4 + 2];
+            m[j] = pmb[e];
+        }
+#pragma unroll
+        for (int j = 0; j < kPackBatch; ++j) {
+            const int e = e0 + j * kPackThreads;
+            if (e >= N) break;
+            const int key = sort_key(vy[j], vx[j], m[j].x, m[j].y, H, W, geo);
+            atomicAdd(&cnt[key], 1);
+            if (e < e_lo) atomicAdd(&before[key], 1);
+        }
     }
     __syncthreads();
     // exclusive scan of the counters: per-thread run of consecutive bins + scan of the run totals
@@ -1754,33 +1780,47 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
     int base = part[tid] - run;
     for (int k = lo; k < hi; ++k) {
         int c = cnt[k];
-        cnt[k] = base;
+        cnt[k] = base + before[k];          // first slot of this slice's share of the bin
         base += c;
-    }
+        if (blockIdx.y == 0 && k + 1 < nbins && (k + 1) % ntiles == 0)
+            cls[((size_t)b * TEF_MAX_PASSES + pass_idx) * 3 + (k + 1) / ntiles - 1] = base;   // run ends of the three
+    }                                                                                        // event classes
     __syncthreads();
-    if (tid < 3)      // run ends of the three event classes of this pass (read by the splat workgroups)
-        cls[((size_t)b * TEF_MAX_PASSES + pass_idx) * 3 + tid] = cnt[(tid + 1) * ntiles];
-    __syncthreads();
-    for (int e = tid; e < N; e += kPackThreads) {
-        float4 v = evb[e];
-        float2 m = pmb[e];
-        float t = v.x + ts_shift;
-        ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
-        int pos = atomicAdd(&cnt[sort_key(v.y, v.z, m.x, m.y, H, W, geo)], 1);
-        size_t o = (size_t)b * cap + slot0 + pos;
-        ts[o] = ts_override ? ts_override[0] : t;
-        y[o] = v.y;
-        x[o] = v.z;
-        mp[o] = m.x;
-        mn[o] = m.y;
-        if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
+    const bool ts_fixed = ts_override != nullptr;
+    const float ts_value = ts_fixed ? ts_override[0] : 0.0f;
+    const float4 *evb = reinterpret_cast<const float4 *>(evf);
+    for (int e0 = e_lo + tid; e0 < e_hi; e0 += kPackThreads * kPackBatch) {
+        float4 v[kPackBatch];
+        float2 m[kPackBatch];
+#pragma unroll
+        for (int j = 0; j < kPackBatch; ++j) {
+            const int e = min(e0 + j * kPackThreads, e_hi - 1);
+            v[j] = evb[e];
+            m[j] = pmb[e];
+        }
+#pragma unroll
+        for (int j = 0; j < kPackBatch; ++j) {
+            const int e = e0 + j * kPackThreads;
+            if (e >= e_hi) break;
+            const float t = v[j].x + ts_shift;
+            ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
+            const int pos = atomicAdd(&cnt[sort_key(v[j].y, v[j].z, m[j].x, m[j].y, H, W, geo)], 1);
+            const size_t o = (size_t)b * cap + slot0 + pos;
+            ts[o] = ts_fixed ? ts_value : t;
+            y[o] = v[j].y;
+            x[o] = v[j].z;
+            mp[o] = m[j].x;
+            mn[o] = m[j].y;
+            if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
+        }
     }
     // alignment slots up to the next multiple of 64 (a wavefront of the chain kernels belongs to one pass): empty events
-    for (int e = N + tid; e < ((N + 63) & ~63); e += kPackThreads) {
-        size_t o = (size_t)b * cap + slot0 + e;
-        ts[o] = y[o] = x[o] = mp[o] = mn[o] = 0.0f;
-        if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
-    }
+    if (blockIdx.y == 0)
+        for (int e = N + tid; e < ((N + 63) & ~63); e += kPackThreads) {
+            size_t o = (size_t)b * cap + slot0 + e;
+            ts[o] = y[o] = x[o] = mp[o] = mn[o] = 0.0f;
+            if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
+        }
 }
 
 // flow map of one head of one pass: [B,2,H,W] (ch0 = x, ch1 = y; any batch/channel strides, dense rows)
@@ -1964,6 +2004,10 @@ bool ensure_attrs()
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplat2LdsBudget);
     static const hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
+    static const hipError_t e3 = hipFuncSetAttribute((const void *)pack_events_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)((2 * kMaxSortBins + kPackThreads) * sizeof(int)));
+    if (e3 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e3);
     if (e1 != hipSuccess || e2 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e1 != hipSuccess ? e1 : e2);
     return true;
 }
@@ -1999,11 +2043,13 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, co
         if (geo.tw <= geo.th) geo.tw *= 2; else geo.th *= 2;
     }
     int nbins = 4 * geo.ntx * geo.nty * geo.sub;
-    size_t lds = (size_t)(nbins + kPackThreads) * sizeof(int);
+    size_t lds = (size_t)(2 * nbins + kPackThreads) * sizeof(int);
+    if (!ensure_attrs()) return TEF_ERR_LAUNCH;
+    const int slices = N >= 4 * kPackThreads ? kPackSlices : 1;
     hipStream_t st = (hipStream_t)stream;
     {
         tef::ProfScope ps(tef::PROF_PACK, st);
-        hipLaunchKernelGGL(pack_events_kernel, dim3(B), dim3(kPackThreads), lds, st, ev, pm, N, ts_shift, ts_override,
+        hipLaunchKernelGGL(pack_events_kernel, dim3(B, slices), dim3(kPackThreads), lds, st, ev, pm, N, ts_shift, ts_override,
                            pass_idx, slot0, cap, H, W, geo, ts, y, x, mp, mn, bin, cls);
     }
     return tef::check_launch("pack_events_kernel");
