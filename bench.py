@@ -49,14 +49,18 @@ def parse():
     ap.add_argument("--presort", default="none", choices=["none", "y", "pol_y", "pol_tile8", "pol_tile16", "pol_yx", "pol_y4"],
                     help="experiment: pre-sort the synthetic events of each pass on the host")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--graph-steps", type=int, default=4,
+                    help="loss mode: consecutive steps captured into ONE hipGraph (a graph launch costs ~40 us of idle GPU, "
+                         "which a training window pays once for its whole pass sequence); 1 = a graph per step")
     ap.add_argument("--step-graph", default="auto", choices=["auto", "on", "off"],
                     help="loss mode: replay a captured hipGraph of the step (for hosts too slow to enqueue 0.8 ms steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train-extra", action="store_true",
                     help="loss mode at 1 GPU: skip the short training-window measurement appended as `extra`")
     ap.add_argument("--cpu-batch", type=int, default=0, help="samples in the CPU-baseline sample (0 = auto)")
-    ap.add_argument("--event-every", type=int, default=24,
-                    help="per-kernel HIP events are recorded on every K-th timed step (each pair costs a few us of stream time)")
+    ap.add_argument("--event-every", type=int, default=50,
+                    help="per-kernel HIP events are recorded on every K-th timed step: that step is launched eagerly (~1.1 ms of host "
+                         "time against ~0.7 of kernels), so it costs the timed region ~0.4 ms")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample: repeat the window this long")
     return ap.parse_args()
 
@@ -288,31 +292,66 @@ def main():
             use = bool(flag.item())
         if not use:
             graphs = []
+    # groups of `graph_steps` consecutive steps as one graph each (same launches, same buffers, in the same order)
+    G = max(1, a.graph_steps)
+    groups = []
+    if graphs and G > 1:
+        try:
+            for k in range(len(staged)):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    for j in range(G):
+                        out = step(k + j)
+                groups.append((gph, out))
+            torch.cuda.synchronize()
+        except Exception as e:                                    # noqa: BLE001
+            print(f"[bench] step-group graph capture failed ({e!r}); one graph per step", file=sys.stderr)
+            groups = []
+        if probe is not None and groups:
+            probe["graph_x%d_ms" % G] = round(probe_ms(lambda k: groups[k % len(groups)][0].replay(), n=8) / G, 4)
     # per-kernel HIP events (start / stop of each launch, on the launch stream) on every `event_every`-th timed step
     lib.tef_profile_enable(0 if a.no_kernel_events else 1)
     if not a.no_kernel_events:
         lib.tef_profile_pause(1)
     # device time of every step from a HIP event pair on the stream the kernels are launched on (torch's current stream):
     # SURVEY.md section 8d asks for the median over >= 20 steps beside the wall-clock mean that `value` is made of
-    step_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    def is_profiled(k):
+        return not a.no_kernel_events and k % max(1, a.event_every) == 0
+
+    # the timed region as a list of units: (first step, number of steps, how it is launched)
+    units, k = [], 0
+    while k < a.steps:
+        if is_profiled(k) or not graphs:
+            units.append((k, 1, "eager"))
+            k += 1
+        elif groups and k + G <= a.steps and not any(is_profiled(j) for j in range(k, k + G)):
+            units.append((k, G, "group"))
+            k += G
+        else:
+            units.append((k, 1, "graph"))
+            k += 1
+    unit_events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in units]
     barrier()
     t0 = time.perf_counter()
-    for k in range(a.steps):
-        profiled = not a.no_kernel_events and k % max(1, a.event_every) == 0
+    for u, (k, n, how) in enumerate(units):
         if not a.no_kernel_events:
-            lib.tef_profile_pause(0 if profiled else 1)
-        step_events[k][0].record()
-        if graphs and not profiled:
+            lib.tef_profile_pause(0 if how == "eager" and is_profiled(k) else 1)
+        unit_events[u][0].record()
+        if how == "group":
+            gph, out = groups[k % len(groups)]
+            gph.replay()
+            last, last_grads = out
+        elif how == "graph":
             gph, out = graphs[k % len(graphs)]
             gph.replay()
             last, last_grads = out
         else:
             last, last_grads = step(k)
-        step_events[k][1].record()
+        unit_events[u][1].record()
     t_enqueue = time.perf_counter() - t0      # host time to enqueue all steps (diagnostic: host- vs device-bound)
     barrier()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in step_events)
+    step_ms = sorted(ms for (k, n, how), (e0, e1) in zip(units, unit_events) for ms in [e0.elapsed_time(e1) / n] * n)
     step_ms_median = step_ms[len(step_ms) // 2]
     lib.tef_profile_collect()
     kern = {}
@@ -360,9 +399,10 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "global_batch": B * world, "events_per_window_per_gpu": events_per_step,
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
-                       "launch": ("hipGraph replay of the step; every %d-th step eager with per-kernel HIP events"
-                                  % max(1, a.event_every)) if graphs and not a.no_kernel_events
-                       else ("hipGraph replay of the step" if graphs else "eager")},
+                       "launch": (("hipGraph replay, %d consecutive steps per graph" % G if groups else
+                                   "hipGraph replay of the step") +
+                                  ("; every %d-th step eager with per-kernel HIP events" % max(1, a.event_every)
+                                   if not a.no_kernel_events else "")) if graphs else "eager"},
             "loss": round(loss_val, 6),
             "ms_per_step_hip_event_median": round(step_ms_median, 4),
             "ms_update_per_window": round(1e3 * t_update, 3),
