@@ -804,8 +804,8 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
         const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
         const uint32_t *mt = meta + (size_t)ib * w.Mt;
         if (fixed) {
-            // Wave-centric sweep.  The rows (16 slots) of all runs form one flattened sequence; a wavefront takes groups of
-            // 128 consecutive rows: every lane reads two row intervals (coalesced 512-byte loads), the rows that can touch
+            // Wave-centric sweep.  The rows (16 slots) of all runs form one flattened sequence; a wavefront takes 128 rows at
+            // a time (eight chunks of 16, see load_range): every lane reads two row intervals, the rows that can touch
             // the band are compacted into the wavefront's list, and the wavefront then works through the list in batches of
             // 16 rows (four quads of 4 x 16 lanes) with the next batch's events already in flight.  Iterations are dense in
             // work whatever the fraction of rows that hit (a workgroup-wide chunk loop spent a memory round trip per mostly
@@ -817,12 +817,17 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
             const int total_rows = run_cum[nruns];
             int2 *list = hit_list + wid * 128;
             int run_hint = 0;                        // run of the first row of the group being located (wave-uniform, monotone)
-            auto load_range = [&](int grp64, int &r_out, int &row_out) -> float2 {
-                const int fr = grp64 * 64 + lane;
+            // Rows are dealt to the wavefronts in chunks of 16 (one 128-byte line of intervals), chunk c to wavefront
+            // c % nwaves: hits cluster over hundreds of rows (the passes are sorted by tile), so with 128 consecutive rows
+            // per wavefront and ~3 such groups per item the wavefronts waited 30 % of an item for the slowest of them.
+            // m-th load of a wavefront: its chunks 4m .. 4m + 3, 16 lanes each.
+            auto load_range = [&](int m, int &r_out, int &row_out) -> float2 {
+                const int first = (m * 4 * nwaves + wid) * 16;                      // (wave-uniform)
+                const int fr = first + (lane >> 4) * (nwaves * 16) + (lane & 15);
                 float2 rg = make_float2(__uint_as_float(0xffffffffu), 0.0f);
                 r_out = row_out = 0;
-                if (grp64 * 64 < total_rows) {
-                    while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= grp64 * 64) ++run_hint;
+                if (first < total_rows) {
+                    while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= first) ++run_hint;
                 }
                 if (fr < total_rows) {
                     int r = run_hint;                // the lanes' rows follow the group's first: a step or two at most
@@ -860,9 +865,9 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
             constexpr int kQ = 4;
             int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
             float2 rg_cur[2], rg_nxt[2];
-            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(2 * wid + hh, r_cur[hh], row_cur[hh]);
-            for (int grp = wid; grp * 128 < total_rows; grp += nwaves) {
-                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(2 * (grp + nwaves) + hh, r_nxt[hh], row_nxt[hh]);
+            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(hh, r_cur[hh], row_cur[hh]);
+            for (int m = 0; (m * 4 * nwaves + wid) * 16 < total_rows; m += 2) {
+                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(m + 2 + hh, r_nxt[hh], row_nxt[hh]);
                 int h = 0;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
@@ -1596,12 +1601,14 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
             const int total_rows = run_cum[nruns];
             int2 *list = hit_list + wid * 128;
             int run_hint = 0;
-            auto load_range = [&](int grp64, int &r_out, int &row_out) -> float2 {
-                const int fr = grp64 * 64 + lane;
+            // (rows dealt to the wavefronts in chunks of 16, chunk c to wavefront c % nwaves, as in K2)
+            auto load_range = [&](int m, int &r_out, int &row_out) -> float2 {
+                const int first = (m * 4 * nwaves + wid) * 16;                      // (wave-uniform)
+                const int fr = first + (lane >> 4) * (nwaves * 16) + (lane & 15);
                 float2 rg = make_float2(__uint_as_float(0xffffffffu), 0.0f);
                 r_out = row_out = 0;
-                if (grp64 * 64 < total_rows) {
-                    while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= grp64 * 64) ++run_hint;
+                if (first < total_rows) {
+                    while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= first) ++run_hint;
                 }
                 if (fr < total_rows) {
                     int r = run_hint;
@@ -1630,9 +1637,9 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
             constexpr int kQ = 4;
             int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
             float2 rg_cur[2], rg_nxt[2];
-            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(2 * wid + hh, r_cur[hh], row_cur[hh]);
-            for (int grp = wid; grp * 128 < total_rows; grp += nwaves) {
-                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(2 * (grp + nwaves) + hh, r_nxt[hh], row_nxt[hh]);
+            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(hh, r_cur[hh], row_cur[hh]);
+            for (int m = 0; (m * 4 * nwaves + wid) * 16 < total_rows; m += 2) {
+                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(m + 2 + hh, r_nxt[hh], row_nxt[hh]);
                 int h = 0;
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
