@@ -89,8 +89,8 @@ typedef struct tef_loss_cfg {
  * not NULL the stored timestamp is that value instead (round_ts, :461-463: the caller computes min + 0.5 of the shifted
  * list on the device, no host round trip).  ev [B,N,4] (ts,y,x,p), pm [B,N,2].  slot0 must be a multiple of 64 and
  * cap >= slot0 + N rounded up to 64: the next pass starts there.
- * The events of the pass are stored sorted by (polarity, 8x8 pixel tile of the H x W frame): the loss is a sum over
- * events, so the order inside a pass is free, and coherent wavefronts halve the cost of the lookups. */
+ * The events of the pass are stored sorted by (polarity class, 16x8 pixel tile of the H x W frame, pixel row): the loss
+ * is a sum over events, so the order inside a pass is free, and coherent wavefronts halve the cost of the lookups. */
 int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx,
                     int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
                     uint8_t *bin, int *cls, void *stream);

@@ -1,0 +1,67 @@
+"""tef_pack_events on its own (the AoS -> SoA packing + sort of one pass; reference bookkeeping loss/flow.py:443-476):
+the stored pass is a permutation of the input grouped pos-only | neg-only | general | padding, the class run ends are
+reported, the caller's time stamps are shifted in place (:457-458), the pass is padded to a multiple of 64 slots with
+empty events — for a list short enough for one workgroup per sample and for one that takes the multi-workgroup path."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+@pytest.mark.parametrize("N", [700, 9001])
+def test_pack_is_a_grouped_sorted_permutation(N):
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import _lib
+
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    B, H, W, P_IDX, SLOT0, SHIFT = 3, 128, 128, 2, 128, 2.0
+    rng = np.random.default_rng(N)
+    ev = np.stack([np.sort(rng.random((B, N)), axis=1), rng.integers(0, H, (B, N)), rng.integers(0, W, (B, N)),
+                   rng.choice([-1.0, 1.0], (B, N))], axis=2).astype(np.float32)
+    pm = np.stack([ev[..., 3] > 0, ev[..., 3] < 0], axis=2).astype(np.float32)
+    pm[:, ::97] = 1.0                      # some events carry both polarities (general class)
+    pm[:, 5::211] = 0.0                    # collate padding
+    cap = SLOT0 + ((N + 63) // 64) * 64 + 64
+    ev_d, pm_d = torch.tensor(ev, device=dev), torch.tensor(pm, device=dev)
+    out = {k: torch.full((B, cap), -7.0, device=dev) for k in ("ts", "y", "x", "mp", "mn")}
+    bins = torch.full((cap,), 255, dtype=torch.uint8, device=dev)
+    cls = torch.zeros((B, 64, 3), dtype=torch.int32, device=dev)
+    rc = lib.tef_pack_events(_ptr(ev_d), _ptr(pm_d), B, N, SHIFT, None, P_IDX, SLOT0, cap, H, W, _ptr(out["ts"]),
+                             _ptr(out["y"]), _ptr(out["x"]), _ptr(out["mp"]), _ptr(out["mn"]), _ptr(bins), _ptr(cls),
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.tef_last_error()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(ev_d.cpu().numpy()[..., 0], ev[..., 0] + np.float32(SHIFT))      # in place, fp32 add
+    np.testing.assert_array_equal(ev_d.cpu().numpy()[..., 1:], ev[..., 1:])
+    o = {k: v.cpu().numpy() for k, v in out.items()}
+    npad = ((N + 63) // 64) * 64
+    assert (bins.cpu().numpy()[SLOT0:SLOT0 + npad] == P_IDX).all() and (bins.cpu().numpy()[:SLOT0] == 255).all()
+    for b in range(B):
+        mp, mn = pm[b, :, 0], pm[b, :, 1]
+        klass = np.where(mp != 0, np.where(mn != 0, 2, 0), np.where(mn != 0, 1, 3))
+        ends = np.cumsum([(klass == c).sum() for c in range(3)])
+        np.testing.assert_array_equal(cls.cpu().numpy()[b, P_IDX], ends)
+        got = np.stack([o[k][b, SLOT0:SLOT0 + N] for k in ("ts", "y", "x", "mp", "mn")], axis=1)
+        want = np.stack([ev[b, :, 0] + np.float32(SHIFT), ev[b, :, 1], ev[b, :, 2], mp, mn], axis=1)
+        # same multiset of records ...
+        np.testing.assert_array_equal(got[np.lexsort(got.T[::-1])], want[np.lexsort(want.T[::-1])])
+        # ... grouped by class, and inside a class ordered by (tile row, tile column, pixel row) of 16 x 8 pixel tiles
+        gk = np.where(got[:, 3] != 0, np.where(got[:, 4] != 0, 2, 0), np.where(got[:, 4] != 0, 1, 3))
+        assert (np.diff(gk) >= 0).all()
+        key = ((got[:, 1].astype(int) // 8) * (W // 16) + got[:, 2].astype(int) // 16) * 8 + got[:, 1].astype(int) % 8
+        for c in range(4):
+            assert (np.diff(key[gk == c]) >= 0).all(), (b, c)
+        for k in ("ts", "y", "x", "mp", "mn"):      # alignment slots: empty events; nothing written beyond them
+            assert (o[k][b, SLOT0 + N:SLOT0 + npad] == 0).all() and (o[k][b, SLOT0 + npad:] == -7).all()
+            assert (o[k][b, :SLOT0] == -7).all()
