@@ -46,7 +46,7 @@ constexpr float kEps = 1e-9f;
 constexpr int kSplatThreads = 1024;
 constexpr size_t kLdsBudget = 144 * 1024;   // per-workgroup accumulator budget (160 KiB LDS per CU on gfx950)
 constexpr size_t kSplatLdsBudget = 138 * 1024;   // K2 keeps 20 KiB of run tables and per-wavefront row lists beside its planes
-constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the 8x8-pixel
+constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the few-row
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
 constexpr int kMaxSegs = 4 * TEF_MAX_PASSES;
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
@@ -346,7 +346,8 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t bits, int kb, int kf, flo
 // multiples of 64 slots, so a wavefront, and with it a row, belongs to one pass).  For every trajectory plane K1 also records, per row, the
 // interval [min y, max y] of the row's events that are still inside the frame there.  The scatter kernels split an
 // image into row bands: a band workgroup looks at a row's interval (8 bytes per 16 events) and loads the events only
-// if it can touch the band — events are sorted by 8x8 tile, so a row spans about one tile and its interval is tight.
+// if it can touch the band — events are sorted by (16x8 tile, pixel row), so a row of slots spans a pixel row or two and
+// its interval is tight.
 // An event that contributes at a plane is inside the frame there, hence inside its row's interval: nothing that counts
 // is ever skipped, and an interval that was never written (all lanes of a wavefront dead) can only cause a useless look.
 // ---------------------------------------------------------------------------------------------
@@ -1698,11 +1699,11 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 }
 
 // K0: AoS -> SoA packing of one pass (Iterative.update / Linear.update bookkeeping, loss/flow.py:457-473),
-// with a counting sort of the pass's events by (polarity class, 8x8 pixel tile).  The loss is a sum over
+// with a counting sort of the pass's events by (polarity class, 16x8 pixel tile, pixel row).  The loss is a sum over
 // events, so the order inside a pass is free; sorting makes the 64 events of a wavefront spatially
 // coherent (their bilinear flow / IWE lookups share cache lines: 2x on the gather-bound kernels) and
 // polarity-uniform (a splat workgroup skips the other polarity a wavefront at a time).
-// One workgroup per sample.  Order inside a (class, tile) bucket follows LDS-atomic arrival.
+// Order inside a (class, tile, row) bucket follows LDS-atomic arrival.
 constexpr int kPackThreads = 1024;
 constexpr int kPackBatch = 4;           // events per thread in flight
 constexpr int kPackSlices = 8;          // workgroups per sample
