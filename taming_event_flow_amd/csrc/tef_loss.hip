@@ -1173,6 +1173,11 @@ __device__ __forceinline__ float2 NT_LD2(const float2 *p)
     return make_float2(v.x, v.y);
 }
 __device__ __forceinline__ void NT_ST(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void NT_ST2(float2 *p, float a, float b)
+{
+    f32x2_v v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x2_v *>(p));
+}
 
 // ONE: a single temporal scale (scales_loss = 1, the headline configuration).  The kernel is VALU-bound (~450 vector
 // instructions per chain step, 2.9e7 steps per BASELINE window): the per-step scale loop with its integer division
@@ -1184,7 +1189,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                                                              const float2 *__restrict__ ar,
                                                              const float *__restrict__ stats,
                                                              const float *__restrict__ grad_out,
-                                                             float *__restrict__ cy, float *__restrict__ cx,
+                                                             float2 *__restrict__ cyx,
                                                              uint32_t *__restrict__ cmax, int chunks)
 {
     int ib, chunk;
@@ -1195,7 +1200,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     uint32_t mag = 0u;
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, P = w.P, M = w.M;
-    float *coy = cy + (size_t)ib * P * M + sl, *cox = cx + (size_t)ib * P * M + sl;
+    float2 *co = cyx + (size_t)ib * P * M + sl;
     uint32_t mv = meta[(size_t)ib * w.Mt + sl];
     uint32_t bits = mv & 0xffu;
     // Passes start at multiples of 64 slots, so a wavefront belongs to ONE pass: t, and with it the reference time k of
@@ -1272,8 +1277,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                 c0x += c * ax;
             } else {
                 const size_t co = uniform_off(((size_t)ib * P + km) * M);
-                NT_ST(at_bytes(cy + co, (uint32_t)sl * 4u), D < 0 ? ay : -ay);
-                NT_ST(at_bytes(cx + co, (uint32_t)sl * 4u), D < 0 ? ax : -ax);
+                NT_ST2(at_bytes(cyx + co, (uint32_t)sl * 8u), D < 0 ? ay : -ay, D < 0 ? ax : -ax);
                 track_mag(mag, ay, ax);
                 const float uy = ay * jyy + ax * jxy, ux = ay * jyx + ax * jxx;
                 const float ny = D < 0 ? ay + uy : ay - uy, nx = D < 0 ? ax + ux : ax - ux;
@@ -1362,16 +1366,14 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                         c0y += c * ay;
                         c0x += c * ax;
                     } else {
-                        NT_ST(&coy[(size_t)(k - 1) * M], ay);
-                        NT_ST(&cox[(size_t)(k - 1) * M], ax);
+                        NT_ST2(&co[(size_t)(k - 1) * M], ay, ax);
                         track_mag(mag, ay, ax);
                         float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
                         ay = ny;
                         ax = nx;
                     }
                 } else if (k - 1 > t) {          // the chain has not started yet: this map gets nothing from the event
-                    NT_ST(&coy[(size_t)(k - 1) * M], 0.0f);
-                    NT_ST(&cox[(size_t)(k - 1) * M], 0.0f);
+                    NT_ST2(&co[(size_t)(k - 1) * M], 0.0f, 0.0f);
                 }
                 cur = nxt;
                 nxt = nn;
@@ -1396,24 +1398,21 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                         c0y += c * ay;
                         c0x += c * ax;
                     } else {
-                        NT_ST(&coy[(size_t)k * M], -ay);
-                        NT_ST(&cox[(size_t)k * M], -ax);
+                        NT_ST2(&co[(size_t)k * M], -ay, -ax);
                         track_mag(mag, ay, ax);
                         float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
                         ay = ny;
                         ax = nx;
                     }
                 } else if (k < t) {
-                    NT_ST(&coy[(size_t)k * M], 0.0f);
-                    NT_ST(&cox[(size_t)k * M], 0.0f);
+                    NT_ST2(&co[(size_t)k * M], 0.0f, 0.0f);
                 }
                 cur = nxt;
                 nxt = nn;
             }
         }
     }
-    NT_ST(&coy[(size_t)t * M], c0y);
-    NT_ST(&cox[(size_t)t * M], c0x);
+    NT_ST2(&co[(size_t)t * M], c0y, c0x);
     track_mag(mag, c0y, c0x);
     commit_mag(mag, cmax + (size_t)ib * (M >> 6) + (sl >> 6));       // (here: the per-wavefront slots)
 }
@@ -1423,8 +1422,8 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
                                                          const uint32_t *__restrict__ meta,
                                                          const float2 *__restrict__ ar,
                                                          const float *__restrict__ stats,
-                                                         const float *__restrict__ grad_out, float *__restrict__ cy,
-                                                         float *__restrict__ cx, uint32_t *__restrict__ cmax, int chunks)
+                                                         const float *__restrict__ grad_out, float2 *__restrict__ cyx,
+                                                         uint32_t *__restrict__ cmax, int chunks)
 {
     int ib, chunk;
     xcd_split(blockIdx.x, chunks, ib, chunk);
@@ -1455,8 +1454,7 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
             }
         }
     }
-    cy[(size_t)ib * w.M + sl] = gy;
-    cx[(size_t)ib * w.M + sl] = gx;
+    cyx[(size_t)ib * w.M + sl] = make_float2(gy, gx);
     uint32_t mag = 0u;
     track_mag(mag, gy, gx);
     commit_mag(mag, cmax + (size_t)ib * (w.M >> 6) + (sl >> 6));
@@ -1535,8 +1533,7 @@ __device__ __forceinline__ void dflow_one(float2 p, float cvy, float cvx, int H,
 // for pass k) and loads the row only if it can touch the band.
 __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
                                                                     const float2 *__restrict__ yr,
-                                                                    const float *__restrict__ cy,
-                                                                    const float *__restrict__ cx,
+                                                                    const float2 *__restrict__ cyx,
                                                                     const uint32_t *__restrict__ cmax,
                                                                     float *__restrict__ dflows, int rows_per_band,
                                                                     int nbands, int *__restrict__ queue)
@@ -1591,7 +1588,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
         const int nev = w.off[t_hi] - w.off[t_lo];
         const bool fixed = mbits < 0x7f800000u && nev < kFxMaxEvents;
         const int e = (int)(mbits >> 23) - 127 + 1;     // 2^e > max |c| (a denormal or zero maximum: any small exponent does)
-        const float *coy = cy + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M), *cox = cx + (coy - cy);
+        const float2 *co = cyx + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
         const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
         const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
         // lookup rows are floor(unnormalize(y)) and the next one; unnormalize(y) is y up to a few ulps: a hundredth of a
@@ -1629,8 +1626,9 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
                 if (en_i < h) {
                     const int2 en = list[en_i];              // (first slot of the row, source plane)
                     const int u = en.x + (lane & 15);
-                    qd.cvy = coy[u];
-                    qd.cvx = cox[u];
+                    const float2 cv = co[u];
+                    qd.cvy = cv.x;
+                    qd.cvx = cv.y;
                     qd.p = en.y == w.nplanes ? make_float2(ey[u], ex[u]) : tr[(size_t)en.y * w.Mt + u];
                 }
                 return qd;
@@ -1674,7 +1672,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
             for (int t = t_lo; t < t_hi; ++t) {
                 const int src = t < k ? k : (t > k ? k + 1 : w.nplanes);
                 for (int sl = w.off[t] + threadIdx.x; sl < w.off[t + 1]; sl += blockDim.x) {
-                    const float cvy = coy[sl], cvx = cox[sl];
+                    const float cvy = co[sl].x, cvx = co[sl].y;
                     if (cvy == 0.0f && cvx == 0.0f) continue;
                     const float2 p = src == w.nplanes ? make_float2(ey[sl], ex[sl]) : tr[(size_t)src * w.Mt + sl];
                     dflow_one<false>(p, cvy, cvx, H, W, WP, 0, img_y, img_x, r0, nrows);
@@ -1869,7 +1867,7 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cy, cx, total;
+    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cyx, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1973,8 +1971,7 @@ Layout make_layout(const Win &w)
     L.queue = o;  o += align_up((kQueueInts + FB) * sizeof(int));      // + one magnitude word per (head, sample) for K6 -> K7
     L.cmax = L.queue + kQueueInts * sizeof(int);
     L.wmax = o;   o += align_up(FB * (size_t)(w.M / 64 + 1) * sizeof(uint32_t));
-    L.cy = o;     o += align_up(nc * sizeof(float));
-    L.cx = o;     o += align_up(nc * sizeof(float));
+    L.cyx = o;    o += align_up(nc * sizeof(float2));
     L.total = o;
     return L;
 }
@@ -2168,7 +2165,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     uint32_t *meta = (uint32_t *)(ws + L.meta);
     float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
-    float *cy = (float *)(ws + L.cy), *cx = (float *)(ws + L.cx);
+    float2 *cyx = (float2 *)(ws + L.cyx);
     uint32_t *cmax = (uint32_t *)(ws + L.cmax), *wmax = (uint32_t *)(ws + L.wmax);
     const float2 *fl = (const float2 *)flows_yx;
     Events g = to_events(grad);
@@ -2178,13 +2175,13 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
         dim3 grid(xcd_grid(FB, chunks));
         if (w.kind == TEF_KIND_ITERATIVE && w.S == 1)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cy, cx, wmax, chunks);
+                             stats, grad_out, cyx, wmax, chunks);
         else if (w.kind == TEF_KIND_ITERATIVE)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cy, cx, wmax, chunks);
+                             stats, grad_out, cyx, wmax, chunks);
         else
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
-                             grad_out, cy, cx, wmax, chunks);
+                             grad_out, cyx, wmax, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_STATS, mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax,
@@ -2198,7 +2195,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
         unsigned grid = (unsigned)std::min<long>(items, num_cus());
         grid = std::max(8u, (grid + 7u) & ~7u);
         TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(grid), dim3(kSplatThreads), lds, st, w, g, traj,
-                         (const float2 *)(ws + L.yr), cy, cx, cmax, dflows, rows, nbands, (int *)(ws + L.queue) + 8);
+                         (const float2 *)(ws + L.yr), cyx, cmax, dflows, rows, nbands, (int *)(ws + L.queue) + 8);
     }
     return tef::check_launch("dflow_splat_kernel");
 }
