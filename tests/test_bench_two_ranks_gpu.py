@@ -1,0 +1,40 @@
+"""`python bench.py --gpus 2` end to end on the GPU box: the launcher's two ranks run the loss bench and a training
+window (captured as the two hipGraphs around the eager all-reduce) and rank 0 prints ONE line with n_gpus = 2 and the
+whole-job rate.  The box has one GPU, so both ranks share it and the collectives run over gloo
+(TEF_BENCH_BACKEND / TEF_BENCH_SHARE_GPU): the control flow — rendezvous, barriers, max-over-ranks timing, lock-step
+flag, split graphs — is the one the RCCL run takes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args):
+    env = dict(os.environ, TEF_BENCH_BACKEND="gloo", TEF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_loss_mode_two_ranks():
+    assert torch.cuda.is_available()
+    d = _bench(["--steps", "12", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert d["value"] > 0 and abs(d["value"] - 2 * 800000 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]
+
+
+def test_train_mode_two_ranks_graph():
+    d = _bench(["--mode", "train", "--graph", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "hipGraph" in d["config"]["launch"]
