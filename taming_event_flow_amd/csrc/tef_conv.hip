@@ -101,34 +101,6 @@ __device__ __forceinline__ Pix decode_pixel(const Gather &G, int p)
     return q;
 }
 
-__device__ __forceinline__ float gather_value(const Gather &G, const Pix &q, int k)
-{
-    if (!q.ok || k >= G.K) return 0.0f;
-    int ci, ky, kx;
-    if (G.ks == 3) {
-        ci = k / 9;
-        int r = k - ci * 9;
-        ky = r / 3;
-        kx = r - ky * 3;
-    } else {
-        ci = k;
-        ky = kx = 0;
-    }
-    int ty = q.py * G.mul + G.sgn * (ky - G.pad), tx = q.px * G.mul + G.sgn * (kx - G.pad);
-    if (ty < 0 || tx < 0) return 0.0f;
-    if (G.div > 1) {
-        if ((ty % G.div) | (tx % G.div)) return 0.0f;
-        ty /= G.div;
-        tx /= G.div;
-    }
-    if (ty >= G.SH || tx >= G.SW) return 0.0f;
-    if (ci < G.C0) return G.src0[(((size_t)q.b * G.C0 + ci) * G.SH + ty) * G.SW + tx];
-    size_t o = (((size_t)q.b * G.C1 + (ci - G.C0)) * G.SH + ty) * G.SW + tx;
-    float v = G.src1[o];
-    if (G.gate1) v *= G.gate1[o];
-    return v;
-}
-
 typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 

@@ -44,13 +44,10 @@ namespace {
 
 constexpr float kEps = 1e-9f;
 constexpr int kSplatThreads = 1024;
-constexpr size_t kLdsBudget = 144 * 1024;   // per-workgroup accumulator budget (160 KiB LDS per CU on gfx950)
 constexpr size_t kSplatLdsBudget = 138 * 1024;   // K2 keeps 20 KiB of run tables and per-wavefront row lists beside its planes
 constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the few-row
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
-constexpr int kMaxSegs = 4 * TEF_MAX_PASSES;
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
-constexpr int kUnroll = 4;
 constexpr int kQueueInts = 16;                // work queues of the persistent scatter kernels: [0, 8) images, [8, 16) flow gradients
 
 // meta word written by K1 per (head, sample, slot)
@@ -1172,7 +1169,6 @@ __device__ __forceinline__ float2 NT_LD2(const float2 *p)
     f32x2_v v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_v *>(p));
     return make_float2(v.x, v.y);
 }
-__device__ __forceinline__ void NT_ST(float *p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void NT_ST2(float2 *p, float a, float b)
 {
     f32x2_v v = {a, b};
@@ -1940,7 +1936,6 @@ bool make_win(const tef_loss_cfg *c, Win *w)
 inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds, size_t budget = kSplatLdsBudget)
 {
     int rows = (int)(budget / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
-    (void)kLdsBudget;
     if (rows > w.H) rows = w.H;
     *nbands = (w.H + rows - 1) / rows;
     rows = (w.H + *nbands - 1) / *nbands;            // equal bands
