@@ -14,7 +14,6 @@ Prints ONE JSON line (rank 0).
 """
 
 import argparse
-import ctypes
 import json
 import os
 import sys

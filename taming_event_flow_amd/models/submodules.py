@@ -11,7 +11,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as f
 
 try:
     from .. import _lib

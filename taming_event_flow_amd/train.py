@@ -11,7 +11,7 @@ import os
 
 import torch
 
-from . import parallel, synth
+from . import parallel
 from .dataloader import base as dl_base
 from .loss.flow import Iterative, Linear  # noqa: F401  (selected by name like the reference's eval(...))
 from .models import submodules
