@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))      # conftest / test_loss_gpu helpers when run as a script
 
 
-def sweep(cases, seed, verbose=True):
+def sweep(cases, seed, verbose=True, big_frac=0.05):
     """-> (number of cases over the 1e-4 bar or raising, worst relative error)"""
     import __graft_entry__ as g
 
@@ -44,6 +44,9 @@ def sweep(cases, seed, verbose=True):
             H, W = int(rng.integers(150, 260)), int(rng.integers(180, 330))      # several LDS row bands
             B, F, P, S = 1, 1, min(P, 4), 1
         nmax = int(rng.integers(1, 400))
+        if rng.random() < big_frac:       # long passes: several pack workgroups per sample, many rows per scatter item
+            nmax = int(rng.integers(4096, 9000))
+            B, F, P, S = 1, int(rng.integers(1, 3)), min(P, 4), 1
         ng = [int(rng.integers(0, nmax + 1)) if rng.random() < 0.5 else nmax for _ in range(P)]
         if sum(ng) == 0:
             ng[0] = 5
@@ -82,8 +85,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--big-frac", type=float, default=0.05, help="fraction of cases with 4096..9000 events per pass")
     a = ap.parse_args()
-    bad, _ = sweep(a.cases, a.seed)
+    bad, _ = sweep(a.cases, a.seed, big_frac=a.big_frac)
     sys.exit(1 if bad else 0)
 
 
