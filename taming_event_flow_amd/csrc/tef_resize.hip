@@ -47,6 +47,50 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restri
     y[idx] = mul * v;
 }
 
+// sh = sw = 2 without crop, W a multiple of 2 (the decoder levels): one thread per 4 consecutive outputs of a row — they
+// read input columns 2j - 1 .. 2j + 2 of two input rows (8 values instead of 16) and leave as one 16-byte store.  The
+// per-output expression is the one above (same weights from src_index, same order of operations).
+__global__ __launch_bounds__(256) void upsample2x_fwd4_kernel(const float *__restrict__ x, const float *__restrict__ x2,
+                                                              int planes, int H, int W, float mul, float *__restrict__ y)
+{
+    const int Ho = 2 * H, Wo = 2 * W, W4 = Wo >> 2;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * Ho * W4) return;
+    const int j = (int)(idx % W4);
+    const size_t t = idx / W4;
+    const int oy = (int)(t % Ho), pl = (int)(t / Ho);
+    int y0, y1;
+    float ly0, ly1;
+    src_index(oy, 0.5f, H, y0, y1, ly0, ly1);
+    const float *p = x + (size_t)pl * H * W, *q = x2 ? x2 + (size_t)pl * H * W : nullptr;
+    // input columns the four outputs can touch: 2j - 1 .. 2j + 2, clamped like src_index does
+    float r0[4], r1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int xi = min(max(2 * j - 1 + c, 0), W - 1);
+        r0[c] = p[y0 * W + xi];
+        r1[c] = p[y1 * W + xi];
+        if (q) {
+            r0[c] += q[y0 * W + xi];
+            r1[c] += q[y1 * W + xi];
+        }
+    }
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int x0, x1;
+        float lx0, lx1;
+        src_index(4 * j + e, 0.5f, W, x0, x1, lx0, lx1);
+        const int a = x0 - (2 * j - 1), b = x1 - (2 * j - 1);          // positions in r0 / r1 (0 .. 3)
+        const float v00 = a == 0 ? r0[0] : (a == 1 ? r0[1] : (a == 2 ? r0[2] : r0[3]));
+        const float v01 = b == 0 ? r0[0] : (b == 1 ? r0[1] : (b == 2 ? r0[2] : r0[3]));
+        const float v10 = a == 0 ? r1[0] : (a == 1 ? r1[1] : (a == 2 ? r1[2] : r1[3]));
+        const float v11 = b == 0 ? r1[0] : (b == 1 ? r1[1] : (b == 2 ? r1[2] : r1[3]));
+        o[e] = mul * (ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11));
+    }
+    *reinterpret_cast<float4 *>(y + ((size_t)pl * Ho + oy) * Wo + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // Exact adjoint, separable: dX = Ry^T dY Rx with the forward's 1-D weights (same expressions as the forward, so the pair
 // is an exact adjoint).  One workgroup per (plane, input row): first the column sums over the <= 3*sh output rows that
 // touch the input row (T[ox], kept in LDS), then every input pixel of the row collects its <= 3*sw columns of T.
@@ -90,6 +134,43 @@ __global__ __launch_bounds__(128) void upsample_bwd_kernel(const float *__restri
     }
 }
 
+// The same adjoint for sh = sw = 2 (the four decoder levels, 60 of the 61 MB a pass up-samples), one thread per INPUT
+// pixel: only the output rows / columns 2i - 1 .. 2i + 2 can carry a weight for input index i, so a thread sums its 4 x 4
+// neighbourhood — vertical sums first, then the horizontal one, in ascending order: the same additions in the same
+// order as the row kernel above.  (That one launches a 128-thread workgroup per input row: at the deep levels, rows of
+// 8 and 16 pixels, 22 us for 1 - 2 MB.)
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
+                                                             float mul, int ct, int cl, float *__restrict__ dx)
+{
+    const int Ho = 2 * H, Wo = 2 * W, Wc = Wo - cl;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * H * W) return;
+    const int ix = (int)(idx % W);
+    const size_t t = idx / W;
+    const int iy = (int)(t % H), pl = (int)(t / H);
+    const float *g = dy + (size_t)pl * (Ho - ct) * Wc;
+    float wy[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int oy = 2 * iy - 1 + a;
+        wy[a] = (oy >= ct && oy < Ho) ? tap_weight(oy, 0.5f, H, iy) : 0.0f;
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int ox = 2 * ix - 1 + b;
+        if (ox < cl || ox >= Wo) continue;
+        const float wx = tap_weight(ox, 0.5f, W, ix);
+        if (wx == 0.0f) continue;
+        float col = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            if (wy[a] != 0.0f) col += wy[a] * g[(size_t)(2 * iy - 1 + a - ct) * Wc + (ox - cl)];
+        acc += wx * col;
+    }
+    dx[idx] = mul * acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -100,6 +181,12 @@ int tef_upsample_bilinear_crop(const float *x, const float *x2, int planes, int 
     if (!x || !y || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1 || crop_top < 0 || crop_left < 0 ||
         crop_top >= H * scale_h || crop_left >= W * scale_w)
         return tef::fail("tef_upsample_bilinear: bad arguments"), TEF_ERR_INVALID;
+    if (scale_h == 2 && scale_w == 2 && crop_top == 0 && crop_left == 0 && (W & 1) == 0 && W >= 2) {
+        const size_t n4 = (size_t)planes * (2 * H) * (W >> 1);
+        hipLaunchKernelGGL(upsample2x_fwd4_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x2,
+                           planes, H, W, mul, y);
+        return tef::check_launch("upsample2x_fwd4_kernel");
+    }
     size_t n = (size_t)planes * (H * scale_h - crop_top) * (W * scale_w - crop_left);
     hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, x2,
                        planes, H, W, scale_h, scale_w, mul, crop_top, crop_left, y);
@@ -112,6 +199,12 @@ int tef_upsample_bilinear_crop_backward(const float *dy, int planes, int H, int 
     if (!dy || !dx || planes < 1 || H < 1 || W < 1 || scale_h < 1 || scale_w < 1 || crop_top < 0 || crop_left < 0 ||
         crop_top >= H * scale_h || crop_left >= W * scale_w)
         return tef::fail("tef_upsample_bilinear_backward: bad arguments"), TEF_ERR_INVALID;
+    if (scale_h == 2 && scale_w == 2) {
+        const size_t n = (size_t)planes * H * W;
+        hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy,
+                           planes, H, W, mul, crop_top, crop_left, dx);
+        return tef::check_launch("upsample2x_bwd_kernel");
+    }
     size_t lds = (size_t)W * scale_w * sizeof(float);
     if (lds > 64 * 1024) return tef::fail("tef_upsample_bilinear_backward: output row too wide"), TEF_ERR_INVALID;
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((size_t)planes * H)), dim3(128), lds, (hipStream_t)stream, dy,
