@@ -634,7 +634,7 @@ __device__ __forceinline__ void splat_one(float2 p, float ts, float m, const Img
     float wx0 = fmaxf(1.0f - fabsf(x - fx0), 0.0f), wx1 = fmaxf(1.0f - fabsf(x - floorf(x + 1.0f)), 0.0f);
     // tau = 1 - |tref - ts| / delta (:94-95); delta is an integer number of passes: exact division by a constant
     const float tau = 1.0f - div_by_const(fabsf(im.tref - ts), rdelta);
-    const int cell = rr * WP + (int)fx0;
+    const int cell = __mul24(rr, WP) + (int)fx0;      // (24-bit multiply: full rate)
     if (ok0) {
         float w00 = wy0 * wx0, w01 = wy0 * wx1;
         acc_add<FX>(img_c + cell, FX ? w00 : w00 * m);
@@ -1510,7 +1510,7 @@ __device__ __forceinline__ void dflow_one(float2 p, float cvy, float cvx, int H,
     for (int c = 0; c < 4; ++c) {
         const int iy = y0 + (c >> 1) - r0, ix = x0 + (c & 1);
         if (iy < 0 || iy >= nrows || ix < 0 || ix >= W) continue;
-        const int cell = iy * WP + ix;
+        const int cell = __mul24(iy, WP) + ix;
         const float vy = cvy * wt[c], vx = cvx * wt[c];
         if (FX) {
             atomicAdd(reinterpret_cast<unsigned long long *>(img_y + cell), to_fixed(ldexpf(vy, -e)));
