@@ -81,6 +81,10 @@ typedef struct tef_loss_cfg {
     int doff[TEF_MAX_PASSES + 1];   /* detached slot offsets per pass */
     int loss_scaling;               /* BaseEventWarping(loss_scaling=...), loss/flow.py:124-127: 1 = divide every image's sum
                                        by its number of active pixels (the default), 0 = plain sum */
+    int border_compensation;        /* BaseEventWarping(border_compensation=...): 1 (the only value the reference's Linear /
+                                       Iterative constructors produce) = an event enters the images of a window only if it
+                                       stays inside the frame at EVERY reference time of the window (loss/flow.py:671-681);
+                                       0 (TEF_KIND_ITERATIVE only) = at each reference time on its own (:691-693, :709-711) */
 } tef_loss_cfg;
 
 /* AoS -> SoA packing of one pass, replaces the bookkeeping of Iterative.update / Linear.update

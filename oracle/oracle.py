@@ -26,6 +26,7 @@ class _Window(ctypes.Structure):
         ("M", ctypes.c_int), ("Md", ctypes.c_int),
         ("off", _i), ("doff", _i), ("flows", _f),
         ("ts", _f), ("y", _f), ("x", _f), ("mp", _f), ("mn", _f), ("loss_scaling", ctypes.c_int),
+        ("border_compensation", ctypes.c_int),
     ]
 
 
@@ -87,7 +88,8 @@ class Window:
     (reference loss/flow.py:443-476): ts += pass index, optional round_ts.
     """
 
-    def __init__(self, flows, ev, pm, dev, dpm, S=1, mode="two", round_ts=False, loss_scaling=True):
+    def __init__(self, flows, ev, pm, dev, dpm, S=1, mode="two", round_ts=False, loss_scaling=True,
+                 border_compensation=True):
         P = len(flows)
         F = len(flows[0])
         B, _, H, W = flows[0][0].shape
@@ -121,7 +123,8 @@ class Window:
         self.mn = both(pm, dpm, 1)
         self._w = _Window(B, H, W, P, F, S, self.mode_div, self.M, self.Md,
                           self.off.ctypes.data_as(_i), self.doff.ctypes.data_as(_i), _p(self.flows),
-                          _p(self.ts), _p(self.y), _p(self.x), _p(self.mp), _p(self.mn), 1 if loss_scaling else 0)
+                          _p(self.ts), _p(self.y), _p(self.x), _p(self.mp), _p(self.mn), 1 if loss_scaling else 0,
+                          1 if border_compensation else 0)
 
     def _run(self, fn, backward, grad_out):
         d = np.zeros_like(self.flows) if backward else None

@@ -231,6 +231,8 @@ typedef struct {
     const float *flows;
     const float *ts, *y, *x, *mp, *mn;  /* [B][M+Md] */
     int loss_scaling;            /* loss/flow.py:124-127: divide each image's sum by its number of active pixels */
+    int border_compensation;     /* loss/flow.py:671-681 shared mask over a window's reference times (1, the reachable
+                                    setting) or each reference time's own cumulative mask (0; Iterative only) */
 } tef_window;
 
 static inline const float *tef_map(const tef_window *wd, int t, int i, int b, int c)
@@ -409,6 +411,9 @@ static double tef_iterative_pair(const tef_window *wd, const int *bin, int i, in
                     for (int sl = 0; sl < Mt; ++sl)
                         valid[sl] = (bin[sl] >= lo && bin[sl] < hi && kb[sl] < lo && kf[sl] > hi);
                     for (int tref = lo; tref <= hi; ++tref) {
+                        if (!wd->border_compensation)    /* :691-693: the mask the chain carried to this reference time */
+                            for (int sl = 0; sl < Mt; ++sl)
+                                valid[sl] = (bin[sl] >= lo && bin[sl] < hi && kb[sl] < tref && tref < kf[sl]);
                         int le = tref - delta > lo ? tref - delta : lo;        /* :685 */
                         int he = tref + delta < hi ? tref + delta : hi;        /* :686 */
                         const float *py = ty + (size_t)tref * Mt, *px = tx + (size_t)tref * Mt;

@@ -33,7 +33,7 @@ class LossCfg(ctypes.Structure):
         ("P", ctypes.c_int), ("F", ctypes.c_int), ("S", ctypes.c_int), ("mode_div", ctypes.c_int),
         ("M", ctypes.c_int), ("Md", ctypes.c_int),
         ("off", ctypes.c_int * (TEF_MAX_PASSES + 1)), ("doff", ctypes.c_int * (TEF_MAX_PASSES + 1)),
-        ("loss_scaling", ctypes.c_int),
+        ("loss_scaling", ctypes.c_int), ("border_compensation", ctypes.c_int),
     ]
 
 

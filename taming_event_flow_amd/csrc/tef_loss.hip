@@ -60,6 +60,7 @@ constexpr uint32_t kMetaNonUnit = 1u << 26;  // a mask value is neither 0 nor 1:
 // ---------------------------------------------------------------------------------------------
 struct Win {
     int kind, B, H, W, P, F, S, mode_div, M, Md, Mt, nplanes, nimg, scaling;
+    int comp;                        // border compensation (loss/flow.py:671-681): shared mask over the window's reference times
     int nrow;                        // rows of 16 slots: ceil(Mt / 16)
     int img_base[TEF_MAX_SCALES + 1];
     int off[TEF_MAX_PASSES + 1];
@@ -336,6 +337,17 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t bits, int kb, int kf, flo
     if (mn != 0.0f) m |= kMetaNeg;
     if ((mp != 0.0f && mp != 1.0f) || (mn != 0.0f && mn != 1.0f)) m |= kMetaNonUnit;
     return m;
+}
+
+// Does the event enter the image of temporal scale s at reference time tref?  With border compensation (the reference's
+// only reachable setting): bit s of the meta word, "inside the frame at every reference time of the scale's window"
+// (loss/flow.py:671-681).  Without: inside the frame at THIS reference time, i.e. the chain has reached it alive
+// (kb < tref < kf; :691-693 takes the event's own cumulative mask).
+__device__ __forceinline__ bool in_image(const Win &w, uint32_t mv, int s, int tref)
+{
+    if (w.comp) return (mv >> s) & 1u;
+    const int kb1 = (int)((mv >> 8) & 0xffu), kf = (int)((mv >> 16) & 0xffu);      // kb + 1, kf
+    return (mv & (kMetaPos | kMetaNeg)) != 0u && tref >= kb1 && tref < kf;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -666,7 +678,7 @@ __device__ __forceinline__ void splat_run_general(const Win &w, const Img &im, d
     for (int v = threadIdx.x; v < len; v += blockDim.x) {
         const int u = u0 + v;
         const uint32_t mv = mt[u];
-        if (!((mv >> im.s) & 1u)) continue;          // shared border mask (:671-681)
+        if (!in_image(w, mv, im.s, im.plane)) continue;          // border mask (:671-681)
         float m = 1.0f;
         if (mv & kMetaNonUnit) m = mask[u];
         splat_one<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, WP);
@@ -883,7 +895,7 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
                     for (int k = 0; k < kQ; ++k) nxt[k] = load_quad_rows(sidx + 4 * (kQ + k), h);
 #pragma unroll
                     for (int k = 0; k < kQ; ++k)
-                        if ((cur[k].mv >> im.s) & 1u)            // shared border mask (:671-681)
+                        if (in_image(w, cur[k].mv, im.s, im.plane))            // border mask (:671-681)
                             splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
 #pragma unroll
                     for (int k = 0; k < kQ; ++k) cur[k] = nxt[k];
@@ -1199,6 +1211,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     float2 *co = cyx + (size_t)ib * P * M + sl;
     uint32_t mv = meta[(size_t)ib * w.Mt + sl];
     uint32_t bits = mv & 0xffu;
+    if (!w.comp) bits = (mv & (kMetaPos | kMetaNeg)) ? (1u << w.S) - 1u : 0u;      // every scale, as far as the chain is alive
     // Passes start at multiples of 64 slots, so a wavefront belongs to ONE pass: t, and with it the reference time k of
     // every loop iteration below, is wave-uniform — map / image / plane base addresses and the image statistics are
     // scalar-register arithmetic and scalar loads instead of per-lane 64-bit index math in a VALU-bound kernel.  Lanes
@@ -1885,6 +1898,8 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     w->kind = c->kind; w->B = c->B; w->H = c->H; w->W = c->W; w->P = c->P; w->F = c->F; w->S = c->S;
     w->mode_div = c->mode_div; w->M = c->M; w->Md = c->Md; w->Mt = c->M + c->Md;
     w->scaling = c->loss_scaling ? 1 : 0;
+    w->comp = c->border_compensation ? 1 : 0;
+    if (!w->comp && c->kind != TEF_KIND_ITERATIVE) return tef::fail("border_compensation = 0 is implemented for the Iterative loss only");
     w->nrow = (w->Mt + 15) / 16;
     w->nplanes = (c->kind == TEF_KIND_ITERATIVE) ? c->P + 1 : 2 * c->S;
     if (c->M < 0 || c->Md < 0 || c->off[0] != 0 || c->doff[0] != 0 || c->off[c->P] != c->M || c->doff[c->P] != c->Md)

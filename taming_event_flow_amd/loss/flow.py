@@ -145,9 +145,6 @@ class BaseEventWarping(torch.nn.Module):
 
     def __init__(self, config, device, loss_scaling=True, border_compensation=True):
         super().__init__()
-        if not border_compensation:       # (not reachable through Linear / Iterative: their constructors do not pass it on)
-            raise NotImplementedError("the HIP path implements border_compensation=True (reference loss/flow.py:221,421: "
-                                      "the only value Linear / Iterative can be built with)")
         self.device = torch.device(device)
         self.config = config
         self.loss_scaling = loss_scaling
@@ -254,6 +251,12 @@ class BaseEventWarping(torch.nn.Module):
         cfg.mode_div = getattr(self, "_mode_div", 1)
         cfg.M, cfg.Md = win.grad.n, win.det.n
         cfg.loss_scaling = 1 if self.loss_scaling else 0
+        # read when the loss is evaluated, like the reference does (loss/flow.py:324, :671): its Linear / Iterative
+        # constructors always leave True, the attribute can be changed afterwards
+        cfg.border_compensation = 1 if self.border_compensation else 0
+        if not self.border_compensation and self._kind == _lib.KIND_LINEAR:
+            raise NotImplementedError("Linear with border_compensation=False (reference loss/flow.py:324-343: events partly "
+                                      "outside the frame are splatted) is not implemented on the HIP path")
         for t in range(P + 1):
             cfg.off[t] = win.grad.off[t]
             cfg.doff[t] = win.det.off[t]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep of the HIP loss path against the CPU oracle (test infrastructure): random resolutions, batch,
 window length, heads, temporal scales, modes, ragged / empty passes, detached lists, float coordinates, flow kinds,
-smoothing weights, round_ts.  Prints every case whose error exceeds the 1e-4 bar and the worst case seen.
+smoothing weights, round_ts, border compensation on / off.  Prints every case whose error exceeds the 1e-4 bar and the worst case seen.
 
     python tests/fuzz_loss.py [--cases 200] [--seed 0]
 """
@@ -58,10 +58,12 @@ def sweep(cases, seed, verbose=True, big_frac=0.05):
         spat = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
         temp = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
         rts = rng.random() < 0.15 and min(ng) > 0          # round_ts on an empty list raises, as in the reference (:461)
-        meta = dict(H=H, W=W, B=B, P=P, S=S, mode=mode, spat=spat, temp=temp, round_ts=bool(rts))
+        comp = not (kind == "Iterative" and rng.random() < 0.2)      # border_compensation=False: Iterative only
+        meta = dict(H=H, W=W, B=B, P=P, S=S, mode=mode, spat=spat, temp=temp, round_ts=bool(rts), border_compensation=comp)
         try:
-            l, gr, _ = run_hip(kind, make_cfg(meta), win, dev)
-            ow = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=S, mode=mode, round_ts=bool(rts))
+            l, gr, _ = run_hip(kind, make_cfg(meta), win, dev, border_compensation=comp)
+            ow = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=S, mode=mode, round_ts=bool(rts),
+                               border_compensation=comp)
             ol, od = ow.loss(kind, spat, temp)
         except Exception as e:                                # noqa: BLE001
             print("EXC", c, kind, meta, ng, nd, repr(e)[:200], flush=True)

@@ -49,11 +49,13 @@ def make_config(H, W, B, P, S, mode="two", spat=None, temp=None, round_ts=False)
     }
 
 
-def run_loss(kind, cfg, win, loss_scaling=True):
+def run_loss(kind, cfg, win, loss_scaling=True, border_compensation=True):
     """Feed a synthetic window through the reference loss; return loss + d loss / d flow."""
     P = len(win["flows"])
     F = len(win["flows"][0])
     L = (Iterative if kind == "Iterative" else Linear)(cfg, torch.device("cpu"), loss_scaling=loss_scaling)
+    # the constructors of Linear / Iterative do not take the argument: the attribute is read at forward time (:671)
+    L.border_compensation = border_compensation
     flows = [[torch.tensor(win["flows"][t][i], requires_grad=True) for i in range(F)] for t in range(P)]
     for t in range(P):
         L.update(
@@ -71,13 +73,14 @@ def run_loss(kind, cfg, win, loss_scaling=True):
 
 
 def save_loss_case(name, kind, H, W, B, P, F, S, mode, n_grad, n_det, seed, sigma=1.5, flow_kind="smooth",
-                   ragged=True, spat=None, temp=None, round_ts=False, integer_coords=True, loss_scaling=True):
+                   ragged=True, spat=None, temp=None, round_ts=False, integer_coords=True, loss_scaling=True,
+                   border_compensation=True):
     rng = np.random.default_rng(seed)
     win = synth.make_window(rng, B, H, W, P, F, n_grad, n_det, sigma, flow_kind, ragged, integer_coords)
     cfg = make_config(H, W, B, P, S, mode, spat, temp, round_ts)
-    loss64, loss32, g = run_loss(kind, cfg, win, loss_scaling)
+    loss64, loss32, g = run_loss(kind, cfg, win, loss_scaling, border_compensation)
     meta = dict(kind=kind, H=H, W=W, B=B, P=P, F=F, S=S, mode=mode, spat=spat, temp=temp, round_ts=round_ts,
-                seed=seed, loss=loss64, loss_scaling=loss_scaling)
+                seed=seed, loss=loss64, loss_scaling=loss_scaling, border_compensation=border_compensation)
     arrays = {"meta": np.array(json.dumps(meta)), "loss": loss32, "dflows": g,
               "flows": np.stack([np.stack(win["flows"][t]) for t in range(P)])}
     for t in range(P):
@@ -201,6 +204,17 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--unscaled":
         save_loss_case("it_two_unscaled", "Iterative", 16, 20, 2, 6, 2, 1, "two", 180, 40, seed=14, loss_scaling=False)
         save_loss_case("lin_unscaled", "Linear", 16, 20, 2, 4, 2, 1, "two", 150, 30, seed=25, loss_scaling=False)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--no-compensation":
+        # border_compensation=False (the attribute is read at forward time, loss/flow.py:671): large flows so that many
+        # events leave the frame inside the window and the two settings differ
+        save_loss_case("it_two_nocomp", "Iterative", 16, 20, 2, 6, 2, 1, "two", 180, 40, seed=41, sigma=4.0,
+                       border_compensation=False)
+        # (mode "one" warps every event across the whole window: with sigma = 3 px per pass over 8 passes the product of
+        # the step Jacobians is so ill-conditioned that two fp32 evaluation orders of the SAME maths differ by 1e-4; the
+        # case below keeps the chains short enough to compare at 1e-5)
+        save_loss_case("it_one_nocomp_s2", "Iterative", 16, 20, 2, 8, 2, 2, "one", 150, [40, 0, 0, 30, 0, 60, 0, 20], seed=42,
+                       sigma=1.5, border_compensation=False)
         return
     save_primitives()
     save_encodings()

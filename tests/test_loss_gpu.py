@@ -20,11 +20,12 @@ def make_cfg(meta):
     }
 
 
-def run_hip(kind, cfg, win, dev, grad_scale=None, loss_scaling=True):
+def run_hip(kind, cfg, win, dev, grad_scale=None, loss_scaling=True, border_compensation=True):
     from taming_event_flow_amd.loss.flow import Iterative, Linear
 
     P, F = len(win["flows"]), len(win["flows"][0])
     L = (Iterative if kind == "Iterative" else Linear)(cfg, dev, loss_scaling=loss_scaling)
+    L.border_compensation = border_compensation      # an attribute read at forward time (reference loss/flow.py:671)
     flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
     evs = []
     for t in range(P):
@@ -53,7 +54,8 @@ def dev():
 @pytest.mark.parametrize("name", ITERATIVE_CASES + LINEAR_CASES + FULL_RES_CASES)
 def test_golden_cases(name, dev):
     meta, win, loss, dflows = load_case(name)
-    l, g, evs = run_hip(meta["kind"], make_cfg(meta), win, dev, loss_scaling=meta.get("loss_scaling", True))
+    l, g, evs = run_hip(meta["kind"], make_cfg(meta), win, dev, loss_scaling=meta.get("loss_scaling", True),
+                        border_compensation=meta.get("border_compensation", True))
     assert abs(l - loss) <= TOL * abs(loss), (l, float(loss))
     assert rel_err(g, dflows) <= TOL
     for t in range(meta["P"]):
@@ -107,6 +109,17 @@ def test_empty_and_padding_only_lists(dev):
     ol, od = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"]).iterative()
     assert abs(l - ol) <= TOL * abs(ol)
     assert rel_err(g, od) <= TOL
+
+
+def test_linear_without_border_compensation_is_refused(dev):
+    """Only the Iterative loss implements border_compensation=False; Linear must say so instead of computing the default."""
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(3)
+    win = synth.make_window(rng, 1, 16, 20, 2, 1, 50, 0, sigma=1.0)
+    meta = dict(H=16, W=20, B=1, P=2, S=1, mode="two", spat=None, temp=None, round_ts=False)
+    with pytest.raises(NotImplementedError):
+        run_hip("Linear", make_cfg(meta), win, dev, border_compensation=False)
 
 
 @pytest.mark.parametrize("kind", ["Iterative", "Linear"])

@@ -18,7 +18,8 @@ TOL = 1e-5
 def test_loss_cases(name):
     meta, win, loss, dflows = load_case(name)
     w = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=meta["S"], mode=meta["mode"],
-                      round_ts=meta["round_ts"], loss_scaling=meta.get("loss_scaling", True))
+                      round_ts=meta["round_ts"], loss_scaling=meta.get("loss_scaling", True),
+                      border_compensation=meta.get("border_compensation", True))
     l, d = w.loss(meta["kind"], meta["spat"], meta["temp"])
     assert abs(l - loss) <= TOL * abs(loss), (l, loss)
     assert d.shape == dflows.shape
