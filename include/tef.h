@@ -83,8 +83,10 @@ typedef struct tef_loss_cfg {
                                        by its number of active pixels (the default), 0 = plain sum */
     int border_compensation;        /* BaseEventWarping(border_compensation=...): 1 (the only value the reference's Linear /
                                        Iterative constructors produce) = an event enters the images of a window only if it
-                                       stays inside the frame at EVERY reference time of the window (loss/flow.py:671-681);
-                                       0 (TEF_KIND_ITERATIVE only) = at each reference time on its own (:691-693, :709-711) */
+                                       stays inside the frame at EVERY reference time of the window (loss/flow.py:671-681,
+                                       Linear: at both window ends, :341-343);
+                                       0 = Iterative: at each reference time on its own (:691-693, :709-711); Linear: nothing
+                                       is purged, corners outside the frame drop out one by one (:324-328) */
 } tef_loss_cfg;
 
 /* AoS -> SoA packing of one pass, replaces the bookkeeping of Iterative.update / Linear.update

@@ -553,7 +553,9 @@ float tef_oracle_linear(const tef_window *wd, float *dflows, float grad_out)
                             py[(size_t)e * Mt + sl] = wd->y[o] + dt * efy[sl];
                             px[(size_t)e * Mt + sl] = wd->x[o] + dt * efx[sl];
                         }
-                        valid[sl] = tef_inbounds(py[sl], px[sl], H, W) && tef_inbounds(py[Mt + sl], px[Mt + sl], H, W);
+                        /* shared purge of both ends (:341-343); without border compensation nothing is purged (:324-328) */
+                        valid[sl] = !wd->border_compensation ||
+                                    (tef_inbounds(py[sl], px[sl], H, W) && tef_inbounds(py[Mt + sl], px[Mt + sl], H, W));
                     }
                     if (dflows) { memset(gy, 0, sizeof(float) * 2 * (M + 1)); memset(gx, 0, sizeof(float) * 2 * (M + 1)); }
                     for (int e = 0; e < 2; ++e) {

@@ -345,7 +345,7 @@ __device__ __forceinline__ uint32_t pack_meta(uint32_t bits, int kb, int kf, flo
 // (kb < tref < kf; :691-693 takes the event's own cumulative mask).
 __device__ __forceinline__ bool in_image(const Win &w, uint32_t mv, int s, int tref)
 {
-    if (w.comp) return (mv >> s) & 1u;
+    if (w.comp || w.kind != TEF_KIND_ITERATIVE) return (mv >> s) & 1u;      // (Linear without: every event of the window)
     const int kb1 = (int)((mv >> 8) & 0xffu), kf = (int)((mv >> 16) & 0xffu);      // kb + 1, kf
     return (mv & (kMetaPos | kMetaNeg)) != 0u && tref >= kb1 && tref < kf;
 }
@@ -559,14 +559,18 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
         float dtf = (float)hi - ts, dtb = (float)lo - ts;
         float yf = y0 + dtf * f.x, xf = x0 + dtf * f.y;
         float yb = y0 + dtb * f.x, xb = x0 + dtb * f.y;
-        const bool in = valid && has && inbounds(yf, xf, H, W) && inbounds(yb, xb, H, W);
+        // shared purge of both window ends (loss/flow.py:341-343); without border compensation nothing is purged and
+        // the corners outside the frame drop out one by one (:324-328, utils/iwe.py:103-107)
+        const bool in = valid && has && (!w.comp || (inbounds(yf, xf, H, W) && inbounds(yb, xb, H, W)));
         if (valid && has) {
             tr[(size_t)(2 * s) * w.Mt] = make_float2(yf, xf);
             tr[(size_t)(2 * s + 1) * w.Mt] = make_float2(yb, xb);
         }
         if (in) bits |= 1u << s;
-        store_row_range(rng, 2 * s, in, yf, has && in_list);
-        store_row_range(rng, 2 * s + 1, in, yb, has && in_list);
+        // (the interval's integer min / max need non-negative values: without border compensation a position above the
+        // frame counts as row 0, which keeps the band test a superset)
+        store_row_range(rng, 2 * s, in, fmaxf(yf, 0.0f), has && in_list);
+        store_row_range(rng, 2 * s + 1, in, fmaxf(yb, 0.0f), has && in_list);
     }
     flush_row_ranges(w, rng, yr, ib, chunk);
     if (in_list) meta[(size_t)ib * w.Mt + u] = valid ? pack_meta(bits, -1, 0, mp, mn) : 0u;
@@ -663,6 +667,33 @@ __device__ __forceinline__ void splat_one(float2 p, float ts, float m, const Img
     }
 }
 
+// The same for a position ANYWHERE (Linear without border compensation: nothing is purged, every corner is tested on its
+// own like utils/iwe.py:103-107 does).  Rows outside the band are outside the frame or another workgroup's.
+template <bool FX>
+__device__ __forceinline__ void splat_any(float2 p, float ts, float m, const Img &im, double rdelta, double *img_c,
+                                          double *img_t, int r0, int nrows, int W, int WP)
+{
+    const float y = p.x, x = p.y;
+    const float fy[2] = {floorf(y), floorf(y + 1.0f)}, fx[2] = {floorf(x), floorf(x + 1.0f)};
+    // (also rejects NaN / infinite positions before anything is converted to an integer)
+    if (!(fy[1] >= (float)r0 && fy[0] < (float)(r0 + nrows) && fx[1] >= 0.0f && fx[0] < (float)W)) return;
+    const float tau = 1.0f - div_by_const(fabsf(im.tref - ts), rdelta);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int rr = (int)fy[a] - r0;
+        if (rr < 0 || rr >= nrows) continue;
+        const float wy = fmaxf(1.0f - fabsf(y - fy[a]), 0.0f);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ix = (int)fx[b];
+            if (ix < 0 || ix >= W) continue;
+            const float wgt = wy * fmaxf(1.0f - fabsf(x - fx[b]), 0.0f);
+            acc_add<FX>(img_c + rr * WP + ix, FX ? wgt : wgt * m);
+            acc_add<FX>(img_t + rr * WP + ix, FX ? wgt * tau : (wgt * tau) * m);
+        }
+    }
+}
+
 // general path (masks other than 0 / 1, or more events than the integers hold): one contiguous run of slots of
 // polarity c in unified slot space, fp64 accumulators, no interval tests
 __device__ __forceinline__ void splat_run_general(const Win &w, const Img &im, double rdelta, const Events &g,
@@ -681,7 +712,8 @@ __device__ __forceinline__ void splat_run_general(const Win &w, const Img &im, d
         if (!in_image(w, mv, im.s, im.plane)) continue;          // border mask (:671-681)
         float m = 1.0f;
         if (mv & kMetaNonUnit) m = mask[u];
-        splat_one<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, WP);
+        if (w.comp || w.kind == TEF_KIND_ITERATIVE) splat_one<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, WP);
+        else splat_any<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, w.W, WP);
     }
 }
 
@@ -873,6 +905,7 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
                 return make_int2(ub, max(u0 - ub, 0) | (min(u1 - ub, 16) << 8) | ((r >= nb ? 1 : 0) << 16));
             };
             constexpr int kQ = 4;
+            const bool in_frame = w.comp || w.kind == TEF_KIND_ITERATIVE;      // every splatted position lies inside the frame
             int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
             float2 rg_cur[2], rg_nxt[2];
             for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(hh, r_cur[hh], row_cur[hh]);
@@ -895,8 +928,10 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
                     for (int k = 0; k < kQ; ++k) nxt[k] = load_quad_rows(sidx + 4 * (kQ + k), h);
 #pragma unroll
                     for (int k = 0; k < kQ; ++k)
-                        if (in_image(w, cur[k].mv, im.s, im.plane))            // border mask (:671-681)
-                            splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
+                        if (in_image(w, cur[k].mv, im.s, im.plane)) {          // border mask (:671-681)
+                            if (in_frame) splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
+                            else splat_any<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, W, WP);
+                        }
 #pragma unroll
                     for (int k = 0; k < kQ; ++k) cur[k] = nxt[k];
                 }
@@ -1899,7 +1934,6 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     w->mode_div = c->mode_div; w->M = c->M; w->Md = c->Md; w->Mt = c->M + c->Md;
     w->scaling = c->loss_scaling ? 1 : 0;
     w->comp = c->border_compensation ? 1 : 0;
-    if (!w->comp && c->kind != TEF_KIND_ITERATIVE) return tef::fail("border_compensation = 0 is implemented for the Iterative loss only");
     w->nrow = (w->Mt + 15) / 16;
     w->nplanes = (c->kind == TEF_KIND_ITERATIVE) ? c->P + 1 : 2 * c->S;
     if (c->M < 0 || c->Md < 0 || c->off[0] != 0 || c->doff[0] != 0 || c->off[c->P] != c->M || c->doff[c->P] != c->Md)

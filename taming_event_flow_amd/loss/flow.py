@@ -254,9 +254,6 @@ class BaseEventWarping(torch.nn.Module):
         # read when the loss is evaluated, like the reference does (loss/flow.py:324, :671): its Linear / Iterative
         # constructors always leave True, the attribute can be changed afterwards
         cfg.border_compensation = 1 if self.border_compensation else 0
-        if not self.border_compensation and self._kind == _lib.KIND_LINEAR:
-            raise NotImplementedError("Linear with border_compensation=False (reference loss/flow.py:324-343: events partly "
-                                      "outside the frame are splatted) is not implemented on the HIP path")
         for t in range(P + 1):
             cfg.off[t] = win.grad.off[t]
             cfg.doff[t] = win.det.off[t]

@@ -53,7 +53,7 @@ ITERATIVE_CASES = [
     "it_two_zero_flow", "it_two_smooth_terms", "it_two_round_ts", "it_two_float_xy", "it_two_p5_odd", "it_two_unscaled",
     "it_two_nocomp", "it_one_nocomp_s2",      # border_compensation=False (set after construction, as the reference allows)
 ]
-LINEAR_CASES = ["lin_s1_p6", "lin_s2_p8", "lin_smooth_terms", "lin_zero_flow", "lin_unscaled"]
+LINEAR_CASES = ["lin_s1_p6", "lin_s2_p8", "lin_smooth_terms", "lin_zero_flow", "lin_unscaled", "lin_nocomp_s2"]
 FULL_RES_CASES = ["it_two_128_p10", "lin_128_p10"]      # BASELINE resolution, inputs regenerated from a seed
 
 

@@ -58,7 +58,7 @@ def sweep(cases, seed, verbose=True, big_frac=0.05):
         spat = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
         temp = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
         rts = rng.random() < 0.15 and min(ng) > 0          # round_ts on an empty list raises, as in the reference (:461)
-        comp = not (kind == "Iterative" and rng.random() < 0.2)      # border_compensation=False: Iterative only
+        comp = rng.random() >= 0.2                                   # border_compensation=False in a fifth of the cases
         meta = dict(H=H, W=W, B=B, P=P, S=S, mode=mode, spat=spat, temp=temp, round_ts=bool(rts), border_compensation=comp)
         try:
             l, gr, _ = run_hip(kind, make_cfg(meta), win, dev, border_compensation=comp)

@@ -215,6 +215,9 @@ def main():
         # case below keeps the chains short enough to compare at 1e-5)
         save_loss_case("it_one_nocomp_s2", "Iterative", 16, 20, 2, 8, 2, 2, "one", 150, [40, 0, 0, 30, 0, 60, 0, 20], seed=42,
                        sigma=1.5, border_compensation=False)
+        # Linear: nothing is purged, events partly outside the frame keep their corners inside it (:324-328)
+        save_loss_case("lin_nocomp_s2", "Linear", 16, 20, 2, 4, 2, 2, "two", 150, 30, seed=43, sigma=4.0,
+                       border_compensation=False)
         return
     save_primitives()
     save_encodings()

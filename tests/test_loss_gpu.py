@@ -111,17 +111,6 @@ def test_empty_and_padding_only_lists(dev):
     assert rel_err(g, od) <= TOL
 
 
-def test_linear_without_border_compensation_is_refused(dev):
-    """Only the Iterative loss implements border_compensation=False; Linear must say so instead of computing the default."""
-    from taming_event_flow_amd import synth
-
-    rng = np.random.default_rng(3)
-    win = synth.make_window(rng, 1, 16, 20, 2, 1, 50, 0, sigma=1.0)
-    meta = dict(H=16, W=20, B=1, P=2, S=1, mode="two", spat=None, temp=None, round_ts=False)
-    with pytest.raises(NotImplementedError):
-        run_hip("Linear", make_cfg(meta), win, dev, border_compensation=False)
-
-
 @pytest.mark.parametrize("kind", ["Iterative", "Linear"])
 def test_general_float_masks(kind, dev):
     """Polarity masks are plain float multipliers in the reference (utils/iwe.py:127-128): non-unit values and events
