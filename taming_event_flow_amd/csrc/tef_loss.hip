@@ -670,27 +670,22 @@ __device__ __forceinline__ void splat_one(float2 p, float ts, float m, const Img
 // The same for a position ANYWHERE (Linear without border compensation: nothing is purged, every corner is tested on its
 // own like utils/iwe.py:103-107 does).  Rows outside the band are outside the frame or another workgroup's.
 template <bool FX>
-__device__ __forceinline__ void splat_any(float2 p, float ts, float m, const Img &im, double rdelta, double *img_c,
-                                          double *img_t, int r0, int nrows, int W, int WP)
+__device__ __noinline__ void splat_any(float2 p, float ts, float m, float tref, double rdelta, double *img_c, double *img_t,
+                                       int r0, int nrows, int W, int WP)
 {
     const float y = p.x, x = p.y;
-    const float fy[2] = {floorf(y), floorf(y + 1.0f)}, fx[2] = {floorf(x), floorf(x + 1.0f)};
+    const float fy0 = floorf(y), fx0 = floorf(x);
     // (also rejects NaN / infinite positions before anything is converted to an integer)
-    if (!(fy[1] >= (float)r0 && fy[0] < (float)(r0 + nrows) && fx[1] >= 0.0f && fx[0] < (float)W)) return;
-    const float tau = 1.0f - div_by_const(fabsf(im.tref - ts), rdelta);
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int rr = (int)fy[a] - r0;
-        if (rr < 0 || rr >= nrows) continue;
-        const float wy = fmaxf(1.0f - fabsf(y - fy[a]), 0.0f);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int ix = (int)fx[b];
-            if (ix < 0 || ix >= W) continue;
-            const float wgt = wy * fmaxf(1.0f - fabsf(x - fx[b]), 0.0f);
-            acc_add<FX>(img_c + rr * WP + ix, FX ? wgt : wgt * m);
-            acc_add<FX>(img_t + rr * WP + ix, FX ? wgt * tau : (wgt * tau) * m);
-        }
+    if (!(fy0 + 1.0f >= (float)r0 && fy0 < (float)(r0 + nrows) && fx0 + 1.0f >= 0.0f && fx0 < (float)W)) return;
+    const float tau = 1.0f - div_by_const(fabsf(tref - ts), rdelta);
+#pragma nounroll
+    for (int k = 0; k < 4; ++k) {                       // corners TL, TR, BL, BR (utils/iwe.py:85-94)
+        const float cy = (k & 2) ? floorf(y + 1.0f) : fy0, cx = (k & 1) ? floorf(x + 1.0f) : fx0;
+        const int rr = (int)cy - r0, ix = (int)cx;
+        if (rr < 0 || rr >= nrows || ix < 0 || ix >= W) continue;
+        const float wgt = fmaxf(1.0f - fabsf(y - cy), 0.0f) * fmaxf(1.0f - fabsf(x - cx), 0.0f);
+        acc_add<FX>(img_c + rr * WP + ix, FX ? wgt : wgt * m);
+        acc_add<FX>(img_t + rr * WP + ix, FX ? wgt * tau : (wgt * tau) * m);
     }
 }
 
@@ -713,7 +708,7 @@ __device__ __forceinline__ void splat_run_general(const Win &w, const Img &im, d
         float m = 1.0f;
         if (mv & kMetaNonUnit) m = mask[u];
         if (w.comp || w.kind == TEF_KIND_ITERATIVE) splat_one<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, WP);
-        else splat_any<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, w.W, WP);
+        else splat_any<false>(pl[u], tsp[u], m, im.tref, rdelta, img_c, img_t, r0, nrows, w.W, WP);
     }
 }
 
@@ -842,7 +837,7 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
             if (threadIdx.x == 0) run_cum[nruns] = carry;
         }
         __syncthreads();
-        const bool fixed = s_flags[0] == 0 && s_flags[1] < kFxMaxEvents;
+        const bool fixed = s_flags[0] == 0 && s_flags[1] < kFxMaxEvents && (w.comp || w.kind == TEF_KIND_ITERATIVE);
         const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
         const uint32_t *mt = meta + (size_t)ib * w.Mt;
         if (fixed) {
@@ -905,7 +900,13 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
                 return make_int2(ub, max(u0 - ub, 0) | (min(u1 - ub, 16) << 8) | ((r >= nb ? 1 : 0) << 16));
             };
             constexpr int kQ = 4;
-            const bool in_frame = w.comp || w.kind == TEF_KIND_ITERATIVE;      // every splatted position lies inside the frame
+            // MODE 0: border compensation (the reference's reachable setting): bit s of the meta word.  MODE 1: Iterative
+            // without: alive at this reference time (kb < tref < kf).  (Two copies of the loop: the test as a run-time
+            // branch inside one copy cost the default path 4 %.  Linear without compensation splats positions outside the
+            // frame and takes the general path below: with its corner tests in here the kernel needs 140 VGPRs and only one
+            // workgroup fits a CU.)
+            auto sweep = [&](auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
             int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
             float2 rg_cur[2], rg_nxt[2];
             for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(hh, r_cur[hh], row_cur[hh]);
@@ -927,11 +928,15 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
 #pragma unroll
                     for (int k = 0; k < kQ; ++k) nxt[k] = load_quad_rows(sidx + 4 * (kQ + k), h);
 #pragma unroll
-                    for (int k = 0; k < kQ; ++k)
-                        if (in_image(w, cur[k].mv, im.s, im.plane)) {          // border mask (:671-681)
-                            if (in_frame) splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
-                            else splat_any<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, W, WP);
+                    for (int k = 0; k < kQ; ++k) {
+                        const uint32_t mv = cur[k].mv;
+                        bool take = (mv >> im.s) & 1u;                         // border mask (:671-681)
+                        if (MODE == 1) {
+                            const int kb1 = (int)((mv >> 8) & 0xffu), kf = (int)((mv >> 16) & 0xffu);
+                            take = (mv & (kMetaPos | kMetaNeg)) != 0u && im.plane >= kb1 && im.plane < kf;
                         }
+                        if (take) splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
+                    }
 #pragma unroll
                     for (int k = 0; k < kQ; ++k) cur[k] = nxt[k];
                 }
@@ -942,6 +947,9 @@ __global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Even
                     row_cur[hh] = row_nxt[hh];
                 }
             }
+            };
+            if (w.comp) sweep(std::integral_constant<int, 0>());
+            else sweep(std::integral_constant<int, 1>());
         } else {
             for (int li = 0; li < nlists; ++li)
                 for (int t = im.le; t < im.he; ++t) {
