@@ -772,7 +772,8 @@ __global__ __launch_bounds__(256) void image_count_kernel(const uint8_t *__restr
 constexpr int kSplat2Threads = 512;             // K2: two such workgroups per CU
 constexpr size_t kSplat2LdsBudget = 70 * 1024;  // planes of one K2 workgroup (beside ~6 KiB of run tables and row lists)
 
-__global__ __launch_bounds__(kSplat2Threads) void splat_stats_kernel(Win w, Events g, Events d,
+// (second argument: at least 4 wavefronts per SIMD, i.e. at most 128 VGPRs — two of these workgroups per CU)
+__global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, Events g, Events d,
                                                                      const float2 *__restrict__ traj,
                                                                      const uint32_t *__restrict__ meta,
                                                                      const float2 *__restrict__ yr,
