@@ -165,10 +165,14 @@ def init_ranks(a):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("TEF_BENCH_BACKEND", "nccl")
+        # fail fast: a broken RCCL bring-up must not sit in a metered lease for the default 10 minutes
+        from datetime import timedelta
+
+        tmo = timedelta(seconds=float(os.environ.get("TEF_BENCH_DIST_TIMEOUT", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
         assert dist.get_world_size() == a.gpus and dist.get_rank() == rank
     return torch, dist, dev, rank, world
 
@@ -273,6 +277,13 @@ def main():
             print(f"[bench] step graph capture failed ({e!r}); running every step eagerly", file=sys.stderr)
             graphs = []
         torch.cuda.synchronize()
+    if dist and a.step_graph != "off":
+        # a rank whose capture failed must not skip the collectives of the probe below: all ranks agree first, and all
+        # drop their graphs if any of them has none
+        from taming_event_flow_amd import parallel
+
+        if parallel.any_rank(not graphs):
+            graphs = []
     if graphs and a.step_graph == "auto":
         # which launch path does this host sustain?  a short untimed probe of both; the graph is used when it is faster
         def probe_ms(fn, n=24):
@@ -314,8 +325,12 @@ def main():
         lib.tef_profile_pause(1)
     # device time of every step from a HIP event pair on the stream the kernels are launched on (torch's current stream):
     # SURVEY.md section 8d asks for the median over >= 20 steps beside the wall-clock mean that `value` is made of
+    # (a short run still profiles at least three steps, so the per-kernel times — and the roofline fractions made of them —
+    # are means over several launches, never one sample)
+    event_every = max(1, min(a.event_every, (a.steps + 2) // 3))
+
     def is_profiled(k):
-        return not a.no_kernel_events and k % max(1, a.event_every) == 0
+        return not a.no_kernel_events and k % event_every == 0
 
     # the timed region as a list of units: (first step, number of steps, how it is launched)
     units, k = [], 0
@@ -370,6 +385,11 @@ def main():
     events_per_step = B * P * (a.events + a.detached)
     total_events = events_per_step * a.steps * world
     value = total_events / elapsed
+    # more than one rank: the loss step above has no collective (the batch shards), so its 1 -> N curve says nothing about
+    # the gradient all-reduce; the DP TRAINING window does, and every rank takes part in measuring it
+    dp_extra = None
+    if world > 1 and not a.no_train_extra and a.warping == "Iterative":
+        dp_extra = dp_train_extra(a, torch, dist, dev, rank, world)
 
     if rank == 0:
         delta = a.passes // 2
@@ -400,7 +420,7 @@ def main():
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
                        "launch": (("hipGraph replay, %d consecutive steps per graph" % G if groups else
                                    "hipGraph replay of the step") +
-                                  ("; every %d-th step eager with per-kernel HIP events" % max(1, a.event_every)
+                                  ("; every %d-th step eager with per-kernel HIP events" % event_every
                                    if not a.no_kernel_events else "")) if graphs else "eager"},
             "loss": round(loss_val, 6),
             "ms_per_step_hip_event_median": round(step_ms_median, 4),
@@ -410,7 +430,7 @@ def main():
             "value_including_update": round(events_per_step * world / (elapsed / a.steps + t_update), 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
             "launch_probe": probe,
-            "kernel_events_every": None if a.no_kernel_events else max(1, a.event_every),
+            "kernel_events_every": None if a.no_kernel_events else event_every,
             "roofline": roofline,
             "kernels": kernels,
         }
@@ -439,6 +459,8 @@ def main():
             out["cpu_baseline_1thread"] = cpu_baseline(a, host_windows[0], threads=1, seconds=min(a.cpu_seconds, 6.0), batch=2)
         if world == 1 and not a.no_train_extra and a.warping == "Iterative":
             out["extra"] = train_extra(a, torch, dev)
+        elif dp_extra is not None:
+            out["extra"] = dp_extra
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
@@ -700,6 +722,80 @@ def train_extra(a, torch, dev):
                 "conv_frac_of_fp32_mfma_peak": round(flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
+
+
+def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
+    """world > 1: the data-parallel TRAINING window (BASELINE configs[3] at this batch size; reference train_flow.py:83-87,
+    :120-137 applied to the global batch) — two hipGraphs around the eager gradient all-reduce (train.CapturedWindow) — so
+    that the driver's `bench.py --gpus N` line carries the number DP scaling is about.  Called by EVERY rank at the same
+    point (it contains collectives); returns the dict on every rank, rank 0 prints it.  A failure on any rank is agreed on
+    by all ranks and reported as a string; it never takes the headline down."""
+    import copy
+
+    from taming_event_flow_amd import parallel, train
+
+    out = {"workload": "DP training window: RecEVFlowNet fwd + loss + BPTT as one hipGraph, all-reduce(SUM) of the flat "
+                       "gradient bucket enqueued eagerly, clip + Adam + state hand-over as a second hipGraph (BASELINE "
+                       "configs[3] at B=%d per GPU)" % a.batch,
+           "backend": dist.get_backend(), "rccl_world_size": dist.get_world_size()}
+    # proof that N ranks contribute to a collective on the data path's backend: sum of (rank + 1) == N (N + 1) / 2
+    chk = torch.tensor([float(rank + 1)], device=dev)
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    out["rank_checksum"] = float(chk.item())
+    out["rank_checksum_expected"] = world * (world + 1) / 2
+    failed, err, window, tr = False, None, None, None
+    try:
+        cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+        cfg["loader"].update(batch_size=a.batch, resolution=list(a.res), max_num_grad_events=a.events)
+        cfg["data"]["passes_loss"] = a.passes
+        cfg["optimizer"]["capturable"] = True
+        torch.manual_seed(1234)                          # identical initial weights on every rank
+        tr = train.Trainer(cfg, dev)
+        src = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100 + rank)
+        tr.reset()
+        window = tr.capture_window([src.next() for _ in range(a.passes)], warmup=1)
+    except Exception as e:                                    # noqa: BLE001
+        failed, err = True, repr(e)
+    if parallel.any_rank(failed):                        # (host-side exchange: every rank reaches it)
+        out["error"] = err or "window capture failed on another rank"
+        return out
+    try:
+        window()
+        torch.cuda.synchronize()
+        dist.barrier()
+        window.allreduce_events = []
+        t0 = time.perf_counter()
+        for _ in range(windows):
+            window()
+        torch.cuda.synchronize()
+        dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        ms = 1e3 * float(el.item()) / windows
+        ar = sorted(e0.elapsed_time(e1) for e0, e1 in window.allreduce_events)
+        ar_ms = torch.tensor([ar[len(ar) // 2]], dtype=torch.float64, device=dev)
+        dist.all_reduce(ar_ms, op=dist.ReduceOp.MAX)
+        ar_ms = float(ar_ms.item())
+        nbytes = tr.bucket.flat.numel() * tr.bucket.flat.element_size()
+        # replicas must still agree after the updates: every rank applied the same reduced gradient
+        p0 = next(iter(tr.model.parameters())).detach().reshape(-1)[:4096].double().sum().reshape(1)
+        lo, hi = p0.clone(), p0.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ev = a.batch * a.passes * (a.events + a.detached) * world
+        out.update({
+            "dp_train_window_ms": round(ms, 3), "dp_train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": windows,
+            "allreduce_ms": round(ar_ms, 3), "allreduce_bytes": nbytes,
+            # bus bandwidth of a ring all-reduce: every rank sends and receives 2 (N - 1) / N of the buffer
+            "allreduce_GBps": round(nbytes * 2.0 * (world - 1) / world / (ar_ms * 1e-3) / 1e9, 2),
+            "replicas_bit_identical": bool(lo.item() == hi.item()),
+            "loss_rank0": round(float(tr.last_loss.item()), 6),
+        })
+    except Exception as e:                                    # noqa: BLE001
+        out["error"] = repr(e)
+    del tr, window
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(a, win, threads=None, seconds=None, batch=None):

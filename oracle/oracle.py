@@ -26,7 +26,7 @@ class _Window(ctypes.Structure):
         ("M", ctypes.c_int), ("Md", ctypes.c_int),
         ("off", _i), ("doff", _i), ("flows", _f),
         ("ts", _f), ("y", _f), ("x", _f), ("mp", _f), ("mn", _f), ("loss_scaling", ctypes.c_int),
-        ("border_compensation", ctypes.c_int),
+        ("border_compensation", ctypes.c_int), ("dmass", _f),
     ]
 
 
@@ -124,12 +124,26 @@ class Window:
         self._w = _Window(B, H, W, P, F, S, self.mode_div, self.M, self.Md,
                           self.off.ctypes.data_as(_i), self.doff.ctypes.data_as(_i), _p(self.flows),
                           _p(self.ts), _p(self.y), _p(self.x), _p(self.mp), _p(self.mn), 1 if loss_scaling else 0,
-                          1 if border_compensation else 0)
+                          1 if border_compensation else 0, None)
+        self.mass = None
 
     def _run(self, fn, backward, grad_out):
         d = np.zeros_like(self.flows) if backward else None
         loss = fn(ctypes.byref(self._w), _p(d), ctypes.c_float(grad_out))
         return np.float32(loss), d
+
+    def gradient_mass(self, kind="Iterative"):
+        """-> [P,F,B,2,H,W]: per pixel of d loss / d flow, the sum over the events of |contribution| (grad_out = 1; the
+        smoothing terms not included).  |gradient| <= mass; where contributions cancel, mass >> |gradient| and two fp32
+        evaluations cannot agree to 1e-4 of the pixel's own value: tests/conftest.py::elementwise_excess compares
+        gradients element by element against this local scale."""
+        self.mass = np.zeros_like(self.flows)
+        self._w.dmass = _p(self.mass)
+        try:
+            (self.iterative if kind == "Iterative" else self.linear)(True, 1.0)
+        finally:
+            self._w.dmass = None
+        return self.mass
 
     def iterative(self, backward=True, grad_out=1.0):
         """-> (loss, dflows [P,F,B,2,H,W]) of loss/flow.py:588 Iterative.forward (no smoothing terms)."""

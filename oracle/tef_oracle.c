@@ -233,6 +233,12 @@ typedef struct {
     int loss_scaling;            /* loss/flow.py:124-127: divide each image's sum by its number of active pixels */
     int border_compensation;     /* loss/flow.py:671-681 shared mask over a window's reference times (1, the reachable
                                     setting) or each reference time's own cumulative mask (0; Iterative only) */
+    float *dmass;                /* optional, laid out like dflows: the gradient's MASS — the same backward pass with every
+                                    term replaced by its absolute value (|tau| + |A| for tau - A, |slope| for the hat
+                                    derivatives, |J| in the chain, |g| in the scatters), i.e. the sum of the magnitudes
+                                    whose signed sum each pixel of d loss / d flow is.  It is the local scale against
+                                    which an element-wise comparison of two fp32 gradients is meaningful (a pixel where
+                                    large terms cancel cannot agree to 1e-4 of its own value); not a reference output */
 } tef_window;
 
 static inline const float *tef_map(const tef_window *wd, int t, int i, int b, int c)
@@ -242,6 +248,13 @@ static inline const float *tef_map(const tef_window *wd, int t, int i, int b, in
 static inline float *tef_dmap(const tef_window *wd, float *dflows, int t, int i, int b, int c)
 {
     return dflows + ((((size_t)t * wd->F + i) * wd->B + b) * 2 + c) * (size_t)wd->H * wd->W;
+}
+/* bilinear scatter of one event's flow-gradient component into map (t, i, b, c) [+ its magnitude into dmass] */
+static inline void tef_scatter_grad(const tef_window *wd, float *dflows, int t, int i, int b, int c, const tef_taps *tp,
+                                    float g, float m)
+{
+    tef_tap_scatter(tef_dmap(wd, dflows, t, i, b, c), tp, g);
+    if (wd->dmass) tef_tap_scatter(tef_dmap(wd, wd->dmass, t, i, b, c), tp, m);
 }
 
 /* One image of warped events for sample b: accumulate grad list and detached list separately
@@ -294,7 +307,7 @@ static float tef_image_loss(const tef_window *wd, tef_imgbuf *ib, float *n_out)
 /* d(coef * image loss) / d position for the grad events of bins [lo, hi); accumulated into gy/gx */
 static void tef_image_backward(const tef_window *wd, int b, const tef_imgbuf *ib, float kimg, const float *py,
                                const float *px, const unsigned char *valid, int lo, int hi, float tref, float scale,
-                               float *gy, float *gx)
+                               float *gy, float *gx, float *my, float *mx)
 {
     int HW = wd->H * wd->W, Mt = wd->M + wd->Md;
     for (int sl = wd->off[lo]; sl < wd->off[hi]; ++sl) {
@@ -303,7 +316,7 @@ static void tef_image_backward(const tef_window *wd, int b, const tef_imgbuf *ib
         tef_splat s;
         tef_make_splat(py[sl], px[sl], wd->H, wd->W, &s);
         float tau = 1.0f - fabsf(tref - wd->ts[o]) / scale;
-        float ay = 0.0f, ax = 0.0f;
+        float ay = 0.0f, ax = 0.0f, may = 0.0f, max_ = 0.0f;
         for (int k = 0; k < 4; ++k) {
             if (s.idx[k] < 0) continue;
             int p = s.idx[k];
@@ -313,9 +326,17 @@ static void tef_image_backward(const tef_window *wd, int b, const tef_imgbuf *ib
             dw *= kimg;
             ay += dw * s.dwy[k];
             ax += dw * s.dwx[k];
+            if (my) {       /* mass: the same expression with every term's magnitude */
+                float dm = fabsf(wd->mp[o]) * (2.0f * fabsf(ib->A[p]) * (fabsf(tau) + fabsf(ib->A[p])) * ib->R[p])
+                         + fabsf(wd->mn[o]) * (2.0f * fabsf(ib->A[HW + p]) * (fabsf(tau) + fabsf(ib->A[HW + p])) * ib->R[HW + p]);
+                dm *= fabsf(kimg);
+                may += dm * fabsf(s.dwy[k]);
+                max_ += dm * fabsf(s.dwx[k]);
+            }
         }
         gy[sl] += ay;
         gx[sl] += ax;
+        if (my) { my[sl] += may; mx[sl] += max_; }
     }
 }
 
@@ -353,6 +374,9 @@ static double tef_iterative_pair(const tef_window *wd, const int *bin, int i, in
     int *kb = (int *)malloc(sizeof(int) * (Mt + 1)), *kf = (int *)malloc(sizeof(int) * (Mt + 1));
     float *gy = (float *)malloc(sizeof(float) * (size_t)(P + 1) * (M + 1));
     float *gx = (float *)malloc(sizeof(float) * (size_t)(P + 1) * (M + 1));
+    const int want_mass = dflows && wd->dmass;
+    float *gmy = want_mass ? (float *)calloc((size_t)(P + 1) * (M + 1), sizeof(float)) : 0;
+    float *gmx = want_mass ? (float *)calloc((size_t)(P + 1) * (M + 1), sizeof(float)) : 0;
     unsigned char *valid = (unsigned char *)malloc(Mt + 1);
     tef_imgbuf ib = tef_imgbuf_new(HW);
     double loss_i = 0.0;
@@ -424,7 +448,8 @@ static double tef_iterative_pair(const tef_window *wd, const int *bin, int i, in
                         loss_i += (double)l * coef;
                         if (dflows)
                             tef_image_backward(wd, b, &ib, grad_out * coef / n, py, px, valid, le, he, (float)tref,
-                                               (float)delta, gy + (size_t)tref * M, gx + (size_t)tref * M);
+                                               (float)delta, gy + (size_t)tref * M, gx + (size_t)tref * M,
+                                               want_mass ? gmy + (size_t)tref * M : 0, want_mass ? gmx + (size_t)tref * M : 0);
                     }
                 }
             }
@@ -435,57 +460,67 @@ static double tef_iterative_pair(const tef_window *wd, const int *bin, int i, in
                 int t = bin[sl];
                 float ts = wd->ts[o];
                 float c0y = 0.0f, c0x = 0.0f;   /* gradient w.r.t. the flow sampled at the original location (map t) */
+                float m0y = 0.0f, m0x = 0.0f, my = 0.0f, mx = 0.0f;      /* their masses (wd->dmass only) */
                 /* forward chain: p_{k} = p_{k-1} + c * f_{k-1}(p_{k-1}),  k = t+1..P */
                 float ay = 0.0f, ax = 0.0f;
                 for (int k = P; k > t; --k) {
                     if (k >= kf[sl]) continue;
                     ay += gy[(size_t)k * M + sl];
                     ax += gx[(size_t)k * M + sl];
+                    if (want_mass) { my += gmy[(size_t)k * M + sl]; mx += gmx[(size_t)k * M + sl]; }
                     if (k - 1 == t) {
                         float c = (float)(t + 1) - ts;
                         c0y += c * ay; c0x += c * ax;
+                        m0y += fabsf(c) * my; m0x += fabsf(c) * mx;
                     } else {
                         tef_taps tp;
                         tef_make_taps(ty[(size_t)(k - 1) * Mt + sl], tx[(size_t)(k - 1) * Mt + sl], H, W, &tp);
-                        tef_tap_scatter(tef_dmap(wd, dflows, k - 1, i, b, 1), &tp, ay);
-                        tef_tap_scatter(tef_dmap(wd, dflows, k - 1, i, b, 0), &tp, ax);
+                        tef_scatter_grad(wd, dflows, k - 1, i, b, 1, &tp, ay, my);
+                        tef_scatter_grad(wd, dflows, k - 1, i, b, 0, &tp, ax, mx);
                         float jyy, jyx, jxy, jxx;
                         tef_tap_jacobian(tef_map(wd, k - 1, i, b, 1), &tp, &jyy, &jyx);
                         tef_tap_jacobian(tef_map(wd, k - 1, i, b, 0), &tp, &jxy, &jxx);
                         float ny = ay + (ay * jyy + ax * jxy), nx = ax + (ay * jyx + ax * jxx);
                         ay = ny; ax = nx;
+                        float nmy = my + (my * fabsf(jyy) + mx * fabsf(jxy)), nmx = mx + (my * fabsf(jyx) + mx * fabsf(jxx));
+                        my = nmy; mx = nmx;
                     }
                 }
                 /* backward chain: p_k = q + c * f_k(q), q = p_{k+1} (k < t) or the original location (k = t) */
                 ay = 0.0f; ax = 0.0f;
+                my = 0.0f; mx = 0.0f;
                 for (int k = 0; k <= t; ++k) {
                     if (k <= kb[sl]) continue;
                     ay += gy[(size_t)k * M + sl];
                     ax += gx[(size_t)k * M + sl];
+                    if (want_mass) { my += gmy[(size_t)k * M + sl]; mx += gmx[(size_t)k * M + sl]; }
                     if (k == t) {
                         float c = (float)t - ts;
                         c0y += c * ay; c0x += c * ax;
+                        m0y += fabsf(c) * my; m0x += fabsf(c) * mx;
                     } else {
                         tef_taps tp;
                         tef_make_taps(ty[(size_t)(k + 1) * Mt + sl], tx[(size_t)(k + 1) * Mt + sl], H, W, &tp);
-                        tef_tap_scatter(tef_dmap(wd, dflows, k, i, b, 1), &tp, -ay);
-                        tef_tap_scatter(tef_dmap(wd, dflows, k, i, b, 0), &tp, -ax);
+                        tef_scatter_grad(wd, dflows, k, i, b, 1, &tp, -ay, my);
+                        tef_scatter_grad(wd, dflows, k, i, b, 0, &tp, -ax, mx);
                         float jyy, jyx, jxy, jxx;
                         tef_tap_jacobian(tef_map(wd, k, i, b, 1), &tp, &jyy, &jyx);
                         tef_tap_jacobian(tef_map(wd, k, i, b, 0), &tp, &jxy, &jxx);
                         float ny = ay - (ay * jyy + ax * jxy), nx = ax - (ay * jyx + ax * jxx);
                         ay = ny; ax = nx;
+                        float nmy = my + (my * fabsf(jyy) + mx * fabsf(jxy)), nmx = mx + (my * fabsf(jyx) + mx * fabsf(jxx));
+                        my = nmy; mx = nmx;
                     }
                 }
                 tef_taps tp;
                 tef_make_taps(wd->y[o], wd->x[o], H, W, &tp);
-                tef_tap_scatter(tef_dmap(wd, dflows, t, i, b, 1), &tp, c0y);
-                tef_tap_scatter(tef_dmap(wd, dflows, t, i, b, 0), &tp, c0x);
+                tef_scatter_grad(wd, dflows, t, i, b, 1, &tp, c0y, m0y);
+                tef_scatter_grad(wd, dflows, t, i, b, 0, &tp, c0x, m0x);
             }
         }
     }
 done:
-    free(ty); free(tx); free(kb); free(kf); free(gy); free(gx); free(valid);
+    free(ty); free(tx); free(kb); free(kf); free(gy); free(gx); free(gmy); free(gmx); free(valid);
     tef_imgbuf_free(&ib);
     return loss_i;
 }
@@ -521,6 +556,9 @@ float tef_oracle_linear(const tef_window *wd, float *dflows, float grad_out)
     float *py = (float *)malloc(sizeof(float) * 2 * Mt), *px = (float *)malloc(sizeof(float) * 2 * Mt);
     float *gy = (float *)malloc(sizeof(float) * 2 * (M + 1)), *gx = (float *)malloc(sizeof(float) * 2 * (M + 1));
     float *cy = (float *)malloc(sizeof(float) * (M + 1)), *cx = (float *)malloc(sizeof(float) * (M + 1));
+    const int want_mass = dflows && wd->dmass;       /* the gradient's mass (see tef_window.dmass) */
+    float *gmy = want_mass ? (float *)malloc(sizeof(float) * 2 * (M + 1)) : 0, *gmx = want_mass ? (float *)malloc(sizeof(float) * 2 * (M + 1)) : 0;
+    float *cmy = want_mass ? (float *)malloc(sizeof(float) * (M + 1)) : 0, *cmx = want_mass ? (float *)malloc(sizeof(float) * (M + 1)) : 0;
     int *bin = (int *)malloc(sizeof(int) * Mt);
     unsigned char *valid = (unsigned char *)malloc(Mt + 1);
     tef_imgbuf ib = tef_imgbuf_new(HW);
@@ -538,6 +576,7 @@ float tef_oracle_linear(const tef_window *wd, float *dflows, float grad_out)
                 efx[sl] = tef_tap_value(tef_map(wd, bin[sl], i, b, 0), &tp);
             }
             if (dflows) { memset(cy, 0, sizeof(float) * (M + 1)); memset(cx, 0, sizeof(float) * (M + 1)); }
+            if (want_mass) { memset(cmy, 0, sizeof(float) * (M + 1)); memset(cmx, 0, sizeof(float) * (M + 1)); }
             for (int s = 0; s < S; ++s) {
                 int scale = P >> s;
                 float coef = 1.0f / ((float)(1 << s) * 2.0f * (float)S * (float)F);   /* :396-397, :401-402 */
@@ -558,6 +597,7 @@ float tef_oracle_linear(const tef_window *wd, float *dflows, float grad_out)
                                     (tef_inbounds(py[sl], px[sl], H, W) && tef_inbounds(py[Mt + sl], px[Mt + sl], H, W));
                     }
                     if (dflows) { memset(gy, 0, sizeof(float) * 2 * (M + 1)); memset(gx, 0, sizeof(float) * 2 * (M + 1)); }
+                    if (want_mass) { memset(gmy, 0, sizeof(float) * 2 * (M + 1)); memset(gmx, 0, sizeof(float) * 2 * (M + 1)); }
                     for (int e = 0; e < 2; ++e) {
                         float tref = (float)(e == 0 ? hi : lo);
                         const float *qy = py + (size_t)e * Mt, *qx = px + (size_t)e * Mt;
@@ -568,13 +608,18 @@ float tef_oracle_linear(const tef_window *wd, float *dflows, float grad_out)
                         loss += (double)l * coef;
                         if (dflows)
                             tef_image_backward(wd, b, &ib, grad_out * coef / n, qy, qx, valid, lo, hi, tref, (float)scale,
-                                               gy + (size_t)e * M, gx + (size_t)e * M);
+                                               gy + (size_t)e * M, gx + (size_t)e * M,
+                                               want_mass ? gmy + (size_t)e * M : 0, want_mass ? gmx + (size_t)e * M : 0);
                     }
                     if (dflows)
                         for (int sl = wd->off[lo]; sl < wd->off[hi]; ++sl) {
                             float ts = wd->ts[(size_t)b * Mt + sl];
                             cy[sl] += ((float)hi - ts) * gy[sl] + ((float)lo - ts) * gy[M + sl];
                             cx[sl] += ((float)hi - ts) * gx[sl] + ((float)lo - ts) * gx[M + sl];
+                            if (want_mass) {
+                                cmy[sl] += fabsf((float)hi - ts) * gmy[sl] + fabsf((float)lo - ts) * gmy[M + sl];
+                                cmx[sl] += fabsf((float)hi - ts) * gmx[sl] + fabsf((float)lo - ts) * gmx[M + sl];
+                            }
                         }
                 }
             }
@@ -583,11 +628,12 @@ float tef_oracle_linear(const tef_window *wd, float *dflows, float grad_out)
                     size_t o = (size_t)b * Mt + sl;
                     tef_taps tp;
                     tef_make_taps(wd->y[o], wd->x[o], H, W, &tp);
-                    tef_tap_scatter(tef_dmap(wd, dflows, bin[sl], i, b, 1), &tp, cy[sl]);
-                    tef_tap_scatter(tef_dmap(wd, dflows, bin[sl], i, b, 0), &tp, cx[sl]);
+                    tef_scatter_grad(wd, dflows, bin[sl], i, b, 1, &tp, cy[sl], want_mass ? cmy[sl] : 0.0f);
+                    tef_scatter_grad(wd, dflows, bin[sl], i, b, 0, &tp, cx[sl], want_mass ? cmx[sl] : 0.0f);
                 }
         }
     free(efy); free(efx); free(py); free(px); free(gy); free(gx); free(cy); free(cx); free(bin); free(valid);
+    free(gmy); free(gmx); free(cmy); free(cmx);
     tef_imgbuf_free(&ib);
     return (float)loss;
 }

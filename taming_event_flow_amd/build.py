@@ -47,16 +47,41 @@ def needs_build():
 def build_hip(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
+    import hashlib
+
     hipcc = os.environ.get("HIPCC", "hipcc")
     objs = []
     os.makedirs(os.path.join(PKG, "build"), exist_ok=True)
+    hdr = hashlib.sha256(" ".join(FLAGS).encode())
+    for p in sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        with open(p, "rb") as f:
+            hdr.update(f.read())
+    procs = []
     for src in sources():
         obj = os.path.join(PKG, "build", os.path.basename(src) + ".o")
+        objs.append(obj)
+        # one object per translation unit, recompiled only when the unit, a header or the flags changed
+        h = hdr.copy()
+        with open(src, "rb") as f:
+            h.update(f.read())
+        stamp, digest = obj + ".srchash", h.hexdigest()
+        if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+            continue
         cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        procs.append((subprocess.Popen(cmd), cmd, stamp, digest))
+        if len(procs) >= 4:                      # a few units at a time (the container has 8 cores)
+            pr, c, st, dg = procs.pop(0)
+            if pr.wait():
+                raise subprocess.CalledProcessError(pr.returncode, c)
+            with open(st, "w") as f:
+                f.write(dg)
+    for pr, c, st, dg in procs:
+        if pr.wait():
+            raise subprocess.CalledProcessError(pr.returncode, c)
+        with open(st, "w") as f:
+            f.write(dg)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

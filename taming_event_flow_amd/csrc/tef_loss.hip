@@ -405,6 +405,21 @@ __device__ __forceinline__ void flush_row_ranges(const Win &w, float2 (*rng)[16]
     }
 }
 
+// Inputs the integer accumulators cannot represent (to_fixed needs |w * tau| < 32 and finite values): a timestamp or a
+// location that is not finite, or a timestamp more than 16 passes away from its own pass (normalised lists hold
+// ts in [t, t + 1]; |tau| <= 1 + (window + 16) / delta < 32 then).  The reference propagates such inputs to a NaN — or,
+// for unnormalised timestamps, to a finite but meaningless — loss; here K1 records one word per workgroup and K4 turns
+// the loss into NaN if any is set, so that bad inputs surface instead of becoming arbitrary integers.
+__device__ __forceinline__ bool event_is_sane(float ts, float y, float x, int t)
+{
+    return fabsf(ts - (float)t) <= 16.0f && fabsf(y) < 3.0e38f && fabsf(x) < 3.0e38f;      // (false for NaN as well)
+}
+__device__ __forceinline__ void flag_bad_events(int *__restrict__ bad, int slot, bool is_bad)
+{
+    const int any = __syncthreads_or(is_bad ? 1 : 0);      // (every workgroup writes its word: nothing to clear)
+    if (threadIdx.x == 0) bad[slot] = any;
+}
+
 // =============================================================================================
 // K1 (Iterative): iterative warping of every event to every reference time.
 // loss/flow.py:521-586 event_warping, :492-519 update_warping_indices, :599-654.
@@ -415,7 +430,8 @@ __device__ __forceinline__ void flush_row_ranges(const Win &w, float2 (*rng)[16]
 // =============================================================================================
 __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
                                                         float2 *__restrict__ traj, uint32_t *__restrict__ meta,
-                                                        float2 *__restrict__ yr, int *__restrict__ queue, int chunks)
+                                                        float2 *__restrict__ yr, int *__restrict__ queue,
+                                                        int *__restrict__ bad, int chunks)
 {
     if (blockIdx.x == 0 && threadIdx.x < kQueueInts) queue[threadIdx.x] = 0;      // work queues of the later kernels
     int ib, chunk;
@@ -437,6 +453,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
     const int H = w.H, W = w.W, P = w.P;
     float ts = E.ts[o], y0 = E.y[o], x0 = E.x[o];
     const int t = __builtin_amdgcn_readfirstlane((int)E.bin[sl]);      // passes start at multiples of 64 slots: wave-uniform
+    flag_bad_events(bad, ib * chunks + chunk, valid && !event_is_sane(ts, y0, x0, t));
     float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
 
     // Bilinear flow lookup of map k at (y, x).  The kernel is VALU-bound (~135 vector instructions per chain step): when
@@ -523,7 +540,8 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
 // =============================================================================================
 __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
                                                           float2 *__restrict__ traj, uint32_t *__restrict__ meta,
-                                                          float2 *__restrict__ yr, int *__restrict__ queue, int chunks)
+                                                          float2 *__restrict__ yr, int *__restrict__ queue,
+                                                          int *__restrict__ bad, int chunks)
 {
     if (blockIdx.x == 0 && threadIdx.x < kQueueInts) queue[threadIdx.x] = 0;
     int ib, chunk;
@@ -544,6 +562,7 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
     const int H = w.H, W = w.W;
     float ts = E.ts[o], y0 = E.y[o], x0 = E.x[o];
     const int t = E.bin[sl];
+    flag_bad_events(bad, ib * chunks + chunk, valid && !event_is_sane(ts, y0, x0, t));
     store_row_range(rng, w.nplanes, valid, y0, in_list);
     float2 f = make_float2(0.0f, 0.0f);
     if (valid) {
@@ -989,10 +1008,13 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
 // loss = sum_images coef * (sum over samples of the per-sample term); fixed summation order.
 __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *__restrict__ part, int nparts,
                                                           const double *__restrict__ counts, float *__restrict__ stats,
-                                                          float *__restrict__ loss_out)
+                                                          const int *__restrict__ bad, int nbad, float *__restrict__ loss_out)
 {
     __shared__ double ssum[256];
     const int FB = w.F * w.B;
+    int any_bad = 0;                                  // K1's per-workgroup "unrepresentable input" words
+    for (int k = threadIdx.x; k < nbad; k += blockDim.x) any_bad |= bad[k];
+    any_bad = __syncthreads_or(any_bad);
     double acc = 0.0;
     for (int q = threadIdx.x; q < w.nimg * FB; q += blockDim.x) {
         double s2 = 0.0, cnt = 0.0;
@@ -1011,7 +1033,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
         if ((int)threadIdx.x < s) ssum[threadIdx.x] += ssum[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss_out[0] = (float)ssum[0];
+    if (threadIdx.x == 0) loss_out[0] = any_bad ? __uint_as_float(0x7fc00000u) : (float)ssum[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1254,13 +1276,20 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     const int H = w.H, W = w.W, P = w.P, M = w.M;
     float2 *co = cyx + (size_t)ib * P * M + sl;
     uint32_t mv = meta[(size_t)ib * w.Mt + sl];
-    uint32_t bits = mv & 0xffu;
-    if (!w.comp) bits = (mv & (kMetaPos | kMetaNeg)) ? (1u << w.S) - 1u : 0u;      // every scale, as far as the chain is alive
     // Passes start at multiples of 64 slots, so a wavefront belongs to ONE pass: t, and with it the reference time k of
     // every loop iteration below, is wave-uniform — map / image / plane base addresses and the image statistics are
     // scalar-register arithmetic and scalar loads instead of per-lane 64-bit index math in a VALU-bound kernel.  Lanes
     // whose chain has not started yet or has left the frame are masked per iteration.
     const int t = __builtin_amdgcn_readfirstlane((int)g.bin[sl]);
+    uint32_t bits = mv & 0xffu;
+    if (!w.comp) {
+        // without border compensation: every scale whose windows hold pass t (the trailing passes of a window length that
+        // does not divide P belong to no window of that scale, exactly as in K1's bits), as far as the chain is alive
+        uint32_t all = 0u;
+        for (int s = 0; s < w.S; ++s)
+            if (t / (P >> s) < (1 << s)) all |= 1u << s;
+        bits = (mv & (kMetaPos | kMetaNeg)) ? all : 0u;
+    }
     // map k receives something from pass t only if |k - t| < delta_passes[0] (largest window and reach); K7 reads
     // exactly those (pass, map) pairs, so only they need a value
     const int reach = P / w.mode_div;
@@ -1920,7 +1949,7 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cyx, total;
+    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cyx, bad, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2025,6 +2054,7 @@ Layout make_layout(const Win &w)
     L.cmax = L.queue + kQueueInts * sizeof(int);
     L.wmax = o;   o += align_up(FB * (size_t)(w.M / 64 + 1) * sizeof(uint32_t));
     L.cyx = o;    o += align_up(nc * sizeof(float2));
+    L.bad = o;    o += align_up(FB * (size_t)((w.Mt + 255) / 256 + 1) * sizeof(int));      // one word per K1 workgroup
     L.total = o;
     return L;
 }
@@ -2163,19 +2193,21 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     uint32_t *meta = (uint32_t *)(ws + L.meta);
     float2 *yr = (float2 *)(ws + L.yr);
     int *queue = (int *)(ws + L.queue);
+    int *bad = (int *)(ws + L.bad);
     float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
     const float2 *fl = (const float2 *)flows_yx;
     Events g = to_events(grad), d = to_events(w.Md > 0 ? det : nullptr);
     const int FB = w.F * w.B;
+    const int nbad = w.Mt > 0 ? FB * ((w.Mt + 255) / 256) : 0;
 
     if (w.Mt > 0) {
         int chunks = (w.Mt + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
         if (w.kind == TEF_KIND_ITERATIVE)
-            TEF_LAUNCH_TIMED(tef::PROF_WARP, iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, yr, queue, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_WARP, iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, yr, queue, bad, chunks);
         else
-            TEF_LAUNCH_TIMED(tef::PROF_WARP, linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, yr, queue, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_WARP, linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, yr, queue, bad, chunks);
     }
     if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
@@ -2198,7 +2230,7 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     TEF_LAUNCH_TIMED(tef::PROF_COUNT, image_count_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, nz, w.H * w.W, counts);
     if (int rc = tef::check_launch("image_count_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_REDUCE, loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), nbands,
-                     counts, stats, loss_out);
+                     counts, stats, bad, nbad, loss_out);
     return tef::check_launch("loss_reduce_kernel");
 }
 

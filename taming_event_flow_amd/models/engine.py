@@ -236,8 +236,10 @@ class PassEngine:
             tape.geom = (ph, pw)
         return flows, hn_all, tape
 
-    def backward(self, tape, dflows, dstates, sink):
-        """-> gradients w.r.t. the incoming states (4).  Parameter gradients go through `sink`."""
+    def backward(self, tape, dflows, dstates, sink, want_dx=False):
+        """-> (gradients w.r.t. the incoming states (4), gradient w.r.t. the padded network input or None).  Parameter
+        gradients go through `sink`.  want_dx: also run the first encoder's input-gradient contraction (the reference's
+        autograd delivers d loss / d input when the caller asks for it, models/arch.py:217-227)."""
         a = self.arch
         ph, pw = tape.geom
         nlev = len(a.decoders)
@@ -285,7 +287,9 @@ class PassEngine:
             xin, e, h, u, r, o, hn = tape.enc[i]
             sources = list(from_above)
             sg = skip_grads[nlev - 1 - i]
-            if sg is not None and not (i == nlev - 1 and any(sg is t for t in sources)):
+            # (the deepest state is decoder 0's skip addend AND the input of the residual blocks; without residual blocks
+            # `from_above` is that same gradient once more — features + skip = 2 x the state — and it is added twice)
+            if sg is not None:
                 sources.append(sg)
             if dstates[i] is not None:
                 sources.append(dstates[i].contiguous())
@@ -294,9 +298,11 @@ class PassEngine:
                 continue
             de, dh_in[i] = self.cell_bwd(enc.recurrent_block, e, h, u, r, o, sources, sink)
             ge = self.grad_act([de], e, "relu", sink.bias_target(enc.conv.conv2d.bias))
-            dxin, _ = self.conv_bwd(enc.conv._packed, (enc.conv.conv2d.weight,), ge, xin, None, self.plan.stride, i > 0, sink)
-            from_above = [dxin] if i > 0 else []
-        return dh_in
+            dxin, _ = self.conv_bwd(enc.conv._packed, (enc.conv.conv2d.weight,), ge, xin, None, self.plan.stride,
+                                    i > 0 or want_dx, sink)
+            from_above = [dxin] if dxin is not None else []
+        # (what is left in `from_above` after level 0 is the gradient of the padded input)
+        return dh_in, (from_above[0] if want_dx and from_above else None)
 
 
 class GradSink:
@@ -357,6 +363,7 @@ class _PassFn(torch.autograd.Function):
         ctx.engine, ctx.tape, ctx.nstates = engine, tape, nstates
         ctx.params = rest[nstates:]
         ctx.state_given = [s is not None for s in states]
+        ctx.x_shape = tuple(x.shape) if x.requires_grad else None
         return tuple(flows) + tuple(new_states)
 
     @staticmethod
@@ -366,16 +373,22 @@ class _PassFn(torch.autograd.Function):
         params = ctx.params
         direct = all(p.grad is not None and p.grad.is_contiguous() for p in params if p.requires_grad) and engine.arch.direct_grads
         sink = GradSink(params, direct, engine.arch.deferred_wgrad)
-        dh = engine.backward(ctx.tape, list(grads[:nflow]), list(grads[nflow:]), sink)
+        ph, pw = ctx.tape.geom
+        dh, dxp = engine.backward(ctx.tape, list(grads[:nflow]), list(grads[nflow:]), sink, want_dx=ctx.x_shape is not None)
         ctx.tape = None
         dh = [g if given else None for g, given in zip(dh, ctx.state_given)]
-        return (None, None, None) + tuple(dh) + tuple(sink.grads())
+        dx = None
+        if ctx.x_shape is not None:
+            # no gradient reached the first encoder (every flow / state gradient absent): zeros, like autograd's own
+            dx = dxp[:, :, ph:, pw:] if dxp is not None else torch.zeros(ctx.x_shape, dtype=torch.float32, device=params[0].device)
+        return (None, None, dx) + tuple(dh) + tuple(sink.grads())
 
 
 def run_pass(engine, x, states):
     """Differentiable pass when gradients are enabled, plain launches otherwise."""
     params = [p for p in engine.arch.parameters()]
-    needs = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or any(s is not None and s.requires_grad for s in states))
+    needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params) or
+                                         any(s is not None and s.requires_grad for s in states))
     if not needs:
         flows, new_states, _ = engine.forward(x, list(states), keep=False)
         return flows, new_states

@@ -78,6 +78,7 @@ class CapturedWindow:
 
     def __init__(self, trainer, graph, graph_tail, inputs, states):
         self.trainer, self.graph, self.graph_tail, self.inputs, self.states = trainer, graph, graph_tail, inputs, states
+        self.allreduce_events = None      # a list: replay() appends a (start, stop) event pair around each DP all-reduce
 
     def replay(self, new_seq=False):
         if parallel.any_rank(new_seq):       # host-side exchange, outside the graph; all ranks reset together
@@ -85,7 +86,14 @@ class CapturedWindow:
                 s.zero_()
         self.graph.replay()
         if self.graph_tail is not None:      # DP: the collective runs between the two graphs, on the same stream
-            self.trainer.bucket.all_reduce_sum()
+            if self.allreduce_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.trainer.bucket.all_reduce_sum()
+                e1.record()
+                self.allreduce_events.append((e0, e1))
+            else:
+                self.trainer.bucket.all_reduce_sum()
             self.graph_tail.replay()
         return self.trainer.last_loss
 

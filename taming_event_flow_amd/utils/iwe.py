@@ -3,7 +3,9 @@
 ``compute_pol_iwe`` / ``deblur_events`` (:139-257; eval_flow.py:104-111, visualisation) are one fused launch.  The
 training-time primitives (:5-136) live fused inside the loss kernels (tef_loss.hip); for callers that import them one
 by one they are also available here as stand-alone, FORWARD-ONLY functions on the HIP kernels of tef_val.hip — the
-differentiable path is the loss module (``loss.flow``), these carry no autograd graph."""
+differentiable path is the loss module (``loss.flow``), these carry no autograd graph.  In the reference they are
+ordinary differentiable torch functions: a call that WOULD need a gradient here (grad mode on and an input that
+requires grad) raises instead of silently returning a constant."""
 
 import torch
 
@@ -13,8 +15,20 @@ except ImportError:      # drop-in mode: this package's directory itself is on s
     import _lib
 
 
+def _forward_only(fn, **tensors):
+    """The HIP primitives below carry no autograd graph: refuse a call whose result the caller could differentiate."""
+    if torch.is_grad_enabled():
+        bad = [k for k, t in tensors.items() if isinstance(t, torch.Tensor) and t.requires_grad]
+        if bad:
+            raise RuntimeError(
+                f"utils.iwe.{fn} is forward-only on the MI355X path, but {', '.join(bad)} require(s) grad: gradients of the "
+                "warping / IWE primitives are computed inside loss.flow.Linear / Iterative (the fused HIP loss); build the "
+                "loss with those modules, or call this under torch.no_grad() / on detached tensors if a constant is meant")
+
+
 def compute_pol_iwe(flow, event_list, res, pol_mask, round_idx=True, round_flow=True):
     """Per-polarity IWE [B, 2, H, W] of `event_list` ([B, N, 4], ts in [0, 1]) warped to t = 1 with `flow` [B, 2, H, W]."""
+    _forward_only("compute_pol_iwe", flow=flow, event_list=event_list, pol_mask=pol_mask)
     for name, t in (("flow", flow), ("event_list", event_list), ("pol_mask", pol_mask)):
         _lib.require_device_tensor(t, name)
     flow, ev, pm = (t.to(torch.float32).contiguous() for t in (flow, event_list, pol_mask))
@@ -45,6 +59,7 @@ def event_propagation(events_ts, events_idx, flow, tref):
 def get_event_flow(flow_map_x, flow_map_y, event_loc):
     """Bilinear lookup (align_corners, zero padding) of [B, H, W] flow maps at [B, N, 2] (y, x) -> [B, N, 2] (f_y, f_x)
     (reference :17-40)."""
+    _forward_only("get_event_flow", flow_map_x=flow_map_x, flow_map_y=flow_map_y, event_loc=event_loc)
     for name, t in (("flow_map_x", flow_map_x), ("flow_map_y", flow_map_y), ("event_loc", event_loc)):
         _lib.require_device_tensor(t, name)
     fx, fy = flow_map_x.detach().to(torch.float32).contiguous(), flow_map_y.detach().to(torch.float32).contiguous()
@@ -71,6 +86,7 @@ def purge_unfeasible(event_loc, event_pol_mask, res):
 def get_interpolation(warped_events, res, round_idx=False, zeros=None):
     """Scatter indices and bilinear (or nearest-pixel) weights of [B, N, 2] locations (reference :63-113):
     -> idx, weights [B, 4N, 1] (corner blocks TL, TR, BL, BR) or [B, N, 1] with round_idx."""
+    _forward_only("get_interpolation", warped_events=warped_events)
     _lib.require_device_tensor(warped_events, "warped_events")
     loc = warped_events.detach().to(torch.float32).contiguous()
     B, N = loc.shape[0], loc.shape[1]
@@ -85,6 +101,7 @@ def get_interpolation(warped_events, res, round_idx=False, zeros=None):
 
 def interpolate(idx, weights, res, polarity_mask=None, zeros=None):
     """Image [B, 1, H, W] of the weights scattered to their indices (reference :116-136)."""
+    _forward_only("interpolate", idx=idx, weights=weights, polarity_mask=polarity_mask, zeros=zeros)
     _lib.require_device_tensor(idx, "idx")
     B, n = idx.shape[0], idx.shape[1]
     HW = int(res[0]) * int(res[1])

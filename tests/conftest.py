@@ -52,8 +52,11 @@ ITERATIVE_CASES = [
     "it_two_s1_p6", "it_one_s1_p4", "it_two_s2_p8", "it_two_s3_p8", "it_two_s1_p10_f4", "it_two_iid",
     "it_two_zero_flow", "it_two_smooth_terms", "it_two_round_ts", "it_two_float_xy", "it_two_p5_odd", "it_two_unscaled",
     "it_two_nocomp", "it_one_nocomp_s2",      # border_compensation=False (set after construction, as the reference allows)
+    # passes_loss not a multiple of 2^(scales_loss - 1): trailing passes outside every window of the finer scales
+    "it_two_p10_s3", "it_two_nocomp_p10_s3", "it_two_nocomp_p5_s2",
 ]
-LINEAR_CASES = ["lin_s1_p6", "lin_s2_p8", "lin_smooth_terms", "lin_zero_flow", "lin_unscaled", "lin_nocomp_s2"]
+LINEAR_CASES = ["lin_s1_p6", "lin_s2_p8", "lin_smooth_terms", "lin_zero_flow", "lin_unscaled", "lin_nocomp_s2",
+                "lin_nocomp_p5_s2", "lin_p10_s3"]
 FULL_RES_CASES = ["it_two_128_p10", "lin_128_p10"]      # BASELINE resolution, inputs regenerated from a seed
 
 
@@ -62,6 +65,25 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elementwise_excess(a, b, mass, rtol=1e-4, floor=1e-7):
+    """Element-wise parity of two flow-gradient arrays: max over the elements of |a - b| / (rtol * mass + floor * max|b|)
+    and where it is attained, -> (excess, index, a[index], b[index]); parity holds when excess <= 1.
+
+    `mass` (oracle.Window.gradient_mass) is, per pixel, the sum over the events of the ABSOLUTE contributions whose signed
+    sum is the gradient: the scale each element is resolved to.  The plain form |a - b| <= rtol |b| + floor max|b| is not
+    satisfiable by ANY fp32 evaluation: on the golden cases the faithful C oracle (which agrees with the reference to
+    1e-5 in max-norm) exceeds it up to 24-fold at pixels where contributions cancel, and the reference's own float64 run
+    differs from its float32 run by far more.  Against the pixel's mass a region of small gradients is held to 1e-4 of
+    ITS OWN scale — a small-magnitude region that is wrong by 100 % fails however right the peak is — and a pixel no
+    event touches must be exactly zero up to the floor."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    bound = rtol * np.asarray(mass, np.float64) + floor * np.abs(b).max()
+    r = np.abs(a - b) / bound
+    i = np.unravel_index(int(r.argmax()), r.shape)
+    return float(r[i]), tuple(int(v) for v in i), float(a[i]), float(b[i])
 
 
 @pytest.fixture(scope="session")

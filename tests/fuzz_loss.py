@@ -18,8 +18,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))      # conftest / test_loss_gpu helpers when run as a script
 
 
-def sweep(cases, seed, verbose=True, big_frac=0.05):
-    """-> (number of cases over the 1e-4 bar or raising, worst relative error)"""
+def sweep(cases, seed, verbose=True, big_frac=0.05, ragged_windows=False):
+    """-> (number of cases over the 1e-4 bar or raising, worst relative error).  ragged_windows: passes_loss need not be a
+    multiple of 2^(scales_loss - 1) — the trailing passes then belong to no window of the finer scales (drawn from a
+    second generator so that the cases of the plain sweeps keep their numbers)."""
     import __graft_entry__ as g
 
     g.build()
@@ -30,6 +32,7 @@ def sweep(cases, seed, verbose=True, big_frac=0.05):
 
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed + 1)
     worst, bad, t0 = (0.0, None), 0, time.time()
     for c in range(cases):
         kind = "Iterative" if rng.random() < 0.7 else "Linear"
@@ -37,6 +40,8 @@ def sweep(cases, seed, verbose=True, big_frac=0.05):
         P = int(rng.integers(2, 7)) * (1 << (S - 1))          # every scale divides the window
         if kind == "Iterative" and P // (1 << (S - 1)) < 2:
             P = 2 << (S - 1)
+        if ragged_windows and S > 1:
+            P += int(rng2.integers(0, 1 << (S - 1)))
         mode = "one" if rng.random() < 0.3 else "two"
         B, F = int(rng.integers(1, 4)), int(rng.integers(1, 4))
         H, W = int(rng.integers(6, 70)), int(rng.integers(6, 90))
@@ -88,8 +93,9 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--big-frac", type=float, default=0.05, help="fraction of cases with 4096..9000 events per pass")
+    ap.add_argument("--ragged-windows", action="store_true", help="passes_loss not a multiple of 2^(scales_loss - 1)")
     a = ap.parse_args()
-    bad, _ = sweep(a.cases, a.seed, big_frac=a.big_frac)
+    bad, _ = sweep(a.cases, a.seed, big_frac=a.big_frac, ragged_windows=a.ragged_windows)
     sys.exit(1 if bad else 0)
 
 

@@ -219,6 +219,21 @@ def main():
         save_loss_case("lin_nocomp_s2", "Linear", 16, 20, 2, 4, 2, 2, "two", 150, 30, seed=43, sigma=4.0,
                        border_compensation=False)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--ragged-windows":
+        # passes_loss not a multiple of 2^(scales_loss - 1): the trailing passes belong to no window of the finer scales
+        # (P = 10, S = 3 is the default passes_loss with three temporal scales: windows of 2 passes cover 0..7 only),
+        # with and without border compensation
+        save_loss_case("it_two_p10_s3", "Iterative", 16, 20, 2, 10, 2, 3, "two", 120, 30, seed=51, sigma=2.5)
+        # (seeds / flow magnitudes picked so that the reference's own fp32 result is well conditioned: at seed 53 with
+        # sigma = 3 one event's tau - A cancels to 1e-3 and the reference differs from its own float64 run by 9e-5)
+        save_loss_case("it_two_nocomp_p10_s3", "Iterative", 16, 20, 2, 10, 2, 3, "two", 150, 30, seed=52, sigma=2.5,
+                       border_compensation=False)
+        save_loss_case("it_two_nocomp_p5_s2", "Iterative", 16, 20, 2, 5, 2, 2, "two", 150, [20, 0, 30, 0, 10], seed=53,
+                       sigma=2.0, border_compensation=False)
+        save_loss_case("lin_nocomp_p5_s2", "Linear", 16, 20, 2, 5, 2, 2, "two", 150, 30, seed=54, sigma=3.0,
+                       border_compensation=False)
+        save_loss_case("lin_p10_s3", "Linear", 16, 20, 2, 10, 2, 3, "two", 120, 30, seed=55, sigma=2.5)
+        return
     save_primitives()
     save_encodings()
     # Iterative (loss/flow.py:415) — the north-star path

@@ -28,6 +28,11 @@ from models.model import RecEVFlowNet  # noqa: E402
 torch.set_num_threads(4)
 
 H, W, B, P, N, ND, SEED, LR, CLIP, WINDOWS = 32, 32, 2, 3, 300, 80, 51, 1e-3, 5.0, 2
+NAME = "train_trace"
+if len(sys.argv) > 1 and sys.argv[1] == "--default-lr":
+    # the reference's own learning rate (configs/train_flow.yml): Adam's first steps are sign-like, +-lr per weight, so the
+    # second window's distance between two fp32 implementations scales with lr — at 1e-5 it can be compared tightly
+    LR, NAME = 1e-5, "train_trace_lr1e-5"
 config = {
     "loader": {"resolution": [H, W], "batch_size": B},
     "loss": {"flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "round_ts": False,
@@ -63,6 +68,15 @@ for w in range(WINDOWS):
         loss_function.update(x["flow"], torch.tensor(ev), torch.tensor(pm), torch.tensor(dev), torch.tensor(dpm))
     loss = loss_function()
     loss.backward()
+    # pre-clip gradient of every parameter: norm + first 32 elements (the digest tests/test_model_gpu.py::check_digest reads)
+    gnorms, gheads = [], []
+    for p in model.parameters():
+        g = p.grad.detach().numpy().ravel()
+        gnorms.append(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        h = np.zeros(32, np.float32)
+        h[: min(32, g.size)] = g[:32]
+        gheads.append(h)
+    out[f"pgnorm{w}"], out[f"pghead{w}"] = np.array(gnorms), np.stack(gheads)
     gn = torch.nn.utils.clip_grad.clip_grad_norm_(model.parameters(), CLIP)
     optimizer.step()
     optimizer.zero_grad()
@@ -73,4 +87,4 @@ for w in range(WINDOWS):
     out[f"gnorm{w}"] = np.float32(float(gn))
     out[f"delta{w}"] = delta
     print(f"window {w}: loss {loss.item():.6f} grad-norm {float(gn):.5f} |dW| {np.sqrt((delta**2).sum()):.5f}")
-np.savez_compressed(os.path.join(HERE, "train_trace.npz"), **out)
+np.savez_compressed(os.path.join(HERE, NAME + ".npz"), **out)

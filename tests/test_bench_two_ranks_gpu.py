@@ -32,6 +32,12 @@ def test_loss_mode_two_ranks():
     d = _bench(["--steps", "12", "--warmup", "2", "--no-cpu-baseline"])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert d["value"] > 0 and abs(d["value"] - 2 * 800000 / (d["ms_per_step"] * 1e-3)) <= 0.02 * d["value"]
+    # the line of a multi-rank run carries the DP training window: both ranks took part in the collectives
+    x = d["extra"]
+    assert "error" not in x, x
+    assert x["rccl_world_size"] == 2 and x["rank_checksum"] == x["rank_checksum_expected"] == 3.0
+    assert x["dp_train_window_ms"] > 0 and x["allreduce_ms"] > 0 and x["allreduce_GBps"] > 0
+    assert x["allreduce_bytes"] == 4 * 31_365_352 and x["replicas_bit_identical"]
 
 
 def test_train_mode_two_ranks_graph():

@@ -1,0 +1,99 @@
+"""BASELINE.json configs[2] at its REAL size, checked (not just timed): RecEVFlowNet forward / BPTT backward (MFMA convs)
++ HIP Iterative loss, 128x128, B = 8, P = 10 passes x 10 000 events, F = 4 heads.
+
+(a) the fused pass engine (one autograd node per pass, hand-written backward: models/engine.py) against the same network
+    run layer by layer through the modules' own autograd nodes (reference models/arch.py:217-242, models/model.py:65-85):
+    the 40 flow maps, the 4 recurrent states and every parameter gradient of the window;
+(b) the HIP loss on the flows the NETWORK produces (random-init weights: |flow| << 1 px, SURVEY.md section 8d flow set iii —
+    nothing like the 2 px synthetic flows of the other tests) against the CPU oracle: loss and d loss / d flow.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import elementwise_excess, rel_err
+
+pytestmark = pytest.mark.gpu
+
+B, H, W, P, N, SCALE = 8, 128, 128, 10, 10000, 32.0
+
+
+def _window_inputs(dev):
+    from taming_event_flow_amd import synth
+    from taming_event_flow_amd.dataloader import encodings
+
+    rng = np.random.default_rng(2024)
+    evs = [synth.make_event_pass(rng, B, N, H, W) for _ in range(P)]
+    empty = (np.zeros((B, 0, 4), np.float32), np.zeros((B, 0, 2), np.float32))
+    xs = [encodings.event_list_to_channels(torch.tensor(e[0], device=dev), (H, W)) for e in evs]
+    return evs, empty, xs
+
+
+def _run(fused, evs, empty, xs, dev):
+    from taming_event_flow_amd.loss.flow import Iterative
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+    from taming_event_flow_amd.models.submodules import upsample_bilinear
+    from test_model_gpu import load_weights
+
+    net = load_weights(RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2), 77, dev)
+    net.train()
+    cfg = {"loader": {"resolution": [H, W], "batch_size": B},
+           "loss": {"flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "round_ts": False, "iterative_mode": "two"},
+           "data": {"passes_loss": P, "scales_loss": 1}}
+    L = Iterative(cfg, dev)
+    flows_all = []
+    for t in range(P):
+        if fused:
+            flows = net(xs[t])["flow"]
+        else:
+            preds = net.arch(xs[t])
+            flows = [upsample_bilinear(p, 2 ** (3 - i), 2 ** (3 - i), mul=float(2 ** (3 - i))) for i, p in enumerate(preds)]
+        flows = [f * SCALE for f in flows]                       # train_flow.py:107-108
+        for f in flows:
+            f.retain_grad()
+        flows_all.append(flows)
+        L.update(flows, torch.tensor(evs[t][0], device=dev), torch.tensor(evs[t][1], device=dev),
+                 torch.tensor(empty[0], device=dev), torch.tensor(empty[1], device=dev))
+    loss = L()
+    loss.backward()
+    torch.cuda.synchronize()
+    return (float(loss.item()), [[f.detach().cpu().numpy() for f in row] for row in flows_all],
+            [[f.grad.cpu().numpy() for f in row] for row in flows_all],
+            [s.detach().cpu().numpy() for s in net.arch.states], [p.grad.cpu().numpy() for p in net.parameters()],
+            [k for k, _ in net.named_parameters()])
+
+
+def test_configs2_full_size():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+
+    g.build()
+    dev = torch.device("cuda:0")
+    evs, empty, xs = _window_inputs(dev)
+    la, fa, dfa, sa, ga, names = _run(True, evs, empty, xs, dev)
+    lb, fb, dfb, sb, gb, _ = _run(False, evs, empty, xs, dev)
+    # (a) fused engine vs layer-by-layer
+    assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+    for t in range(P):
+        for i in range(4):
+            assert fa[t][i].shape == (B, 2, H, W)
+            assert rel_err(fa[t][i], fb[t][i]) <= 1e-5, (t, i)
+    for k, (a, b) in enumerate(zip(sa, sb)):
+        assert rel_err(a, b) <= 1e-5, k
+    worst = max((rel_err(a, b), n) for a, b, n in zip(ga, gb, names))
+    print(f"configs[2] full size: loss {la:.6f}; worst parameter-gradient difference fused vs layer-by-layer {worst[0]:.2e} ({worst[1]})")
+    for a, b, n in zip(ga, gb, names):
+        assert rel_err(a, b) <= 1e-4, n
+    # (b) HIP loss vs the CPU oracle on the network-produced flows
+    from oracle import oracle
+
+    assert max(np.abs(f).max() for row in fa for f in row) < 1.0          # flow set iii: |flow| << 1 px
+    ow = oracle.Window(fa, [e[0] for e in evs], [e[1] for e in evs], [empty[0]] * P, [empty[1]] * P, S=1, mode="two")
+    ol, od = ow.iterative()
+    assert abs(la - ol) <= 1e-4 * abs(ol), (la, float(ol))
+    g_hip = np.stack([np.stack(row) for row in dfa])
+    assert rel_err(g_hip, od) <= 1e-4
+    ex, where, got, want = elementwise_excess(g_hip, od, ow.gradient_mass("Iterative"))
+    print(f"configs[2] loss on network flows: hip {la:.7f} oracle {float(ol):.7f}; d loss / d flow max-norm {rel_err(g_hip, od):.2e}, "
+          f"element-wise excess {ex:.3f} at {where}")
+    assert ex <= 4.0, (ex, where, got, want)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, load_case, rel_err
+from conftest import FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, elementwise_excess, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -65,6 +65,22 @@ def test_golden_cases(name, dev):
         for i in range(meta["F"]):
             if np.abs(dflows[t, i]).max() > 0:
                 assert rel_err(g[t, i], dflows[t, i]) <= 2e-3, (t, i)
+    # element by element, each pixel against ITS OWN scale (conftest.elementwise_excess): |hip - reference| <= 1e-4 x the
+    # pixel's gradient mass (the backward pass with every term's magnitude, from the oracle) + 1e-7 max|reference|.  A
+    # small-magnitude region that is wrong fails here however right the peak is.  Calibration: the C oracle — the same
+    # arithmetic in the reference's own order, 1e-5 from the reference in max-norm — reaches 2.5 on these cases (worst:
+    # it_two_128_p10), so the bar for the HIP path is 4.
+    from oracle import oracle
+
+    w = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=meta["S"], mode=meta["mode"],
+                      round_ts=meta["round_ts"], loss_scaling=meta.get("loss_scaling", True),
+                      border_compensation=meta.get("border_compensation", True))
+    mass = w.gradient_mass(meta["kind"])
+    if meta["spat"] is not None or meta["temp"] is not None:
+        mass = mass + np.abs(w.smoothing(meta["spat"], meta["temp"])[1])
+    ex, where, got, want = elementwise_excess(g, dflows, mass)
+    print(f"{name}: max-norm {rel_err(g, dflows):.2e}; element-wise excess {ex:.3f} at {where}: hip {got:.6e} reference {want:.6e}")
+    assert ex <= 4.0, (ex, where, got, want)
 
 
 def test_upstream_gradient_scaling(dev):
@@ -198,6 +214,10 @@ def test_randomised_sweep(dev):
     # odd P at cases 122, 136, 216 — they caught a reciprocal in the backward's tau
     bad, worst = fuzz.sweep(220, seed=5150, verbose=False)
     assert bad == 0 and worst <= TOL
+    # window lengths that the finer temporal scales do not divide (trailing passes outside every window of a scale), a
+    # fifth of them without border compensation
+    bad, worst = fuzz.sweep(150, seed=77, verbose=False, ragged_windows=True)
+    assert bad == 0 and worst <= TOL
 
 
 def test_long_runs_take_fp64_accumulators(dev):
@@ -229,3 +249,31 @@ def test_bitwise_reproducible(dev):
     for l, g, _ in runs[1:]:
         assert l == runs[0][0]
         assert np.array_equal(g, runs[0][1])
+
+
+@pytest.mark.parametrize("kind", ["Iterative", "Linear"])
+def test_unrepresentable_inputs_surface_as_nan(kind, dev):
+    """A NaN timestamp / location, or a timestamp list that was never normalised (microseconds instead of [0, 1]), cannot
+    be held by the integer accumulators of the scatter kernels (to_fixed needs |w * tau| < 32): the reference propagates
+    such inputs to a NaN or meaningless loss; here K1 flags them and the loss comes out NaN instead of an arbitrary
+    finite number.  A clean window of the same shape stays finite."""
+    from taming_event_flow_amd import synth
+
+    B, H, W, P, F = 2, 24, 28, 4, 2
+    meta = dict(H=H, W=W, B=B, P=P, S=1, mode="two", spat=None, temp=None, round_ts=False)
+    rng = np.random.default_rng(3)
+    clean = synth.make_window(rng, B, H, W, P, F, 200, 50, sigma=1.0)
+    l, g, _ = run_hip(kind, make_cfg(meta), clean, dev)
+    assert np.isfinite(l) and np.isfinite(g).all()
+    for what in ("nan_ts", "raw_ts", "nan_xy", "nan_detached_ts"):
+        win = {k: [([m.copy() for m in row] if isinstance(row, list) else row.copy()) for row in clean[k]] for k in clean}
+        if what == "nan_ts":
+            win["ev"][2][1, 17, 0] = np.nan
+        elif what == "raw_ts":
+            win["ev"][1][:, :, 0] *= 1e6
+        elif what == "nan_xy":
+            win["ev"][0][0, 5, 2] = np.nan
+        else:
+            win["dev"][3][0, 7, 0] = np.nan
+        l, _, _ = run_hip(kind, make_cfg(meta), win, dev)
+        assert np.isnan(l), (what, l)

@@ -11,7 +11,29 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 
-def test_two_window_trace():
+def _digest_errors(params_grad_flat, params, gnorm, ghead):
+    """-> (worst error of a parameter's gradient norm relative to the LARGEST norm, worst relative to its own norm, worst
+    error of a 32-element head relative to max(|head|, 1e-3 x the parameter's norm)) — check_digest's three criteria."""
+    e_glob = e_own = e_head = 0.0
+    o = 0
+    for i, p in enumerate(params):
+        g = params_grad_flat[o:o + p.numel()].double().cpu().numpy()
+        o += p.numel()
+        n = float(np.sqrt((g ** 2).sum()))
+        e_glob = max(e_glob, abs(n - gnorm[i]) / gnorm.max())
+        e_own = max(e_own, abs(n - gnorm[i]) / max(gnorm[i], 1e-12))
+        h = np.zeros(32)
+        h[: min(32, g.size)] = g[:32]
+        e_head = max(e_head, np.abs(h - ghead[i]).max() / max(np.abs(ghead[i]).max(), 1e-3 * gnorm[i]))
+    return e_glob, e_own, e_head
+
+
+@pytest.mark.parametrize("trace", ["train_trace", "train_trace_lr1e-5"])
+def test_two_window_trace(trace):
+    """Two consecutive loss windows against the reference's recorded trace: loss, pre-clip gradient (global norm and, per
+    parameter, norm + first 32 elements), Adam update norms.  `train_trace_lr1e-5` runs at the reference's own learning
+    rate: Adam's first steps move every weight by +-lr whatever the gradient's size, so the second window's distance
+    between two fp32 implementations scales with lr and can be held to 1e-3 there (lr = 1e-3: percent level)."""
     assert torch.cuda.is_available()
     import __graft_entry__ as g
 
@@ -20,7 +42,7 @@ def test_two_window_trace():
     from taming_event_flow_amd.dataloader import encodings
 
     dev = torch.device("cuda:0")
-    z = np.load(os.path.join(GOLDEN, "train_trace.npz"))
+    z = np.load(os.path.join(GOLDEN, trace + ".npz"))
     H, W, B, P = int(z["H"]), int(z["W"]), int(z["B"]), int(z["P"])
     cfg = {
         "data": {"passes_loss": P, "scales_loss": 1, "voxel": None},
@@ -34,6 +56,7 @@ def test_two_window_trace():
     sd = tr.model.state_dict()
     w = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], int(z["seed"]))
     tr.model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    small_lr = float(z["lr"]) <= 1e-4
     for win in range(int(z["windows"])):
         before = [p.detach().clone() for p in tr.model.parameters()]
         for t in range(P):
@@ -41,14 +64,30 @@ def test_two_window_trace():
             dv, dpm = torch.tensor(z[f"dev{win}_{t}"], device=dev), torch.tensor(z[f"dpm{win}_{t}"], device=dev)
             net_input = encodings.event_list_to_channels(torch.cat([ev, dv], 1), (H, W))
             np.testing.assert_array_equal(net_input.cpu().numpy(), z[f"inp{win}_{t}"])     # counts: bit-exact
-            stepped = tr.step({"net_input": net_input, "event_list": ev, "event_list_pol_mask": pm,
-                               "d_event_list": dv, "d_event_list_pol_mask": dpm}, new_seq=(win == 0 and t == 0))
-            assert stepped == (t == P - 1)
+            batch = {"net_input": net_input, "event_list": ev, "event_list_pol_mask": pm, "d_event_list": dv,
+                     "d_event_list_pol_mask": dpm}
+            if t < P - 1:
+                assert not tr.step(batch, new_seq=(win == 0 and t == 0))
+            else:
+                # the last pass of the window taken apart (what Trainer.step does, train.py::_pass) so that the gradient can
+                # be read BEFORE clipping and the optimiser step
+                assert tr._forward_update(batch)
+                tr._backward_window()
+                tr.bucket.all_reduce_sum()
+                flat = tr.bucket.flat.detach().clone()
+                tr._apply_update()
         loss, gn = float(tr.last_loss.item()), float(tr.last_grad_norm.item())
+        assert abs(float(flat.double().norm()) - gn) <= 1e-5 * gn            # what was clipped is what was read
         delta = np.array([float((p.detach() - b0).double().norm()) for p, b0 in zip(tr.model.parameters(), before)])
-        tol = 1e-4 if win == 0 else 2e-2       # window 1 sees weights that went through an Adam step (sign-like update)
+        e_glob, e_own, e_head = _digest_errors(flat, tr.bucket.params, z[f"pgnorm{win}"], z[f"pghead{win}"])
+        print(f"{trace} window {win}: loss rel {abs(loss - float(z[f'loss{win}'])) / abs(float(z[f'loss{win}'])):.2e} "
+              f"gnorm rel {abs(gn - float(z[f'gnorm{win}'])) / float(z[f'gnorm{win}']):.2e} per-parameter norm {e_glob:.2e} "
+              f"(own {e_own:.2e}) heads {e_head:.2e}")
+        # window 0: the same weights as the reference -> the north-star bar; window 1: weights after one Adam step
+        tol = 1e-4 if win == 0 else (1e-3 if small_lr else 2e-2)
         assert abs(loss - float(z[f"loss{win}"])) <= tol * abs(float(z[f"loss{win}"])), (win, loss)
-        assert abs(gn - float(z[f"gnorm{win}"])) <= 10 * tol * float(z[f"gnorm{win}"]), (win, gn)
+        assert abs(gn - float(z[f"gnorm{win}"])) <= (1 if win == 0 else 10) * tol * float(z[f"gnorm{win}"]), (win, gn)
+        assert e_glob <= tol and e_own <= 10 * tol and e_head <= 10 * tol, (win, e_glob, e_own, e_head)
         ref = z[f"delta{win}"]
         assert np.abs(delta - ref).max() <= 5e-2 * ref.max(), win
         assert tr.loss_function.num_passes == 0
