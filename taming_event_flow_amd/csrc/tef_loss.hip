@@ -44,13 +44,14 @@ namespace {
 
 constexpr float kEps = 1e-9f;
 constexpr int kSplatThreads = 1024;
-constexpr size_t kSplatLdsBudget = 138 * 1024;   // K2 keeps 20 KiB of run tables and per-wavefront row lists beside its planes
+constexpr size_t kSplatLdsBudget = 141 * 1024;   // K7's two planes of 64 + 2 halo rows at 128 x 128 (beside ~22 KiB of run tables and per-wavefront row lists)
 constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the few-row
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
 constexpr int kQueueInts = 16;                // work queues of the persistent scatter kernels: [0, 8) images, [8, 16) flow gradients
 
-// meta word written by K1 per (head, sample, slot)
+// meta word written by K1 per (head, sample, slot): .x = flags below | border bits per scale | kb + 1 | kf, .y = the
+// event's timestamp (bit pattern), so that the scatter reads everything but the position of an event in ONE 8-byte load
 constexpr uint32_t kMetaPos = 1u << 24;      // mask_pos != 0
 constexpr uint32_t kMetaNeg = 1u << 25;      // mask_neg != 0
 constexpr uint32_t kMetaNonUnit = 1u << 26;  // a mask value is neither 0 nor 1: fetch the float
@@ -135,6 +136,21 @@ __device__ __forceinline__ void xcd_split(int bid, int nsub, int &item, int &sub
     sub = r % nsub;
 }
 inline unsigned xcd_grid(int nitems, int nsub) { return 8u * (unsigned)((nitems + 7) / 8) * (unsigned)nsub; }
+
+// wave-uniform base + 32-bit byte offset per lane: the form the scalar-base global loads / stores take
+// (the uniform element offset goes through readfirstlane so that loop strength reduction cannot turn base + k * stride +
+// lane into a 64-bit per-lane induction pointer)
+__device__ __forceinline__ size_t uniform_off(size_t v)
+{
+    return (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+           ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+}
+template <class T>
+__device__ __forceinline__ T *at_bytes(T *base, uint32_t off)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+    return reinterpret_cast<T *>(reinterpret_cast<B *>(base) + off);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Bilinear flow lookup: utils/iwe.py:17-40 + ATen grid_sampler_2d (bilinear, align_corners=True, zeros).
@@ -429,7 +445,7 @@ __device__ __forceinline__ void flag_bad_events(int *__restrict__ bad, int slot,
 // Every lane stays in the loops (dead and padding lanes masked): the per-row reductions need the whole row.
 // =============================================================================================
 __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
-                                                        float2 *__restrict__ traj, uint32_t *__restrict__ meta,
+                                                        float2 *__restrict__ traj, uint2 *__restrict__ meta,
                                                         float2 *__restrict__ yr, int *__restrict__ queue,
                                                         int *__restrict__ bad, int chunks)
 {
@@ -454,7 +470,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
     float ts = E.ts[o], y0 = E.y[o], x0 = E.x[o];
     const int t = __builtin_amdgcn_readfirstlane((int)E.bin[sl]);      // passes start at multiples of 64 slots: wave-uniform
     flag_bad_events(bad, ib * chunks + chunk, valid && !event_is_sane(ts, y0, x0, t));
-    float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
+    float2 *tr = traj + (size_t)ib * (w.nplanes + 1) * w.Mt + u;
 
     // Bilinear flow lookup of map k at (y, x).  The kernel is VALU-bound (~135 vector instructions per chain step): when
     // every lane of the wavefront has its four taps inside the map, two plain 16-byte loads replace the clamped,
@@ -469,6 +485,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         return quad_value(load_quad(map, q, H * W), q);
     };
     store_row_range(rng, w.nplanes, valid, y0, in_list);
+    if (in_list) tr[(size_t)w.nplanes * w.Mt] = make_float2(y0, x0);      // plane nplanes: where pass t sampled its own map (K7)
     // flow at the original location, shared by the first forward and the first backward step
     float2 f0 = make_float2(0.0f, 0.0f);
     if (valid) f0 = lookup(y0, x0, t);
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         int lo = wi * scale, hi = lo + scale;
         if (kb < lo && kf > hi) bits |= 1u << s;
     }
-    meta[(size_t)ib * w.Mt + u] = valid ? pack_meta(bits, kb, kf, mp, mn) : 0u;
+    meta[(size_t)ib * w.Mt + u] = make_uint2(valid ? pack_meta(bits, kb, kf, mp, mn) : 0u, __float_as_uint(ts));
 }
 
 // =============================================================================================
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
 // plane 2s+1 = backward (tref = lo).
 // =============================================================================================
 __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
-                                                          float2 *__restrict__ traj, uint32_t *__restrict__ meta,
+                                                          float2 *__restrict__ traj, uint2 *__restrict__ meta,
                                                           float2 *__restrict__ yr, int *__restrict__ queue,
                                                           int *__restrict__ bad, int chunks)
 {
@@ -569,7 +586,8 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
         Taps tp = make_taps(y0, x0, H, W);
         f = quad_value(load_quad(flow_map(w, flows, t, i, b), tp, w.H * w.W), tp);
     }
-    float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + u;
+    float2 *tr = traj + (size_t)ib * (w.nplanes + 1) * w.Mt + u;
+    if (in_list) tr[(size_t)w.nplanes * w.Mt] = make_float2(y0, x0);      // plane nplanes: the sampling locations (K7)
     uint32_t bits = 0;
     for (int s = 0; s < w.S; ++s) {
         int scale = w.P >> s, wi = t / scale;
@@ -592,7 +610,7 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
         store_row_range(rng, 2 * s + 1, in, fmaxf(yb, 0.0f), has && in_list);
     }
     flush_row_ranges(w, rng, yr, ib, chunk);
-    if (in_list) meta[(size_t)ib * w.Mt + u] = valid ? pack_meta(bits, -1, 0, mp, mn) : 0u;
+    if (in_list) meta[(size_t)ib * w.Mt + u] = make_uint2(valid ? pack_meta(bits, -1, 0, mp, mn) : 0u, __float_as_uint(ts));
 }
 
 // LDS image plane helpers of the two scatter kernels: [rows][W + kRowPad] 8-byte accumulators.
@@ -712,33 +730,34 @@ __device__ __noinline__ void splat_any(float2 p, float ts, float m, float tref, 
 // polarity c in unified slot space, fp64 accumulators, no interval tests
 __device__ __forceinline__ void splat_run_general(const Win &w, const Img &im, double rdelta, const Events &g,
                                                   const Events &d, int b, int c, int u0, int len,
-                                                  const float2 *__restrict__ pl, const uint32_t *__restrict__ mt,
+                                                  const float2 *__restrict__ pl, const uint2 *__restrict__ mt,
                                                   double *img_c, double *img_t, int r0, int nrows)
 {
     const bool isd = u0 >= w.M;
     const Events &E = isd ? d : g;
-    const float *tsp = E.ts + (size_t)b * E.cap - (isd ? w.M : 0);      // indexed by unified slot
-    const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap - (isd ? w.M : 0);
+    const float *mask = (c ? E.mn : E.mp) + (size_t)b * E.cap - (isd ? w.M : 0);      // indexed by unified slot
     const int WP = w.W + kRowPad;
     for (int v = threadIdx.x; v < len; v += blockDim.x) {
         const int u = u0 + v;
-        const uint32_t mv = mt[u];
+        const uint2 m2 = mt[u];
+        const uint32_t mv = m2.x;
         if (!in_image(w, mv, im.s, im.plane)) continue;          // border mask (:671-681)
         float m = 1.0f;
         if (mv & kMetaNonUnit) m = mask[u];
-        if (w.comp || w.kind == TEF_KIND_ITERATIVE) splat_one<false>(pl[u], tsp[u], m, im, rdelta, img_c, img_t, r0, nrows, WP);
-        else splat_any<false>(pl[u], tsp[u], m, im.tref, rdelta, img_c, img_t, r0, nrows, w.W, WP);
+        const float ts = __uint_as_float(m2.y);
+        if (w.comp || w.kind == TEF_KIND_ITERATIVE) splat_one<false>(pl[u], ts, m, im, rdelta, img_c, img_t, r0, nrows, WP);
+        else splat_any<false>(pl[u], ts, m, im.tref, rdelta, img_c, img_t, r0, nrows, w.W, WP);
     }
 }
 
 
 // band pixels of one polarity -> (A, R), the polarity's share of the focus-loss sum, and one byte per pixel "C != 0" (the
-// count of active pixels needs both polarities: image_count_kernel).  planes: [C | T], each nrows x WP
+// count of active pixels needs both polarities: image_count_kernel).  planes: first band row of C; T is plane_sz further
 template <bool FX>
-__device__ __forceinline__ void band_stats(const double *planes, int nrows, int W, int WP, float2 *__restrict__ ar,
-                                           uint8_t *__restrict__ nz, float &acc)
+__device__ __forceinline__ void band_stats(const double *planes, size_t plane_sz, int nrows, int W, int WP,
+                                           float2 *__restrict__ ar, uint8_t *__restrict__ nz, float &acc)
 {
-    const double *cp = planes, *tp = planes + (size_t)nrows * WP;
+    const double *cp = planes, *tp = planes + plane_sz;
     auto pixel = [&](float c, float t, float2 &o) {
         float a = t / (c + kEps);                     // :727
         o = make_float2(a, 1.0f / (c + kEps));
@@ -769,9 +788,19 @@ __device__ __forceinline__ void band_stats(const double *planes, int nrows, int 
 }
 
 // number of pixels of each image that hold events of either polarity (loss/flow.py:125-127), from K2's per-polarity bytes
-__global__ __launch_bounds__(256) void image_count_kernel(const uint8_t *__restrict__ nz, int HW, double *__restrict__ cnt)
+// (+ this block's slice of K1's "unrepresentable input" words, folded into one word per image for K4: a single block
+// scanning all of them there took 18 us)
+__global__ __launch_bounds__(256) void image_count_kernel(const uint8_t *__restrict__ nz, int HW, double *__restrict__ cnt,
+                                                          const int *__restrict__ bad, int nbad, int *__restrict__ bad_img)
 {
     __shared__ int red[4];
+    {
+        const int per = (nbad + (int)gridDim.x - 1) / (int)gridDim.x, lo = (int)blockIdx.x * per, hi = min(lo + per, nbad);
+        int any = 0;
+        for (int k = lo + (int)threadIdx.x; k < hi; k += blockDim.x) any |= bad[k];
+        any = __syncthreads_or(any);
+        if (threadIdx.x == 0) bad_img[blockIdx.x] = any;
+    }
     const uint8_t *p = nz + (size_t)blockIdx.x * 2 * HW, *n = p + HW;
     int c = 0;
     if ((HW & 3) == 0) {
@@ -789,12 +818,81 @@ __global__ __launch_bounds__(256) void image_count_kernel(const uint8_t *__restr
 }
 
 constexpr int kSplat2Threads = 512;             // K2: two such workgroups per CU
-constexpr size_t kSplat2LdsBudget = 70 * 1024;  // planes of one K2 workgroup (beside ~6 KiB of run tables and row lists)
+constexpr size_t kSplat2LdsBudget = 74 * 1024;  // planes of one K2 workgroup incl. their two halo rows (beside ~7 KiB of run tables and row lists)
+constexpr int kRing = 128;                      // hit-row FIFO entries per wavefront (power of two)
 
+typedef float f32x2_e __attribute__((ext_vector_type(2)));      // (y, x) pairs: the compiler picks v_pk_{add,mul}_f32 for these
+
+// One event into the integer planes of a band (the hot path of the whole forward: instruction count is what bounds it).
+//   p = (y, x) inside the frame (shared border mask), so 0 <= floor(y) <= H - 1 and 0 <= floor(x) <= W - 1.  utils/iwe.py:85-107:
+//   near weights max(0, 1 - |v - floor(v)|) = 1 - (v - floor(v)) exactly (0 <= v - floor(v) < 1: neither the abs nor the max
+//   can act); far weights max(0, 1 - |v - floor(v + 1)|) = max(0, 1 + (v - floor(v + 1))) (the difference is negative; the
+//   max stays: where fp32 rounds v + 1 up to the next integer the sum is a negative ulp, and the reference clamps it to 0).
+//   The far corners are addressed as +1: floor(v + 1) differs from floor(v) + 1 only in that case, with weight 0.
+// The planes carry ONE HALO ROW above and below the band, so the eight accumulations are unconditional: an event of the
+// row above the band leaves its near row in the halo (never read), one of the band's last row its far row; the right
+// column may be W (row padding).  A weight of exactly 0 adds 0.
+//   cpl: byte address of the C plane's halo row 0 in LDS; tpl_off / row_off: bytes from C to T / from a row to the next;
+//   rr = floor(y) - (r0 - 1) in [0, nrows]
+__device__ __forceinline__ void splat_fixed(float y, float x, float tau, int rr, int WP, unsigned long long *cpl,
+                                            unsigned long long *tpl)
+{
+    const f32x2_e p = {y, x};
+    const f32x2_e f0 = {floorf(y), floorf(x)};
+    const f32x2_e p1 = p + 1.0f;
+    const f32x2_e f1 = {floorf(p1.x), floorf(p1.y)};
+    const f32x2_e nearw = 1.0f - (p - f0);               // (wy0, wx0)
+    f32x2_e farw = 1.0f + (p - f1);                      // (wy1, wx1) before the clamp
+    farw.x = fmaxf(farw.x, 0.0f);
+    farw.y = fmaxf(farw.y, 0.0f);
+    const f32x2_e wx = {nearw.y, farw.y};
+    const f32x2_e w0 = nearw.x * wx, w1 = farw.x * wx;   // (w00, w01), (w10, w11)
+    const f32x2_e t0 = w0 * tau, t1 = w1 * tau;          // utils/iwe.py:94-95 weights * tau, then the polarity mask (1)
+    const int cell = __mul24(rr, WP) + (int)f0.y;        // (24-bit multiply: full rate)
+    unsigned long long *c0 = cpl + cell, *q0 = tpl + cell;
+    atomicAdd(c0, to_fixed(w0.x));
+    atomicAdd(c0 + 1, to_fixed(w0.y));
+    atomicAdd(c0 + WP, to_fixed(w1.x));
+    atomicAdd(c0 + WP + 1, to_fixed(w1.y));
+    atomicAdd(q0, to_fixed(t0.x));
+    atomicAdd(q0 + 1, to_fixed(t0.y));
+    atomicAdd(q0 + WP, to_fixed(t1.x));
+    atomicAdd(q0 + WP + 1, to_fixed(t1.y));
+}
+
+// =============================================================================================
+// K2: images of warped events + their focus-loss statistics.
+//   loss/flow.py:81-110 iwe_formatting = utils/iwe.py:63-136 get_interpolation + 4x interpolate (scatter_add_), then
+//   :725-727 A = T / (C + 1e-9) and :112-129 focus_loss.
+// A workgroup owns a ROW BAND of one polarity of one image with its two planes — event count C and weighted timestamp
+// sum T — in LDS (32 rows + 2 halo rows at 128x128 = 72 KiB; two workgroups per CU).  Per 16-slot row of events it reads
+// K1's [min y, max y] interval (8 bytes) and loads the row's events only if the interval can touch the band; an event is
+// split into corner weights once for its eight accumulations.  When all events are in, the band's pixels are turned into
+// (A, R = 1/(C + eps)) for the backward and into the partial sums of the focus loss: the images themselves never go to
+// memory.  Accumulators: Q17.46 integers (ds_add_u64) or fp64 (general masks / very long runs).
+// Workgroups are persistent: they pull (image, head, sample, polarity, band) items from one queue per XCD — largest images
+// first, the bands of an image on one XCD so that its trajectory plane is fetched from HBM once.
+//   ar   [(j*FB + ib)*2 + c][H*W] float2 = (A, R)
+//   part [((j*FB + ib)*2 + c)*nbands + band] = sum_px A_c^2 of the band
+// Instruction diet of round 3 (the sweep was VALU-bound at ~155 vector instructions per 64 event slots, a third of them
+// address arithmetic and lane-range bookkeeping of the event loads):
+//   * the item index goes through readfirstlane: everything derived from it (image, planes, base pointers) is scalar;
+//   * an event visit is TWO 8-byte loads at one 32-bit offset from scalar bases: the position, and K1's (flags, timestamp)
+//     word pair;
+//   * whole rows are loaded; which slots of a row belong to this polarity is decided by the event's own flag bits (the
+//     integer path runs only when the passes hold no general-mask events, so a slot is pos-only, neg-only or padding):
+//     a list entry is just the row;
+//   * halo rows instead of per-corner band tests; near weights without abs / max; (y, x) as packed pairs.
+// =============================================================================================
+// MODE 0: border compensation (the reference's reachable setting): the border bit of the image's temporal scale in the meta
+// word.  MODE 1: Iterative without: alive at this reference time (kb < tref < kf).  Two instantiations (the test as a
+// run-time branch cost the default path 4 %).  Linear without compensation splats positions
+// outside the frame and takes the general path.
 // (second argument: at least 4 wavefronts per SIMD, i.e. at most 128 VGPRs — two of these workgroups per CU)
+template <int MODE>
 __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, Events g, Events d,
                                                                      const float2 *__restrict__ traj,
-                                                                     const uint32_t *__restrict__ meta,
+                                                                     const uint2 *__restrict__ meta,
                                                                      const float2 *__restrict__ yr,
                                                                      float2 *__restrict__ ar, uint8_t *__restrict__ nz,
                                                                      double *__restrict__ part, int rows_per_band,
@@ -803,15 +901,16 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
     extern __shared__ double lds_img[];
     constexpr int kRuns = 2 * TEF_MAX_PASSES;      // (grad, detached) per pass, one polarity
     __shared__ int run_u0[kRuns], run_len[kRuns], run_cum[kRuns + 1], s_item, s_flags[2];
-    __shared__ int2 hit_list[2 * kSplat2Threads];  // 128 (row, lanes) entries per wavefront
+    __shared__ int hit_ring[(kSplat2Threads / 64) * kRing];      // rows that can touch the band: one FIFO per wavefront
     __shared__ double red_s[kSplat2Threads / 64];
     const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad, HW = H * W;
     const int xcd = blockIdx.x & 7;
     const int nitems = w.nimg * FB, nsub = 2 * nbands;
+    for (int k = threadIdx.x; k < (kSplat2Threads / 64) * kRing; k += blockDim.x) hit_ring[k] = 0;      // (stale entries are read, as rows)
     if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
     __syncthreads();
     for (;;) {
-        const int q = s_item;
+        const int q = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: everything derived from it is scalar
         const int it = xcd + 8 * (q / nsub), sub = q - (q / nsub) * nsub;
         if (it >= nitems) break;
         const int c = sub & 1, band = sub >> 1;          // polarity, row band
@@ -820,9 +919,10 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
         const Img im = decode_image(w, j);
         const double rdelta = 1.0 / (double)im.delta;
         const float band_lo = (float)(r0 - 1), band_hi = (float)(r0 + nrows);     // rows floor(y), floor(y) + 1 of an event
-        const size_t plane_sz = (size_t)nrows * WP;
+        // planes: [C | T], each nrows + 2 rows (halo row, the band, halo row) of WP accumulators
+        const size_t plane_sz = (size_t)(nrows + 2) * WP;
         double *img_c = lds_img, *img_t = lds_img + plane_sz;
-        lds_plane_zero(lds_img, 2 * nrows * WP);         // all-zero bits: 0.0 and integer 0 alike
+        lds_plane_zero(lds_img, 2 * (nrows + 2) * WP);         // all-zero bits: 0.0 and integer 0 alike
         // run list of the integer path (the [pos-only] or [neg-only] slots of every pass / list) + accumulator choice
         const int nb = im.he - im.le, nlists = w.Md > 0 ? 2 : 1, nruns = nb * nlists;
         if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
@@ -858,8 +958,8 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
         }
         __syncthreads();
         const bool fixed = s_flags[0] == 0 && s_flags[1] < kFxMaxEvents && (w.comp || w.kind == TEF_KIND_ITERATIVE);
-        const float2 *pl = traj + ((size_t)ib * w.nplanes + im.plane) * w.Mt;
-        const uint32_t *mt = meta + (size_t)ib * w.Mt;
+        const float2 *pl = traj + uniform_off(((size_t)ib * (w.nplanes + 1) + im.plane) * w.Mt);
+        const uint2 *mt = meta + uniform_off((size_t)ib * w.Mt);
         if (fixed) {
             // Wave-centric sweep.  The rows (16 slots) of all runs form one flattened sequence; a wavefront takes 128 rows at
             // a time (eight chunks of 16, see load_range): every lane reads two row intervals, the rows that can touch
@@ -867,120 +967,136 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
             // 16 rows (four quads of 4 x 16 lanes) with the next batch's events already in flight.  Iterations are dense in
             // work whatever the fraction of rows that hit (a workgroup-wide chunk loop spent a memory round trip per mostly
             // skipped chunk: 0.30 ms instead of 0.21).
-            const float2 *rows = yr + ((size_t)ib * (w.nplanes + 1) + im.plane) * w.nrow;
-            const float *tsg = g.ts + (size_t)b * g.cap;                                   // indexed by unified slot
-            const float *tsd = (w.Md > 0) ? d.ts + (size_t)b * d.cap - w.M : tsg;
+            const float2 *rows = yr + uniform_off(((size_t)ib * (w.nplanes + 1) + im.plane) * w.nrow);
             const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
             const int total_rows = run_cum[nruns];
-            int2 *list = hit_list + wid * 128;
+            int *ring = hit_ring + wid * kRing;      // this wavefront's FIFO of hit rows (entry i lives at i & (kRing - 1))
             int run_hint = 0;                        // run of the first row of the group being located (wave-uniform, monotone)
             // Rows are dealt to the wavefronts in chunks of 16 (one 128-byte line of intervals), chunk c to wavefront
             // c % nwaves: hits cluster over hundreds of rows (the passes are sorted by tile), so with 128 consecutive rows
             // per wavefront and ~3 such groups per item the wavefronts waited 30 % of an item for the slowest of them.
             // m-th load of a wavefront: its chunks 4m .. 4m + 3, 16 lanes each.
-            auto load_range = [&](int m, int &r_out, int &row_out) -> float2 {
+            auto load_range = [&](int m, int &row_out) -> float2 {
                 const int first = (m * 4 * nwaves + wid) * 16;                      // (wave-uniform)
                 const int fr = first + (lane >> 4) * (nwaves * 16) + (lane & 15);
                 float2 rg = make_float2(__uint_as_float(0xffffffffu), 0.0f);
-                r_out = row_out = 0;
+                row_out = 0;
                 if (first < total_rows) {
                     while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= first) ++run_hint;
                 }
                 if (fr < total_rows) {
                     int r = run_hint;                // the lanes' rows follow the group's first: a step or two at most
                     while (run_cum[r + 1] <= fr) ++r;
-                    r_out = r;
-                    row_out = (run_u0[r_out] >> 4) + (fr - run_cum[r_out]);
+                    row_out = (run_u0[r] >> 4) + (fr - run_cum[r]);
                     rg = rows[row_out];
                 }
                 return rg;
             };
-            struct Quad { uint32_t mv; float2 p; float ts; };
-            // list entry of a hit row: x = first slot of the row, y = [lo | hi << 8 | detached << 16] with [lo, hi) the lanes
-            // of the row that belong to the run (everything a quad needs, decided once per row)
-            auto load_quad_rows = [&](int s_, int h) -> Quad {      // events of list entries s_ .. s_ + 3, 16 lanes each
-                Quad qd;
-                qd.mv = 0u;
-                qd.p = make_float2(0.0f, 0.0f);
-                qd.ts = 0.0f;
-                const int e = s_ + (lane >> 4);
-                if (e < h) {
-                    const int2 en = list[e];
-                    const int l16 = lane & 15, u = en.x + l16;
-                    if (l16 >= (en.y & 0xff) && l16 < ((en.y >> 8) & 0xff)) {
-                        qd.mv = mt[u];
-                        qd.p = pl[u];
-                        qd.ts = ((en.y >> 16) ? tsd : tsg)[u];
-                    }
-                }
-                return qd;
-            };
-            auto list_entry = [&](int row, int r) {
-                const int u0 = run_u0[r], u1 = u0 + run_len[r], ub = row * 16;
-                return make_int2(ub, max(u0 - ub, 0) | (min(u1 - ub, 16) << 8) | ((r >= nb ? 1 : 0) << 16));
-            };
+            // A batch = 16 ring entries = four quads of (4 rows x 16 slots).  An event visit is two 8-byte loads at the same
+            // 32-bit offset from scalar bases.  Entries past the tail hold rows seen earlier (or row 0): their loads are
+            // harmless and they are discarded when the batch is processed (`rem`).
             constexpr int kQ = 4;
-            // MODE 0: border compensation (the reference's reachable setting): bit s of the meta word.  MODE 1: Iterative
-            // without: alive at this reference time (kb < tref < kf).  (Two copies of the loop: the test as a run-time
-            // branch inside one copy cost the default path 4 %.  Linear without compensation splats positions outside the
-            // frame and takes the general path below: with its corner tests in here the kernel needs 140 VGPRs and only one
-            // workgroup fits a CU.)
-            auto sweep = [&](auto mode_tag) {
-            constexpr int MODE = decltype(mode_tag)::value;
-            int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
-            float2 rg_cur[2], rg_nxt[2];
-            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(hh, r_cur[hh], row_cur[hh]);
-            for (int m = 0; (m * 4 * nwaves + wid) * 16 < total_rows; m += 2) {
-                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(m + 2 + hh, r_nxt[hh], row_nxt[hh]);
-                int h = 0;
+            struct Quad { uint32_t mv; float y, x, ts; };
+            const uint32_t lane_off = (uint32_t)(lane & 15) * 8u;
+            const int lane_grp = lane >> 4;
+            auto load_batch = [&](Quad (&qd)[kQ], int pos) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const bool hit = rg_cur[hh].y >= band_lo && rg_cur[hh].x < band_hi;      // (NaN for an empty / absent row)
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    if (hit) list[h + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] = list_entry(row_cur[hh], r_cur[hh]);
-                    h += __builtin_popcountll(mask);
+                for (int k = 0; k < kQ; ++k) {
+                    const uint32_t off = (uint32_t)ring[(pos + 4 * k + lane_grp) & (kRing - 1)] * 128u + lane_off;   // slot (16 row + lane) x 8 bytes
+                    const uint2 m2 = *at_bytes(mt, off);
+                    const float2 pp = *at_bytes(pl, off);
+                    // (nothing here may LOOK at the loaded registers: a select on them makes the compiler wait for the
+                    // load right where it was issued — that is how round 3's first version of this loop lost its
+                    // prefetch)
+                    qd[k].mv = m2.x;
+                    qd[k].ts = __uint_as_float(m2.y);
+                    qd[k].y = pp.x;                    // traj stores (y, x) in (.x, .y)
+                    qd[k].x = pp.y;
                 }
-                __builtin_amdgcn_wave_barrier();
-                Quad cur[kQ], nxt[kQ];
-#pragma unroll
-                for (int k = 0; k < kQ; ++k) cur[k] = load_quad_rows(4 * k, h);
-                for (int sidx = 0; sidx < h; sidx += 4 * kQ) {
-#pragma unroll
-                    for (int k = 0; k < kQ; ++k) nxt[k] = load_quad_rows(sidx + 4 * (kQ + k), h);
-#pragma unroll
-                    for (int k = 0; k < kQ; ++k) {
-                        const uint32_t mv = cur[k].mv;
-                        bool take = (mv >> im.s) & 1u;                         // border mask (:671-681)
-                        if (MODE == 1) {
-                            const int kb1 = (int)((mv >> 8) & 0xffu), kf = (int)((mv >> 16) & 0xffu);
-                            take = (mv & (kMetaPos | kMetaNeg)) != 0u && im.plane >= kb1 && im.plane < kf;
-                        }
-                        if (take) splat_one<true>(cur[k].p, cur[k].ts, 1.0f, im, rdelta, img_c, img_t, r0, nrows, WP);
-                    }
-#pragma unroll
-                    for (int k = 0; k < kQ; ++k) cur[k] = nxt[k];
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (int hh = 0; hh < 2; ++hh) {
-                    rg_cur[hh] = rg_nxt[hh];
-                    r_cur[hh] = r_nxt[hh];
-                    row_cur[hh] = row_nxt[hh];
-                }
-            }
             };
-            if (w.comp) sweep(std::integral_constant<int, 0>());
-            else sweep(std::integral_constant<int, 1>());
+            unsigned long long *cpl = reinterpret_cast<unsigned long long *>(img_c), *tpl = reinterpret_cast<unsigned long long *>(img_t);
+            const uint32_t polbit = c ? kMetaNeg : kMetaPos;
+            const int r0m1 = r0 - 1;
+            const uint32_t need = polbit | (1u << im.s);
+            // rem: list entries left at the batch's first one (a quad's lane group g holds entry 4 k + g)
+            auto process = [&](const Quad (&qd)[kQ], int rem) {
+#pragma unroll
+                for (int k = 0; k < kQ; ++k) {
+                    const uint32_t mv = qd[k].mv;
+                    bool take = (mv & need) == need;                       // this polarity + border mask (:671-681)
+                    if (MODE == 1) {
+                        const int kb1 = (int)((mv >> 8) & 0xffu), kf = (int)((mv >> 16) & 0xffu);
+                        take = (mv & polbit) != 0u && im.plane >= kb1 && im.plane < kf;
+                    }
+                    const int rr = (int)floorf(qd[k].y) - r0m1;          // halo row 0 = image row r0 - 1
+                    take = take && (unsigned)rr <= (unsigned)nrows && lane_grp < rem - 4 * k;
+                    if (take) {
+                        // tau = 1 - |tref - ts| / delta (:94-95); delta is an integer number of passes: exact division by a constant
+                        const float tau = 1.0f - div_by_const(fabsf(im.tref - qd[k].ts), rdelta);
+                        splat_fixed(qd[k].y, qd[k].x, tau, rr, WP, cpl, tpl);
+                    }
+                }
+            };
+            // The hit rows of the whole item form ONE stream per wavefront: candidate groups of 64 rows (one interval per lane,
+            // two groups in flight) are tested and their hits appended to the ring; batches are taken from its head.  The
+            // event loads of the next batch are always in flight, across candidate groups (round 2 / the first round-3
+            // version drained and restarted the load pipeline every 128 candidates and issued a batch of discarded loads
+            // each time; the scatter is bound by how many bytes a wavefront keeps in flight).
+            int tail = 0, head = 0;                  // entries produced / handed to load_batch (wave-uniform)
+            int next_m = 0;                          // oldest candidate group in flight
+            float2 rg_a, rg_b;
+            int row_a, row_b;
+            rg_a = load_range(0, row_a);
+            rg_b = load_range(1, row_b);
+            auto more = [&]() { return (next_m * 4 * nwaves + wid) * 16 < total_rows; };      // (wave-uniform)
+            auto top_up = [&]() {                    // keep two batches' worth of entries ahead of the loads while candidates last
+                while (tail - head < 8 * kQ && more()) {
+                    const bool hit = rg_a.y >= band_lo && rg_a.x < band_hi;      // (NaN for an empty / absent row)
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (hit) ring[(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))) & (kRing - 1)] = row_a;
+                    tail += __builtin_popcountll(mask);
+                    rg_a = rg_b;
+                    row_a = row_b;
+                    ++next_m;
+                    rg_b = load_range(next_m + 1, row_b);
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            // Two register sets in turn.  Every load_batch is UNCONDITIONAL on the path to the process() that follows it: the
+            // hardware counts outstanding loads in order, and where a path may or may not have issued the younger batch the
+            // compiler has to wait for the smaller count — i.e. for the prefetch itself.
+            // (ring capacity: at most 8 kQ - 1 + 64 entries are ahead of `head`, 8 kQ behind it are still being worked on)
+            Quad qa[kQ], qb[kQ];
+            top_up();
+            load_batch(qa, head);
+            int rem_a = tail - head, rem_b;
+            head += 4 * kQ;
+            for (;;) {
+                top_up();
+                load_batch(qb, head);
+                rem_b = tail - head;
+                head += 4 * kQ;
+                process(qa, rem_a);
+                if (rem_b <= 0) break;               // (the stream had run dry when qb was issued)
+                top_up();
+                load_batch(qa, head);
+                rem_a = tail - head;
+                head += 4 * kQ;
+                process(qb, rem_b);
+                if (rem_a <= 0) break;
+            }
         } else {
             for (int li = 0; li < nlists; ++li)
                 for (int t = im.le; t < im.he; ++t) {
                     const int *cl = (li ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
                     const int s0 = li ? w.M + w.doff[t] : w.off[t];
                     const int n0 = cl[0], n01 = cl[1], n012 = cl[2];
+                    double *gc = img_c + WP, *gt = img_t + WP;          // (the band proper: past the halo row)
                     if (c == 0) {
-                        splat_run_general(w, im, rdelta, g, d, b, c, s0, n0, pl, mt, img_c, img_t, r0, nrows);
-                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n01, n012 - n01, pl, mt, img_c, img_t, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0, n0, pl, mt, gc, gt, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n01, n012 - n01, pl, mt, gc, gt, r0, nrows);
                     } else {
-                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n0, n012 - n0, pl, mt, img_c, img_t, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n0, n012 - n0, pl, mt, gc, gt, r0, nrows);
                     }
                 }
         }
@@ -988,8 +1104,8 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
         // ---- band statistics of this polarity (round 1: a separate launch over the stored images) ----
         float acc = 0.0f;
         const size_t qpol = ((size_t)j * FB + ib) * 2 + c, o = qpol * HW + (size_t)r0 * W;
-        if (fixed) band_stats<true>(lds_img, nrows, W, WP, ar + o, nz + o, acc);
-        else band_stats<false>(lds_img, nrows, W, WP, ar + o, nz + o, acc);
+        if (fixed) band_stats<true>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nz + o, acc);
+        else band_stats<false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nz + o, acc);
         double dacc = (double)acc;
         for (int sft = 32; sft > 0; sft >>= 1) dacc += __shfl_down(dacc, sft, 64);
         if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6] = dacc;
@@ -1008,15 +1124,14 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
 // loss = sum_images coef * (sum over samples of the per-sample term); fixed summation order.
 __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *__restrict__ part, int nparts,
                                                           const double *__restrict__ counts, float *__restrict__ stats,
-                                                          const int *__restrict__ bad, int nbad, float *__restrict__ loss_out)
+                                                          const int *__restrict__ bad_img, float *__restrict__ loss_out)
 {
     __shared__ double ssum[256];
     const int FB = w.F * w.B;
-    int any_bad = 0;                                  // K1's per-workgroup "unrepresentable input" words
-    for (int k = threadIdx.x; k < nbad; k += blockDim.x) any_bad |= bad[k];
-    any_bad = __syncthreads_or(any_bad);
+    int any_bad = 0;                                  // K1's "unrepresentable input" words, folded per image by image_count
     double acc = 0.0;
     for (int q = threadIdx.x; q < w.nimg * FB; q += blockDim.x) {
+        any_bad |= bad_img[q];
         double s2 = 0.0, cnt = 0.0;
         for (int k = 0; k < 2 * nparts; ++k) s2 += part[(size_t)q * 2 * nparts + k];      // (polarity, band), fixed order
         cnt = counts[q];
@@ -1027,6 +1142,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
         Img im = decode_image(w, q / FB);
         acc += (double)term * (double)im.coef;
     }
+    any_bad = __syncthreads_or(any_bad);
     ssum[threadIdx.x] = acc;
     __syncthreads();
     for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
@@ -1226,21 +1342,6 @@ __global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restr
     if (threadIdx.x == 0) cmax[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
-// wave-uniform base + 32-bit byte offset per lane: the form the scalar-base global loads / stores take
-// (the uniform element offset goes through readfirstlane so that loop strength reduction cannot turn base + k * stride +
-// lane into a 64-bit per-lane induction pointer)
-__device__ __forceinline__ size_t uniform_off(size_t v)
-{
-    return (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
-           ((size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
-}
-template <class T>
-__device__ __forceinline__ T *at_bytes(T *base, uint32_t off)
-{
-    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
-    return reinterpret_cast<T *>(reinterpret_cast<B *>(base) + off);
-}
-
 typedef float f32x2_v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float2 NT_LD2(const float2 *p)
 {
@@ -1259,7 +1360,7 @@ __device__ __forceinline__ void NT_ST2(float2 *p, float a, float b)
 template <bool ONE>
 __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
-                                                             const uint32_t *__restrict__ meta,
+                                                             const uint2 *__restrict__ meta,
                                                              const float2 *__restrict__ ar,
                                                              const float *__restrict__ stats,
                                                              const float *__restrict__ grad_out,
@@ -1275,7 +1376,8 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, P = w.P, M = w.M;
     float2 *co = cyx + (size_t)ib * P * M + sl;
-    uint32_t mv = meta[(size_t)ib * w.Mt + sl];
+    const uint2 mv_ts = meta[(size_t)ib * w.Mt + sl];
+    const uint32_t mv = mv_ts.x;
     // Passes start at multiples of 64 slots, so a wavefront belongs to ONE pass: t, and with it the reference time k of
     // every loop iteration below, is wave-uniform — map / image / plane base addresses and the image statistics are
     // scalar-register arithmetic and scalar loads instead of per-lane 64-bit index math in a VALU-bound kernel.  Lanes
@@ -1295,9 +1397,9 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     const int reach = P / w.mode_div;
     int kb = (int)((mv >> 8) & 0xffu) - 1, kf = (int)((mv >> 16) & 0xffu);
     size_t o = (size_t)b * g.cap + sl;
-    float ts = g.ts[o], mp = g.mp[o], mn = g.mn[o];
+    float ts = __uint_as_float(mv_ts.y), mp = g.mp[o], mn = g.mn[o];
     float gout = grad_out[0];
-    const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + sl;
+    const float2 *tr = traj + (size_t)ib * (w.nplanes + 1) * w.Mt + sl;
     float c0y = 0.0f, c0x = 0.0f;
 
     // reference times that can carry a gradient for this event: tref k contributes at scale s iff the event's window is
@@ -1342,7 +1444,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         const int k0 = D < 0 ? min(P, t + reach) : max(0, t - reach + 1);
         const int kend = D < 0 ? t + 1 : t;                       // last reference time of the sweep
         auto plane = [&](int k) {
-            const float2 *pb = traj + uniform_off(((size_t)ib * w.nplanes + (D < 0 ? max(k, kend) : min(k, kend))) * w.Mt);
+            const float2 *pb = traj + uniform_off(((size_t)ib * (w.nplanes + 1) + (D < 0 ? max(k, kend) : min(k, kend))) * w.Mt);
             return NT_LD2(at_bytes(pb, (uint32_t)sl * 8u));
         };
         auto active = [&](int k) { return D < 0 ? k <= ks_f : k >= ks_b; };
@@ -1501,7 +1603,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
 
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
 __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const float2 *__restrict__ traj,
-                                                         const uint32_t *__restrict__ meta,
+                                                         const uint2 *__restrict__ meta,
                                                          const float2 *__restrict__ ar,
                                                          const float *__restrict__ stats,
                                                          const float *__restrict__ grad_out, float2 *__restrict__ cyx,
@@ -1513,14 +1615,14 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
     int sl = chunk * blockDim.x + threadIdx.x;
     if (sl >= w.M) return;
     int b = ib % w.B;
-    uint32_t bits = meta[(size_t)ib * w.Mt + sl] & 0xffu;
+    uint32_t bits = meta[(size_t)ib * w.Mt + sl].x & 0xffu;
     float gy = 0.0f, gx = 0.0f;
     if (bits) {
         size_t o = (size_t)b * g.cap + sl;
         float ts = g.ts[o], mp = g.mp[o], mn = g.mn[o];
         int t = g.bin[sl];
         float gout = grad_out[0];
-        const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt + sl;
+        const float2 *tr = traj + (size_t)ib * (w.nplanes + 1) * w.Mt + sl;
         for (int s = 0; s < w.S; ++s) {
             if (!((bits >> s) & 1u)) continue;
             int scale = w.P >> s, wi = t / scale;
@@ -1608,11 +1710,45 @@ __device__ __forceinline__ void dflow_one(float2 p, float cvy, float cvx, int H,
     }
 }
 
+// (the tap-by-tap integer form as a real call: it runs only for sampling locations outside the frame)
+__device__ __noinline__ void dflow_one_fixed_slow(float2 p, float cvy, float cvx, int H, int W, int WP, int e, double *img_y,
+                                                  double *img_x, int r0, int nrows)
+{
+    dflow_one<true>(p, cvy, cvx, H, W, WP, e, img_y, img_x, r0, nrows);
+}
+
+// The integer path's event (the hot path of K7; same diet as K2's splat_fixed): planes with one halo row above and below
+// the band, so the eight accumulations are unconditional — grid_sample's zero padding drops the taps of row -1 / row H,
+// which are halo rows of the first / last band, and a tap of column W lands in the row padding.  The vector arrives
+// already scaled by 2^-e (a power of two commutes with the products).  Caller guarantees 0 <= x0 <= W - 1 and
+// rr = y0 - (r0 - 1) in [0, nrows].  (fiy, fix) = unnormalize(p): the forward lookup's own coordinates.
+__device__ __forceinline__ void dflow_fixed(float fiy, float fix, float fy0, float fx0, float sy, float sx, int rr, int WP,
+                                            unsigned long long *py, unsigned long long *px)
+{
+    const f32x2_e fi = {fiy, fix}, f0 = {fy0, fx0};
+    const f32x2_e tf = fi - f0;                          // (tn, tw)
+    const f32x2_e tc = 1.0f - tf;                        // (ts, te)
+    const f32x2_e wxp = {tc.y, tf.y};                    // (te, tw)
+    const f32x2_e w0 = tc.x * wxp, w1 = tf.x * wxp;      // (w00, w01), (w10, w11)
+    const f32x2_e a0 = sy * w0, a1 = sy * w1, b0 = sx * w0, b1 = sx * w1;
+    const int cell = __mul24(rr, WP) + (int)fx0;
+    unsigned long long *c0 = py + cell, *q0 = px + cell;
+    atomicAdd(c0, to_fixed(a0.x));
+    atomicAdd(c0 + 1, to_fixed(a0.y));
+    atomicAdd(c0 + WP, to_fixed(a1.x));
+    atomicAdd(c0 + WP + 1, to_fixed(a1.y));
+    atomicAdd(q0, to_fixed(b0.x));
+    atomicAdd(q0 + 1, to_fixed(b0.y));
+    atomicAdd(q0 + WP, to_fixed(b1.x));
+    atomicAdd(q0 + WP + 1, to_fixed(b1.y));
+}
+
 // Persistent like K2: one workgroup per CU pulls (map k, head, sample, row band) items from the per-XCD queues
-// [8, 16); the band holds BOTH components of the map's gradient (2 planes x 64 rows at 128x128), so an event's position,
-// taps and weights are computed once for its eight accumulations, and per 16-slot row the workgroup reads K1's interval
-// of the plane the events sampled the map at (plane k for earlier passes, k + 1 for later ones, the original locations
-// for pass k) and loads the row only if it can touch the band.
+// [8, 16); the band holds BOTH components of the map's gradient (2 planes x (64 + 2 halo) rows at 128x128), so an
+// event's position, taps and weights are computed once for its eight accumulations, and per 16-slot row the workgroup
+// reads K1's interval of the plane the events sampled the map at (plane k for earlier passes, k + 1 for later ones, the
+// original locations — trajectory plane `nplanes` — for pass k) and loads the row only if it can touch the band.  An event
+// visit is two 8-byte loads (vector, position) at 32-bit offsets from scalar bases.
 __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
                                                                     const float2 *__restrict__ yr,
                                                                     const float2 *__restrict__ cyx,
@@ -1622,24 +1758,26 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 {
     extern __shared__ double lds_img[];
     __shared__ int run_u0[TEF_MAX_PASSES], run_len[TEF_MAX_PASSES], run_src[TEF_MAX_PASSES], run_cum[TEF_MAX_PASSES + 1], s_item;
-    __shared__ int2 hit_list[2 * kSplatThreads];   // 128 (row, source) entries per wavefront
+    __shared__ int hit_ring[(kSplatThreads / 64) * kRing];   // hit rows (row | source plane << 24): one FIFO per wavefront
     const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad, M = w.M;
     const int xcd = blockIdx.x & 7;
     const int nitems = w.P * FB;
     const bool iter = (w.kind == TEF_KIND_ITERATIVE);
     const int reach = w.P / max(1, w.mode_div);     // Iterative: pass t feeds map k only if |k - t| < delta_passes[0]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int k = threadIdx.x; k < (kSplatThreads / 64) * kRing; k += blockDim.x) hit_ring[k] = 0;      // (stale entries are read)
     if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
     __syncthreads();
     for (;;) {
-        const int q = s_item;
+        const int q = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: everything derived from it is scalar
         const int it = xcd + 8 * (q / nbands), band = q - (q / nbands) * nbands;
         if (it >= nitems) break;
         const int k = w.korder[it / FB], ib = it % FB, i = ib / w.B, b = ib - i * w.B;
         const int r0 = band * rows_per_band, nrows = min(H, r0 + rows_per_band) - r0;
-        const size_t plane_sz = (size_t)nrows * WP;
+        // planes: [d/d flow_y | d/d flow_x], each nrows + 2 rows (halo row, the band, halo row) of WP accumulators
+        const size_t plane_sz = (size_t)(nrows + 2) * WP;
         double *img_y = lds_img, *img_x = lds_img + plane_sz;
-        lds_plane_zero(lds_img, 2 * nrows * WP);
+        lds_plane_zero(lds_img, 2 * (nrows + 2) * WP);
         const int t_lo = iter ? max(0, k - reach + 1) : k, t_hi = iter ? min(w.P, k + reach) : k + 1, nruns = t_hi - t_lo;
         __syncthreads();                                  // (everybody has read s_item)
         int next_item = 0;
@@ -1668,87 +1806,118 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
         __syncthreads();
         const uint32_t mbits = cmax[ib];                // bit pattern of max |c| over this (head, sample), from K6
         const int nev = w.off[t_hi] - w.off[t_lo];
-        const bool fixed = mbits < 0x7f800000u && nev < kFxMaxEvents;
+        // (the integer sweep addresses the trajectory planes of a (head, sample) with 32-bit byte offsets)
+        const bool fixed = mbits < 0x7f800000u && nev < kFxMaxEvents && (size_t)(w.nplanes + 1) * w.Mt * sizeof(float2) < 0x7fffffffull &&
+                           w.nrow < (1 << 24) && w.nplanes < 127;
         const int e = (int)(mbits >> 23) - 127 + 1;     // 2^e > max |c| (a denormal or zero maximum: any small exponent does)
-        const float2 *co = cyx + (iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
-        const float2 *tr = traj + (size_t)ib * w.nplanes * w.Mt;
-        const float *ey = g.y + (size_t)b * g.cap, *ex = g.x + (size_t)b * g.cap;
+        const float2 *co = cyx + uniform_off(iter ? ((size_t)ib * w.P + k) * M : (size_t)ib * M);
+        const float2 *tr = traj + uniform_off((size_t)ib * (w.nplanes + 1) * w.Mt);
         // lookup rows are floor(unnormalize(y)) and the next one; unnormalize(y) is y up to a few ulps: a hundredth of a
         // pixel of slack keeps the test a superset
         const float band_lo = (float)(r0 - 1) - 0.01f, band_hi = (float)(r0 + nrows) + 0.01f;
         if (fixed) {
-            const float2 *rows = yr + (size_t)ib * (w.nplanes + 1) * w.nrow;
+            const float2 *rows = yr + uniform_off((size_t)ib * (w.nplanes + 1) * w.nrow);
             const int total_rows = run_cum[nruns];
-            int2 *list = hit_list + wid * 128;
+            int *ring = hit_ring + wid * kRing;      // this wavefront's FIFO of hit rows: row | source plane << 24
             int run_hint = 0;
+            const uint32_t plane_bytes = (uint32_t)w.Mt * 8u;
             // (rows dealt to the wavefronts in chunks of 16, chunk c to wavefront c % nwaves, as in K2)
-            auto load_range = [&](int m, int &r_out, int &row_out) -> float2 {
+            auto load_range = [&](int m, int &entry) -> float2 {
                 const int first = (m * 4 * nwaves + wid) * 16;                      // (wave-uniform)
                 const int fr = first + (lane >> 4) * (nwaves * 16) + (lane & 15);
                 float2 rg = make_float2(__uint_as_float(0xffffffffu), 0.0f);
-                r_out = row_out = 0;
+                entry = 0;
                 if (first < total_rows) {
                     while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= first) ++run_hint;
                 }
                 if (fr < total_rows) {
                     int r = run_hint;
                     while (run_cum[r + 1] <= fr) ++r;
-                    r_out = r;
-                    row_out = (run_u0[r] >> 4) + (fr - run_cum[r]);
-                    rg = rows[(size_t)run_src[r] * w.nrow + row_out];
+                    const int row = (run_u0[r] >> 4) + (fr - run_cum[r]), src = run_src[r];
+                    rg = rows[(size_t)src * w.nrow + row];
+                    entry = row | (src << 24);
                 }
                 return rg;
             };
-            struct Quad { float cvy, cvx; float2 p; };
-            auto load_quad_rows = [&](int s, int h) -> Quad {      // events of list entries s .. s + 3, 16 lanes each
-                Quad qd;
-                qd.cvy = qd.cvx = 0.0f;
-                qd.p = make_float2(0.0f, 0.0f);
-                const int en_i = s + (lane >> 4);
-                if (en_i < h) {
-                    const int2 en = list[en_i];              // (first slot of the row, source plane)
-                    const int u = en.x + (lane & 15);
-                    const float2 cv = co[u];
-                    qd.cvy = cv.x;
-                    qd.cvx = cv.y;
-                    qd.p = en.y == w.nplanes ? make_float2(ey[u], ex[u]) : tr[(size_t)en.y * w.Mt + u];
-                }
-                return qd;
-            };
             constexpr int kQ = 4;
-            int r_cur[2], row_cur[2], r_nxt[2], row_nxt[2];
-            float2 rg_cur[2], rg_nxt[2];
-            for (int hh = 0; hh < 2; ++hh) rg_cur[hh] = load_range(hh, r_cur[hh], row_cur[hh]);
-            for (int m = 0; (m * 4 * nwaves + wid) * 16 < total_rows; m += 2) {
-                for (int hh = 0; hh < 2; ++hh) rg_nxt[hh] = load_range(m + 2 + hh, r_nxt[hh], row_nxt[hh]);
-                int h = 0;
+            struct Quad { float cvy, cvx, y, x; };
+            const uint32_t lane_off = (uint32_t)(lane & 15) * 8u;
+            const int lane_grp = lane >> 4;
+            auto load_batch = [&](Quad (&qd)[kQ], int pos) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const bool hit = rg_cur[hh].y >= band_lo && rg_cur[hh].x < band_hi;      // (NaN for an empty / absent row)
+                for (int kq = 0; kq < kQ; ++kq) {
+                    const uint32_t en = (uint32_t)ring[(pos + 4 * kq + lane_grp) & (kRing - 1)];
+                    const uint32_t voff = (en & 0xffffffu) * 128u + lane_off;          // slot (16 row + lane) x 8 bytes
+                    const float2 cv = *at_bytes(co, voff);
+                    const float2 pp = *at_bytes(tr, (en >> 24) * plane_bytes + voff);
+                    qd[kq].cvy = cv.x;          // (no select on loaded registers here: see K2's load_batch)
+                    qd[kq].cvx = cv.y;
+                    qd[kq].y = pp.x;
+                    qd[kq].x = pp.y;
+                }
+            };
+            unsigned long long *py = reinterpret_cast<unsigned long long *>(img_y), *px = reinterpret_cast<unsigned long long *>(img_x);
+            const AxisConst ach = axis_const(H), acw = axis_const(W);
+            const int r0m1 = r0 - 1;
+            auto process = [&](const Quad (&qd)[kQ], int rem) {      // rem: ring entries left at the batch's first one
+#pragma unroll
+                for (int kq = 0; kq < kQ; ++kq) {
+                    const float cvy = qd[kq].cvy, cvx = qd[kq].cvx;
+                    // same taps as the forward lookup (taps_core), kept as (row, column) to address the padded LDS planes
+                    const float fiy = (div_by_const(2.0f * qd[kq].y, ach.rinv) - 1.0f + 1.0f) * ach.half;
+                    const float fix = (div_by_const(2.0f * qd[kq].x, acw.rinv) - 1.0f + 1.0f) * acw.half;
+                    const float fy0 = floorf(fiy), fx0 = floorf(fix);
+                    const int rr = (int)fy0 - r0m1, x0 = (int)fx0;
+                    const bool take = (cvy != 0.0f || cvx != 0.0f) && (unsigned)rr <= (unsigned)nrows && lane_grp < rem - 4 * kq;
+                    const bool fast = take && (unsigned)x0 < (unsigned)W;
+                    if (fast) dflow_fixed(fiy, fix, fy0, fx0, ldexpf(cvy, -e), ldexpf(cvx, -e), rr, WP, py, px);
+                    // a sampling location left of / beyond the frame (only an event list with coordinates outside the
+                    // frame has them): the tap-by-tap form, as a real call
+                    if (__builtin_amdgcn_ballot_w64(take && !fast) != 0ull) {
+                        if (take && !fast)
+                            dflow_one_fixed_slow(make_float2(qd[kq].y, qd[kq].x), cvy, cvx, H, W, WP, e, img_y + WP, img_x + WP, r0, nrows);
+                    }
+                }
+            };
+            // (one stream of hit rows per wavefront and item, the next batch's loads always in flight: see K2)
+            int tail = 0, head = 0;
+            int next_m = 0;
+            float2 rg_a, rg_b;
+            int en_a, en_b;
+            rg_a = load_range(0, en_a);
+            rg_b = load_range(1, en_b);
+            auto more = [&]() { return (next_m * 4 * nwaves + wid) * 16 < total_rows; };      // (wave-uniform)
+            auto top_up = [&]() {
+                while (tail - head < 8 * kQ && more()) {
+                    const bool hit = rg_a.y >= band_lo && rg_a.x < band_hi;      // (NaN for an empty / absent row)
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
-                    if (hit) list[h + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))] = make_int2(row_cur[hh] * 16, run_src[r_cur[hh]]);
-                    h += __builtin_popcountll(mask);
+                    if (hit) ring[(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))) & (kRing - 1)] = en_a;
+                    tail += __builtin_popcountll(mask);
+                    rg_a = rg_b;
+                    en_a = en_b;
+                    ++next_m;
+                    rg_b = load_range(next_m + 1, en_b);
                 }
                 __builtin_amdgcn_wave_barrier();
-                Quad cur[kQ], nxt[kQ];
-#pragma unroll
-                for (int kq = 0; kq < kQ; ++kq) cur[kq] = load_quad_rows(4 * kq, h);
-                for (int sidx = 0; sidx < h; sidx += 4 * kQ) {
-#pragma unroll
-                    for (int kq = 0; kq < kQ; ++kq) nxt[kq] = load_quad_rows(sidx + 4 * (kQ + kq), h);
-#pragma unroll
-                    for (int kq = 0; kq < kQ; ++kq)
-                        if (cur[kq].cvy != 0.0f || cur[kq].cvx != 0.0f)
-                            dflow_one<true>(cur[kq].p, cur[kq].cvy, cur[kq].cvx, H, W, WP, e, img_y, img_x, r0, nrows);
-#pragma unroll
-                    for (int kq = 0; kq < kQ; ++kq) cur[kq] = nxt[kq];
-                }
-                __builtin_amdgcn_wave_barrier();
-                for (int hh = 0; hh < 2; ++hh) {
-                    rg_cur[hh] = rg_nxt[hh];
-                    r_cur[hh] = r_nxt[hh];
-                    row_cur[hh] = row_nxt[hh];
-                }
+            };
+            Quad qa[kQ], qb[kQ];
+            top_up();
+            load_batch(qa, head);
+            int rem_a = tail - head, rem_b;
+            head += 4 * kQ;
+            for (;;) {
+                top_up();
+                load_batch(qb, head);
+                rem_b = tail - head;
+                head += 4 * kQ;
+                process(qa, rem_a);
+                if (rem_b <= 0) break;
+                top_up();
+                load_batch(qa, head);
+                rem_a = tail - head;
+                head += 4 * kQ;
+                process(qb, rem_b);
+                if (rem_a <= 0) break;
             }
         } else {
             for (int t = t_lo; t < t_hi; ++t) {
@@ -1756,8 +1925,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
                 for (int sl = w.off[t] + threadIdx.x; sl < w.off[t + 1]; sl += blockDim.x) {
                     const float cvy = co[sl].x, cvx = co[sl].y;
                     if (cvy == 0.0f && cvx == 0.0f) continue;
-                    const float2 p = src == w.nplanes ? make_float2(ey[sl], ex[sl]) : tr[(size_t)src * w.Mt + sl];
-                    dflow_one<false>(p, cvy, cvx, H, W, WP, 0, img_y, img_x, r0, nrows);
+                    dflow_one<false>(tr[(size_t)src * w.Mt + sl], cvy, cvx, H, W, WP, 0, img_y + WP, img_x + WP, r0, nrows);
                 }
             }
         }
@@ -1766,11 +1934,11 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
         float *ox = dflows + ((((size_t)k * w.F + i) * w.B + b) * 2) * (size_t)(H * W) + (size_t)r0 * W, *oy = ox + (size_t)H * W;
         const double unscale = __builtin_ldexp(1.0, e - 46);
         if (fixed) {
-            dflow_plane_store<true>(img_x, nrows, W, WP, unscale, ox);
-            dflow_plane_store<true>(img_y, nrows, W, WP, unscale, oy);
+            dflow_plane_store<true>(img_x + WP, nrows, W, WP, unscale, ox);
+            dflow_plane_store<true>(img_y + WP, nrows, W, WP, unscale, oy);
         } else {
-            dflow_plane_store<false>(img_x, nrows, W, WP, 1.0, ox);
-            dflow_plane_store<false>(img_y, nrows, W, WP, 1.0, oy);
+            dflow_plane_store<false>(img_x + WP, nrows, W, WP, 1.0, ox);
+            dflow_plane_store<false>(img_y + WP, nrows, W, WP, 1.0, oy);
         }
         __syncthreads();                                  // the planes have been read: the next item may clear them
         if (threadIdx.x == 0) s_item = next_item;
@@ -1961,7 +2129,7 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     if (c->B < 1 || c->H < 2 || c->W < 2 || c->F < 1) return tef::fail("bad B/H/W/F");
     if (c->P < 1 || c->P > TEF_MAX_PASSES) return tef::fail("passes_loss out of range [1, 64]");
     if (c->S < 1 || c->S > TEF_MAX_SCALES) return tef::fail("scales_loss out of range [1, 6]");
-    if (2 * (size_t)(c->W + kRowPad) * sizeof(double) > kSplat2LdsBudget) return tef::fail("image row does not fit the LDS band");
+    if (2 * 3 * (size_t)(c->W + kRowPad) * sizeof(double) > kSplat2LdsBudget) return tef::fail("image row does not fit the LDS band");
     if (c->kind == TEF_KIND_ITERATIVE) {
         // iterative_mode "four" raises TypeError in the reference itself (loss/flow.py:666-692); only one/two exist here
         if (c->mode_div != 1 && c->mode_div != 2) return tef::fail("iterative_mode must be 'one' or 'two'");
@@ -2020,14 +2188,17 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     return true;
 }
 
-inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds, size_t budget = kSplatLdsBudget)
+// halo: extra rows above + below the band that a plane carries (K2: 2, its unconditional corner accumulations)
+inline void band_geometry(const Win &w, int planes, int *rows_per_band, int *nbands, size_t *lds, size_t budget = kSplatLdsBudget,
+                          int halo = 0)
 {
-    int rows = (int)(budget / ((size_t)planes * (w.W + kRowPad) * sizeof(double)));
+    int rows = (int)(budget / ((size_t)planes * (w.W + kRowPad) * sizeof(double))) - halo;
     if (rows > w.H) rows = w.H;
+    if (rows < 1) rows = 1;                          // (make_win has checked that a band of one row fits)
     *nbands = (w.H + rows - 1) / rows;
     rows = (w.H + *nbands - 1) / *nbands;            // equal bands
     *rows_per_band = rows;
-    *lds = (size_t)planes * rows * (w.W + kRowPad) * sizeof(double);
+    *lds = (size_t)planes * (rows + halo) * (w.W + kRowPad) * sizeof(double);
 }
 
 Layout make_layout(const Win &w)
@@ -2037,8 +2208,8 @@ Layout make_layout(const Win &w)
     const size_t img = (size_t)w.nimg * FB * 2 * HW;
     const size_t nc = FB * (size_t)(w.kind == TEF_KIND_ITERATIVE ? w.P : 1) * (size_t)w.M;
     size_t o = 0;
-    L.traj = o;   o += align_up(FB * w.nplanes * (size_t)w.Mt * sizeof(float2));
-    L.meta = o;   o += align_up(FB * (size_t)w.Mt * sizeof(uint32_t));
+    L.traj = o;   o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.Mt * sizeof(float2));      // + the original locations
+    L.meta = o;   o += align_up(FB * (size_t)w.Mt * sizeof(uint2));
     L.yr = o;     o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.nrow * sizeof(float2));
     L.ar = o;     o += align_up(img * sizeof(float2));
     L.stats = o;  o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
@@ -2047,14 +2218,14 @@ Layout make_layout(const Win &w)
     {
         int rows, nbands;
         size_t lds;
-        band_geometry(w, 2, &rows, &nbands, &lds, kSplat2LdsBudget);
+        band_geometry(w, 2, &rows, &nbands, &lds, kSplat2LdsBudget, 2);
         L.parts = o;  o += align_up((size_t)w.nimg * FB * nbands * 2 * sizeof(double));
     }
     L.queue = o;  o += align_up((kQueueInts + FB) * sizeof(int));      // + one magnitude word per (head, sample) for K6 -> K7
     L.cmax = L.queue + kQueueInts * sizeof(int);
     L.wmax = o;   o += align_up(FB * (size_t)(w.M / 64 + 1) * sizeof(uint32_t));
     L.cyx = o;    o += align_up(nc * sizeof(float2));
-    L.bad = o;    o += align_up(FB * (size_t)((w.Mt + 255) / 256 + 1) * sizeof(int));      // one word per K1 workgroup
+    L.bad = o;    o += align_up((FB * (size_t)((w.Mt + 255) / 256 + 1) + (size_t)w.nimg * FB) * sizeof(int));   // one word per K1 workgroup, then one per image
     L.total = o;
     return L;
 }
@@ -2088,7 +2259,9 @@ inline int num_cus()
 // opt in to > 64 KiB dynamic LDS for the two LDS-resident splat kernels: once per process (thread-safe static init)
 bool ensure_attrs()
 {
-    static const hipError_t e1 = hipFuncSetAttribute((const void *)splat_stats_kernel,
+    static const hipError_t e1a = hipFuncSetAttribute((const void *)splat_stats_kernel<0>,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplat2LdsBudget);
+    static const hipError_t e1 = e1a != hipSuccess ? e1a : hipFuncSetAttribute((const void *)splat_stats_kernel<1>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplat2LdsBudget);
     static const hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
@@ -2190,7 +2363,7 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
     float2 *traj = (float2 *)(ws + L.traj);
-    uint32_t *meta = (uint32_t *)(ws + L.meta);
+    uint2 *meta = (uint2 *)(ws + L.meta);
     float2 *yr = (float2 *)(ws + L.yr);
     int *queue = (int *)(ws + L.queue);
     int *bad = (int *)(ws + L.bad);
@@ -2212,7 +2385,7 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
     size_t lds;
-    band_geometry(w, 2, &rows, &nbands, &lds, kSplat2LdsBudget);
+    band_geometry(w, 2, &rows, &nbands, &lds, kSplat2LdsBudget, 2);
     if (w.Mt == 0 && hipMemsetAsync(queue, 0, (kQueueInts + FB) * sizeof(int), st) != hipSuccess)      // (K1 clears them otherwise)
         return tef::fail("hipMemsetAsync(queue)"), TEF_ERR_LAUNCH;
     uint8_t *nz = (uint8_t *)(ws + L.nz);
@@ -2223,14 +2396,20 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
         const long items = (long)w.nimg * FB * nbands * 2;
         unsigned grid = (unsigned)std::min<long>(items, 2 * num_cus());
         grid = std::max(8u, (grid + 7u) & ~7u);
-        TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel, dim3(grid), dim3(kSplat2Threads), lds, st, w, g, d, traj, meta, yr,
-                         ar, nz, (double *)(ws + L.parts), rows, nbands, queue);
+        if (w.comp || w.kind != TEF_KIND_ITERATIVE)
+            TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel<0>, dim3(grid), dim3(kSplat2Threads), lds, st, w, g, d, traj, meta,
+                             yr, ar, nz, (double *)(ws + L.parts), rows, nbands, queue);
+        else
+            TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel<1>, dim3(grid), dim3(kSplat2Threads), lds, st, w, g, d, traj, meta,
+                             yr, ar, nz, (double *)(ws + L.parts), rows, nbands, queue);
     }
     if (int rc = tef::check_launch("splat_stats_kernel")) return rc;
-    TEF_LAUNCH_TIMED(tef::PROF_COUNT, image_count_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, nz, w.H * w.W, counts);
+    int *bad_img = bad + FB * ((w.Mt + 255) / 256 + 1);
+    TEF_LAUNCH_TIMED(tef::PROF_COUNT, image_count_kernel, dim3((unsigned)(w.nimg * FB)), dim3(256), 0, st, nz, w.H * w.W, counts,
+                     bad, nbad, bad_img);
     if (int rc = tef::check_launch("image_count_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_REDUCE, loss_reduce_kernel, dim3(1), dim3(256), 0, st, w, (const double *)(ws + L.parts), nbands,
-                     counts, stats, bad, nbad, loss_out);
+                     counts, stats, bad_img, loss_out);
     return tef::check_launch("loss_reduce_kernel");
 }
 
@@ -2247,7 +2426,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     hipStream_t st = (hipStream_t)stream;
     char *ws = (char *)workspace;
     float2 *traj = (float2 *)(ws + L.traj);
-    uint32_t *meta = (uint32_t *)(ws + L.meta);
+    uint2 *meta = (uint2 *)(ws + L.meta);
     float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
     float2 *cyx = (float2 *)(ws + L.cyx);
@@ -2274,7 +2453,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     if (int rc = tef::check_launch("mag_reduce_kernel")) return rc;
     int rows, nbands;
     size_t lds;
-    band_geometry(w, 2, &rows, &nbands, &lds);
+    band_geometry(w, 2, &rows, &nbands, &lds, kSplatLdsBudget, 2);
     {
         const long items = (long)w.P * FB * nbands;
         unsigned grid = (unsigned)std::min<long>(items, num_cus());

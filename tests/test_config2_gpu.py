@@ -4,8 +4,9 @@
 (a) the fused pass engine (one autograd node per pass, hand-written backward: models/engine.py) against the same network
     run layer by layer through the modules' own autograd nodes (reference models/arch.py:217-242, models/model.py:65-85):
     the 40 flow maps, the 4 recurrent states and every parameter gradient of the window;
-(b) the HIP loss on the flows the NETWORK produces (random-init weights: |flow| << 1 px, SURVEY.md section 8d flow set iii —
-    nothing like the 2 px synthetic flows of the other tests) against the CPU oracle: loss and d loss / d flow.
+(b) the HIP loss on the flows the NETWORK produces (SURVEY.md section 8d flow set iii — coarse-to-fine heads with very
+    different magnitudes, nothing like the 2 px synthetic flows of the other tests) against the CPU oracle: loss and
+    d loss / d flow.
 """
 import numpy as np
 import pytest
@@ -87,7 +88,7 @@ def test_configs2_full_size():
     # (b) HIP loss vs the CPU oracle on the network-produced flows
     from oracle import oracle
 
-    assert max(np.abs(f).max() for row in fa for f in row) < 1.0          # flow set iii: |flow| << 1 px
+    print("largest |flow| the network produced: %.3f px" % max(np.abs(f).max() for row in fa for f in row))
     ow = oracle.Window(fa, [e[0] for e in evs], [e[1] for e in evs], [empty[0]] * P, [empty[1]] * P, S=1, mode="two")
     ol, od = ow.iterative()
     assert abs(la - ol) <= 1e-4 * abs(ol), (la, float(ol))
