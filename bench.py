@@ -287,6 +287,8 @@ def main():
     if graphs and a.step_graph == "auto":
         # which launch path does this host sustain?  a short untimed probe of both; the graph is used when it is faster
         def probe_ms(fn, n=24):
+            for k in range(4):          # (after the captures the caching allocator has to find the eager path's 0.7 GB workspaces
+                fn(k)                   # again: without these the probe timed two hipMallocs — 1.1 ms "per step" on a 0.65 ms path)
             torch.cuda.synchronize()
             t0_ = time.perf_counter()
             for k in range(n):
@@ -430,6 +432,8 @@ def main():
             "value_including_update": round(events_per_step * world / (elapsed / a.steps + t_update), 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
             "launch_probe": probe,
+            # the eager launch path (what a drop-in caller of the loss module runs: Python + ctypes + 7 launches per step)
+            "eager_ms": None if probe is None else probe["eager_ms"],
             "kernel_events_every": None if a.no_kernel_events else event_every,
             "roofline": roofline,
             "kernels": kernels,
@@ -547,20 +551,30 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
     for _ in range(a.warmup):
         window()
     barrier()
-    lib.tef_profile_enable(0 if a.no_kernel_events else 1)
+    # (the timed region runs WITHOUT per-kernel events: two hipEventRecords around each of the ~1300 launches of a window
+    # cost an eager window 10 ms of host time — the per-kernel times come from one extra, untimed eager window below)
+    lib.tef_profile_enable(0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         window()
     t_enqueue = time.perf_counter() - t0
     barrier()
     elapsed = time.perf_counter() - t0
-    lib.tef_profile_collect()
     kern = {}
-    for s in range(lib.tef_profile_slots()):
-        n = lib.tef_profile_calls(s)
-        if n:
-            kern[lib.tef_profile_name(s).decode()] = (lib.tef_profile_ms(s), n)
-    lib.tef_profile_enable(0)
+    if not a.no_kernel_events:
+        lib.tef_profile_enable(1)
+        if a.graph:          # a graph replay carries no per-launch events: one eager window on the same static inputs
+            for b in window.inputs:
+                tr.step({k: v.clone() for k, v in b.items()}, new_seq=False)
+        else:
+            window()
+        torch.cuda.synchronize()
+        lib.tef_profile_collect()
+        for s in range(lib.tef_profile_slots()):
+            n = lib.tef_profile_calls(s)
+            if n:
+                kern[lib.tef_profile_name(s).decode()] = (lib.tef_profile_ms(s) * a.steps, n)      # (scaled: reported per window below)
+        lib.tef_profile_enable(0)
     if dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -702,10 +716,22 @@ def train_extra(a, torch, dev):
             window()
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / n
-        # the conv kernels' own time needs per-launch events, which a graph replay does not carry: one eager window
+        # the same window launched eagerly (what a drop-in train_flow.py loop does: one C call per network pass and direction)
+        def eager_window():
+            for b in window.inputs:
+                tr.step({k: v.clone() for k, v in b.items()}, new_seq=False)
+
+        eager_window()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eager_window()
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        eager_ms = 1e3 * (time.perf_counter() - t0) / 3
+        # the conv kernels' own time needs per-launch events, which a graph replay does not carry: one more eager window
         lib.tef_profile_enable(1)
-        for b in window.inputs:
-            tr.step({k: v.clone() for k, v in b.items()}, new_seq=False)
+        eager_window()
         torch.cuda.synchronize()
         lib.tef_profile_collect()
         conv_ms = sum(lib.tef_profile_ms(s_) for s_ in range(lib.tef_profile_slots())
@@ -718,6 +744,7 @@ def train_extra(a, torch, dev):
         return {"workload": "training window as one hipGraph (bench.py --mode train --graph): RecEVFlowNet fwd + loss + BPTT "
                             "+ clip + Adam, BASELINE configs[2]",
                 "train_window_ms": round(ms, 3), "train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": n,
+                "train_window_eager_ms": round(eager_ms, 3), "train_window_eager_host_enqueue_ms": round(1e3 * t_host / 3, 3),
                 "conv_ms_per_window_eager": round(conv_ms, 3), "conv_tflops": round(flops / (conv_ms * 1e-3) / 1e12, 2),
                 "conv_frac_of_fp32_mfma_peak": round(flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
     except Exception as e:                                    # noqa: BLE001

@@ -303,6 +303,59 @@ int tef_grad_act(const float *const *dy, int ndy, const float *out, int act, int
 /* out = act(a + b), n elements: the residual connection of ResidualBlock (models/submodules.py:219-226). */
 int tef_add_act(const float *a, const float *b, int act, size_t n, float *out, void *stream);
 
+/* ---- RecEVFlowNet: one recurrent pass as ONE call (models/arch.py:217-242 + models/model.py:65-85) -------------------
+ * The layer table of the reference's default architecture — `levels` x (strided 3x3 head convolution, ConvGRU cell),
+ * `nres` residual blocks, `levels` x (bilinear x2 of (features + encoder skip) [and of the previous prediction], 3x3
+ * convolution over the two sources, 1x1 prediction head), each prediction brought to the input size x 2^level x
+ * flow_scale and cropped — walked in C: every launch of the pass is enqueued from a single call.  The caller owns
+ *   - the packed weights / biases / gradient accumulators of every convolution (tef_net_conv; tef_conv_pack_weight),
+ *   - ONE activation arena per pass ("tape", tef_net_tape_floats floats: everything the backward reads + the pass's
+ *     outputs: the flows and the new states live in it at the offsets tef_net_layout reports),
+ *   - ONE gradient arena per backward call (tef_net_gtape_floats floats: pre-activation gradients, the gradients w.r.t.
+ *     the incoming states and the input at the reported offsets, scratch),
+ *   - one workspace (tef_net_workspace_bytes) shared by all launches of a stream. */
+#define TEF_NET_MAX_LEVELS 6
+#define TEF_NET_MAX_RES 4
+typedef struct tef_net_conv {
+    const float *wp, *w2;        /* packed weight: forward / input-gradient GEMM operands (tef_conv_pack_weight) */
+    const float *bias;           /* [N] or NULL (ConvGRU update|reset gates: the two biases concatenated) */
+    float *dw, *dw2;             /* weight-gradient accumulators (+=); dw2: second row block (reset gate) or NULL */
+    float *db, *db2;             /* bias-gradient accumulators (+=) or NULL */
+    int defer;                   /* 1: leave the weight gradient to tef_net_window_wgrads (the pre-activation gradient
+                                    stays in the gradient arena); layers tef_conv_wgrad_parts cannot run accumulate anyway */
+} tef_net_conv;
+typedef struct tef_net_plan {
+    int B, H, W;                 /* the (padded) input: sides multiples of 2^levels */
+    int bins, levels, nres, nout, final_act;
+    int width[TEF_NET_MAX_LEVELS];      /* channels of the encoder levels */
+    int dec_out[TEF_NET_MAX_LEVELS];    /* output channels of the decoders, coarse to fine */
+    int crop_top, crop_left;     /* rows / columns of padding to drop from the full-resolution flows */
+    float flow_scale;            /* extra factor on the flows (train_flow.py:107-108 flow_scaling) */
+    tef_net_conv head[TEF_NET_MAX_LEVELS], gate_ur[TEF_NET_MAX_LEVELS], gate_o[TEF_NET_MAX_LEVELS];
+    tef_net_conv res1[TEF_NET_MAX_RES], res2[TEF_NET_MAX_RES];
+    tef_net_conv dec[TEF_NET_MAX_LEVELS], pred[TEF_NET_MAX_LEVELS];
+} tef_net_plan;
+size_t tef_net_tape_floats(const tef_net_plan *p);
+size_t tef_net_gtape_floats(const tef_net_plan *p);
+size_t tef_net_workspace_bytes(const tef_net_plan *p);
+/* offsets in floats: flows [levels] (coarse to fine, [B,nout,H-crop_top,W-crop_left]) and new states [levels] inside a
+ * tape; gradients w.r.t. the incoming states [levels] and w.r.t. the input ([B,bins,H,W]) inside a gradient arena */
+int tef_net_layout(const tef_net_plan *p, size_t *flow_off, size_t *state_off, size_t *dstate_off, size_t *dx_off);
+/* x [B,bins,H,W]; states_in: HOST array of `levels` device pointers (zeros for a fresh sequence, submodules.py:141-143) */
+int tef_net_pass_forward(const tef_net_plan *p, const float *x, const float *const *states_in, float *tape,
+                         void *workspace, size_t workspace_bytes, void *stream);
+/* dflows / dstates: HOST arrays of `levels` device pointers, NULL entries = no gradient arrives there.  ran: bit mask of
+ * the layers whose pre-activation gradient was formed (for tef_net_window_wgrads); dstate_valid [levels] / dx_valid: which
+ * of the reported gradients were written (a dead chain leaves them unset). */
+int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *const *states_in, const float *tape,
+                          const float *const *dflows, const float *const *dstates, int want_dx, float *gtape,
+                          unsigned long long *ran, int *dstate_valid, int *dx_valid, void *workspace,
+                          size_t workspace_bytes, void *stream);
+/* the deferred weight gradients of a BPTT window: per layer one reduction over the pixels of all npass backward calls */
+int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
+                          const float *const *tape, const float *const *gtape, const unsigned long long *ran,
+                          void *stream);
+
 /* ---- validation metrics (loss/flow_val.py; evaluation only, batch 1, no gradients) ---------------------------------
  * Flow maps are planar [H][W] (fx, fy separately); event lists are loc [N][2] = (y, x), ts [N], mask [N][2]. */
 /* one warping step: flow lookup at loc (flow_out [N][2] = (f_y, f_x) if not NULL); if do_warp: loc += (tref - ts) * flow,

@@ -51,6 +51,28 @@ class GruDesc(ctypes.Structure):
 
 ACT = {None: 0, "relu": 1, "tanh": 2, "sigmoid": 3}
 
+TEF_NET_MAX_LEVELS = 6
+TEF_NET_MAX_RES = 4
+
+
+class NetConv(ctypes.Structure):
+    """struct tef_net_conv (include/tef.h)"""
+
+    _fields_ = [("wp", _fp), ("w2", _fp), ("bias", _fp), ("dw", _fp), ("dw2", _fp), ("db", _fp), ("db2", _fp),
+                ("defer", ctypes.c_int)]
+
+
+class NetPlan(ctypes.Structure):
+    """struct tef_net_plan (include/tef.h)"""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "H", "W", "bins", "levels", "nres", "nout", "final_act")] + [
+        ("width", ctypes.c_int * TEF_NET_MAX_LEVELS), ("dec_out", ctypes.c_int * TEF_NET_MAX_LEVELS),
+        ("crop_top", ctypes.c_int), ("crop_left", ctypes.c_int), ("flow_scale", ctypes.c_float),
+        ("head", NetConv * TEF_NET_MAX_LEVELS), ("gate_ur", NetConv * TEF_NET_MAX_LEVELS),
+        ("gate_o", NetConv * TEF_NET_MAX_LEVELS), ("res1", NetConv * TEF_NET_MAX_RES), ("res2", NetConv * TEF_NET_MAX_RES),
+        ("dec", NetConv * TEF_NET_MAX_LEVELS), ("pred", NetConv * TEF_NET_MAX_LEVELS),
+    ]
+
 # name -> (restype, argtypes); every symbol include/tef.h declares
 SIGNATURES = {
     "tef_version": (ctypes.c_int, []),
@@ -119,6 +141,19 @@ SIGNATURES = {
     "tef_grad_act": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
     "tef_add_act": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_size_t, _fp, _fp]),
+    "tef_net_tape_floats": (ctypes.c_size_t, [ctypes.POINTER(NetPlan)]),
+    "tef_net_gtape_floats": (ctypes.c_size_t, [ctypes.POINTER(NetPlan)]),
+    "tef_net_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(NetPlan)]),
+    "tef_net_layout": (ctypes.c_int, [ctypes.POINTER(NetPlan)] + [ctypes.POINTER(ctypes.c_size_t)] * 4),
+    "tef_net_pass_forward": (ctypes.c_int, [ctypes.POINTER(NetPlan), _fp, ctypes.POINTER(ctypes.c_void_p), _fp, _fp,
+                                            ctypes.c_size_t, _fp]),
+    "tef_net_pass_backward": (ctypes.c_int, [ctypes.POINTER(NetPlan), _fp, ctypes.POINTER(ctypes.c_void_p), _fp,
+                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
+                                             _fp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_int),
+                                             ctypes.POINTER(ctypes.c_int), _fp, ctypes.c_size_t, _fp]),
+    "tef_net_window_wgrads": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.POINTER(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ulonglong), _fp]),
     "tef_gru_blend": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_size_t, _fp, _fp]),
     "tef_gru_blend_backward": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_val_event_step": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,

@@ -1,20 +1,23 @@
-"""One recurrent pass of RecEVFlowNet as ONE autograd node with a hand-written backward.
+"""One recurrent pass of RecEVFlowNet as ONE autograd node and ONE call into libtef_hip.so per direction.
 
 The reference runs the pass as ~60 autograd nodes (models/arch.py:217-242, models/model.py:65-85) and lets autograd sum
-the gradients of every tensor that has several consumers (encoder states: next encoder + decoder skip + next pass;
-decoder outputs: prediction head + next decoder; head outputs: two gate convolutions; ...).  Here the pass is a static
-sequence of libtef_hip.so launches over the layer table of `arch.NetPlan`:
+the gradients of every tensor that has several consumers.  Round 2 turned the pass into one autograd node whose Python
+body issued ~100 ctypes calls and ~60 tensor allocations; an eager caller — a drop-in ``train_flow.py`` loop — was then
+bound by the host (49 ms of Python per window for 38 ms of GPU work).  Now the layer table of `arch.NetPlan` is walked in C
+(csrc/tef_net.hip, include/tef.h ``tef_net_*``):
 
-  forward   [pad] -> 4 x (strided head conv, fused ConvGRU cell) -> 2 residual blocks -> 4 x (bilinear x2 of
-            (features + encoder skip) [+ bilinear x2 of the previous prediction], conv over the two sources without
-            materialising their concatenation, 1x1 tanh head) -> 4 x (bilinear to the input size, x 2^(3-k), crop)
-  backward  the same table walked in reverse.  A gradient with several producers is never accumulated by a separate
-            pass: the kernel that CONSUMES it (tef_grad_act, tef_convgru_cell_bwd) takes up to four addends.  Bias
-            gradients come out of those same sweeps; weight gradients go straight into the parameters' .grad buffers
-            (or, inside a BPTT window, into one tef_conv_wgrad_parts reduction per layer over all passes).
+  forward   `tef_net_pass_forward`: [pad] -> 4 x (strided head conv, fused ConvGRU cell) -> residual blocks -> 4 x
+            (bilinear x2 of (features + encoder skip) [+ of the previous prediction], conv over the two sources without
+            materialising their concatenation, 1x1 tanh head, bilinear to the input size x 2^(3-k) x flow_scale, crop);
+            all activations the backward needs and the pass's outputs live in ONE arena (the "tape"), the flows and the new
+            states are views of it
+  backward  `tef_net_pass_backward`: the same table in reverse, a gradient with several producers summed where it is
+            consumed; parameter gradients go straight into the caller's accumulators (.grad of the flat bucket, or one
+            fresh zero buffer handed back to autograd) or, inside a BPTT window, stay as pre-activation gradients in the
+            call's gradient arena until `flush_window` reduces them over all passes with ONE `tef_net_window_wgrads`.
 
-No ATen arithmetic runs inside a pass (padding a non-multiple-of-16 input is one strided copy); torch provides the
-buffers and the stream.  All scratch lives in one workspace per engine, reused by every launch (stream order).
+This file only fills the plan (pointers of packed weights, biases, gradient targets), owns the arenas and is the autograd
+boundary.  No ATen arithmetic runs inside a pass (padding a non-multiple-of-16 input is one strided copy).
 """
 
 import ctypes
@@ -35,18 +38,10 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
-def _ptr_array(tensors):
-    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
-    return arr, len(tensors)
-
-
 class _Tape:
-    """Activations one pass keeps for its backward."""
+    """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
-    __slots__ = ("xp", "enc", "res", "dec", "geom", "dirty")
-
-    def __init__(self):
-        self.enc, self.res, self.dec = [], [], []
+    __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape")
 
 
 class PassEngine:
@@ -55,6 +50,8 @@ class PassEngine:
         self.plan = arch.plan
         self._ws = None
         self._zeros = {}
+        self._layout = {}
+        self._pending = []            # backward calls of the current window whose weight gradients are still deferred
 
     # ---- buffers -----------------------------------------------------------------------------------------------
     def workspace(self, nbytes, device):
@@ -69,128 +66,102 @@ class PassEngine:
             z = self._zeros[key] = torch.zeros(shape, dtype=torch.float32, device=device)
         return z
 
-    # ---- primitive launches ------------------------------------------------------------------------------------
-    def conv_fwd(self, packer, weights, biases, x0, x1, stride, act):
-        lib = _lib.lib()
-        B, C0, H, W = x0.shape
-        C1 = x1.shape[1] if x1 is not None else 0
-        w = weights[0]
-        N, k = sum(t.shape[0] for t in weights), w.shape[2]
-        d = _lib.ConvDesc(B, C0, C1, H, W, N, k, stride, ACT[act])
-        wp, _ = packer.get(weights, d)
+    # ---- the plan ----------------------------------------------------------------------------------------------
+    def _conv_fields(self, nc, packer, weights, biases, desc):
+        wp, wt = packer.get(weights, desc)
         bias = packer.bias(biases)
-        pad = k // 2
-        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        out = torch.empty((B, N, Ho, Wo), dtype=torch.float32, device=x0.device)
-        nbytes = lib.tef_conv_workspace_bytes(ctypes.byref(d))
-        ws = self.workspace(nbytes, x0.device)
-        rc = lib.tef_conv_forward(ctypes.byref(d), x0.data_ptr(), _p(x1), None, wp.data_ptr(), _p(bias), out.data_ptr(),
-                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, "tef_conv_forward")
-        return out
+        nc.wp, nc.w2, nc.bias = wp.data_ptr(), wt.data_ptr(), _p(bias)
 
-    def conv_bwd(self, packer, weights, g, x0, x1, stride, want_dx, sink):
-        """Input gradients of a convolution whose pre-activation gradient `g` is already formed; weight gradients go to
-        `sink` (immediately, or queued for the window's per-layer reduction)."""
-        lib = _lib.lib()
-        B, C0, H, W = x0.shape
-        C1 = x1.shape[1] if x1 is not None else 0
-        w = weights[0]
-        N, k = sum(t.shape[0] for t in weights), w.shape[2]
-        d = _lib.ConvDesc(B, C0, C1, H, W, N, k, stride, ACT[None])
-        _, wt = packer.get(weights, d)
-        dx0 = torch.empty_like(x0) if want_dx else None
-        dx1 = torch.empty_like(x1) if (want_dx and x1 is not None) else None
-        dws = sink.weight_targets(packer, weights, d, (g, x0, x1, None))
-        nbytes = lib.tef_conv_workspace_bytes(ctypes.byref(d))
-        ws = self.workspace(nbytes, x0.device)
-        rc = lib.tef_conv_backward_keep(ctypes.byref(d), x0.data_ptr(), _p(x1), None, wt.data_ptr(), None, None,
-                                        g.data_ptr(), None, N, _p(dx0), _p(dx1), _p(dws[0]), None, None, None, N, None,
-                                        ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, "tef_conv_backward_keep")
-        return dx0, dx1
+    def make_plan(self, B, Hp, Wp, ph, pw):
+        """struct tef_net_plan for a (padded) input of B x bins x Hp x Wp: geometry + the packed weights / biases of
+        every convolution (re-packed by PackedWeights only when a parameter changed)."""
+        a, np_ = self.arch, self.plan
+        pl = _lib.NetPlan()
+        pl.B, pl.H, pl.W = B, Hp, Wp
+        pl.bins, pl.levels, pl.nres, pl.nout = np_.num_bins, np_.levels, np_.nres, np_.nout
+        pl.final_act = ACT[np_.final_activation]
+        pl.crop_top, pl.crop_left, pl.flow_scale = ph, pw, float(a.flow_scale)
+        dec_rows = np_.of("dec")
+        for i, c in enumerate(np_.width):
+            pl.width[i] = c
+            pl.dec_out[i] = dec_rows[i].cout
+        cin, h, w = np_.num_bins, Hp, Wp
+        for i, enc in enumerate(a.encoders):
+            c = np_.width[i]
+            self._conv_fields(pl.head[i], enc.conv._packed, (enc.conv.conv2d.weight,), (enc.conv.conv2d.bias,),
+                              _lib.ConvDesc(B, cin, 0, h, w, c, 3, np_.stride, ACT["relu"]))
+            h, w = h // 2, w // 2
+            g = enc.recurrent_block
+            self._conv_fields(pl.gate_ur[i], g._packed_ur, (g.update_gate.weight, g.reset_gate.weight),
+                              (g.update_gate.bias, g.reset_gate.bias), _lib.ConvDesc(B, c, c, h, w, 2 * c, 3, 1, ACT["sigmoid"]))
+            self._conv_fields(pl.gate_o[i], g._packed_o, (g.out_gate.weight,), (g.out_gate.bias,),
+                              _lib.ConvDesc(B, c, c, h, w, c, 3, 1, ACT["tanh"]))
+            cin = c
+        top = np_.width[-1]
+        for j, rb in enumerate(a.resblocks):
+            d = _lib.ConvDesc(B, top, 0, h, w, top, 3, 1, ACT["relu"])
+            self._conv_fields(pl.res1[j], rb._packed1, (rb.conv1.weight,), (rb.conv1.bias,), d)
+            self._conv_fields(pl.res2[j], rb._packed2, (rb.conv2.weight,), (rb.conv2.bias,), d)
+        src = top
+        for k, (dec, head) in enumerate(zip(a.decoders, a.preds)):
+            h, w = h * 2, w * 2
+            c0, c1 = (np_.nout, src) if k else (src, 0)
+            out = dec_rows[k].cout
+            self._conv_fields(pl.dec[k], dec._packed, (dec.conv2d.weight,), (dec.conv2d.bias,),
+                              _lib.ConvDesc(B, c0, c1, h, w, out, 3, 1, ACT["relu"]))
+            self._conv_fields(pl.pred[k], head._packed, (head.conv2d.weight,), (head.conv2d.bias,),
+                              _lib.ConvDesc(B, out, 0, h, w, np_.nout, 1, 1, ACT[np_.final_activation]))
+            src = out
+        return pl
 
-    def grad_act(self, sources, out, act, dbias):
-        B, C = out.shape[0], out.shape[1]
-        HW = out.shape[2] * out.shape[3]
-        g = torch.empty_like(out)
-        arr, n = _ptr_array(sources)
-        rc = _lib.lib().tef_grad_act(arr, n, out.data_ptr(), ACT[act], B, C, HW, g.data_ptr(), _p(dbias), _lib.stream_ptr())
-        _lib.check(rc, "tef_grad_act")
-        return g
+    def layout(self, pl):
+        """(tape floats, gradient-arena floats, workspace bytes, flow / state / dstate offsets, dx offset) of a geometry."""
+        key = (pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left)
+        lay = self._layout.get(key)
+        if lay is None:
+            lib = _lib.lib()
+            n = self.plan.levels
+            fo, so, do = ((ctypes.c_size_t * n)() for _ in range(3))
+            dx = ctypes.c_size_t()
+            _lib.check(lib.tef_net_layout(ctypes.byref(pl), fo, so, do, ctypes.byref(dx)), "tef_net_layout")
+            tape, gtape = lib.tef_net_tape_floats(ctypes.byref(pl)), lib.tef_net_gtape_floats(ctypes.byref(pl))
+            if not tape or not gtape:
+                _lib.check(-1, "tef_net_tape_floats")
+            lay = self._layout[key] = (tape, gtape, lib.tef_net_workspace_bytes(ctypes.byref(pl)), list(fo), list(so),
+                                       list(do), dx.value)
+        return lay
 
-    def upsample(self, x, x2, scale, mul=1.0, crop=(0, 0)):
-        B, C, H, W = x.shape
-        y = torch.empty((B, C, H * scale - crop[0], W * scale - crop[1]), dtype=torch.float32, device=x.device)
-        rc = _lib.lib().tef_upsample_bilinear_crop(x.data_ptr(), _p(x2), B * C, H, W, scale, scale, float(mul), crop[0],
-                                                   crop[1], y.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "tef_upsample_bilinear_crop")
-        return y
+    def _grad_targets(self, pl, params_grad, defer):
+        """Fill the gradient accumulators of the plan: params_grad(parameter) -> tensor to add into (or None)."""
+        a = self.arch
 
-    def upsample_bwd(self, dy, shape, scale, mul=1.0, crop=(0, 0)):
-        B, C, H, W = shape
-        dx = torch.empty(shape, dtype=torch.float32, device=dy.device)
-        rc = _lib.lib().tef_upsample_bilinear_crop_backward(dy.data_ptr(), B * C, H, W, scale, scale, float(mul), crop[0],
-                                                            crop[1], dx.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "tef_upsample_bilinear_crop_backward")
-        return dx
+        def tgt(nc, weights, biases):
+            gw = [params_grad(w) for w in weights]
+            gb = [params_grad(b) if b is not None else None for b in biases]
+            nc.dw, nc.dw2 = _p(gw[0]), (_p(gw[1]) if len(gw) > 1 else None)
+            nc.db, nc.db2 = _p(gb[0]), (_p(gb[1]) if len(gb) > 1 else None)
+            nc.defer = 1 if (defer and all(g_ is not None for g_ in gw)) else 0
 
-    def add_act(self, a, b, act):
-        out = torch.empty_like(a)
-        rc = _lib.lib().tef_add_act(a.data_ptr(), b.data_ptr(), ACT[act], a.numel(), out.data_ptr(), _lib.stream_ptr())
-        _lib.check(rc, "tef_add_act")
-        return out
-
-    def cell_fwd(self, gru, x, h):
-        lib = _lib.lib()
-        B, C, H, W = x.shape
-        d = _lib.GruDesc(B, C, H, W)
-        d_ur = _lib.ConvDesc(B, C, C, H, W, 2 * C, 3, 1, ACT["sigmoid"])
-        d_o = _lib.ConvDesc(B, C, C, H, W, C, 3, 1, ACT["tanh"])
-        w_ur = (gru.update_gate.weight, gru.reset_gate.weight)
-        wp_ur, _ = gru._packed_ur.get(w_ur, d_ur)
-        wp_o, _ = gru._packed_o.get((gru.out_gate.weight,), d_o)
-        b_ur = gru._packed_ur.bias((gru.update_gate.bias, gru.reset_gate.bias))
-        b_o = gru._packed_o.bias((gru.out_gate.bias,))
-        u, r, o, hn = (torch.empty_like(x) for _ in range(4))
-        nbytes = lib.tef_convgru_workspace_bytes(ctypes.byref(d))
-        ws = self.workspace(nbytes, x.device)
-        rc = lib.tef_convgru_cell_fwd(ctypes.byref(d), x.data_ptr(), h.data_ptr(), wp_ur.data_ptr(), wp_o.data_ptr(),
-                                      _p(b_ur), _p(b_o), u.data_ptr(), r.data_ptr(), o.data_ptr(), hn.data_ptr(),
-                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, "tef_convgru_cell_fwd")
-        return u, r, o, hn
-
-    def cell_bwd(self, gru, x, h, u, r, o, sources, sink):
-        lib = _lib.lib()
-        B, C, H, W = x.shape
-        d = _lib.GruDesc(B, C, H, W)
-        d_ur = _lib.ConvDesc(B, C, C, H, W, 2 * C, 3, 1, ACT[None])
-        d_o = _lib.ConvDesc(B, C, C, H, W, C, 3, 1, ACT[None])
-        w_ur = (gru.update_gate.weight, gru.reset_gate.weight)
-        _, wt_ur = gru._packed_ur.get(w_ur, d_ur)
-        _, wt_o = gru._packed_o.get((gru.out_gate.weight,), d_o)
-        g_ur = torch.empty((B, 2 * C, H, W), dtype=torch.float32, device=x.device)
-        g_o, dx, dh = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        dw_ur = sink.weight_targets(gru._packed_ur, w_ur, d_ur, (g_ur, x, h, None))
-        dw_o = sink.weight_targets(gru._packed_o, (gru.out_gate.weight,), d_o, (g_o, x, h, r))
-        db = [sink.bias_target(b) for b in (gru.update_gate.bias, gru.reset_gate.bias, gru.out_gate.bias)]
-        arr, n = _ptr_array(sources)
-        nbytes = lib.tef_convgru_workspace_bytes(ctypes.byref(d))
-        ws = self.workspace(nbytes, x.device)
-        rc = lib.tef_convgru_cell_bwd(ctypes.byref(d), x.data_ptr(), h.data_ptr(), u.data_ptr(), r.data_ptr(), o.data_ptr(),
-                                      arr, n, wt_ur.data_ptr(), wt_o.data_ptr(), g_ur.data_ptr(), g_o.data_ptr(),
-                                      dx.data_ptr(), dh.data_ptr(), _p(dw_ur[0]), _p(dw_ur[1]), _p(dw_o[0]), _p(db[0]),
-                                      _p(db[1]), _p(db[2]), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-        _lib.check(rc, "tef_convgru_cell_bwd")
-        return dx, dh
+        for i, enc in enumerate(a.encoders):
+            g = enc.recurrent_block
+            tgt(pl.head[i], (enc.conv.conv2d.weight,), (enc.conv.conv2d.bias,))
+            tgt(pl.gate_ur[i], (g.update_gate.weight, g.reset_gate.weight), (g.update_gate.bias, g.reset_gate.bias))
+            tgt(pl.gate_o[i], (g.out_gate.weight,), (g.out_gate.bias,))
+        for j, rb in enumerate(a.resblocks):
+            tgt(pl.res1[j], (rb.conv1.weight,), (rb.conv1.bias,))
+            tgt(pl.res2[j], (rb.conv2.weight,), (rb.conv2.bias,))
+        for k, (dec, head) in enumerate(zip(a.decoders, a.preds)):
+            tgt(pl.dec[k], (dec.conv2d.weight,), (dec.conv2d.bias,))
+            tgt(pl.pred[k], (head.conv2d.weight,), (head.conv2d.bias,))
 
     # ---- the pass ----------------------------------------------------------------------------------------------
     def forward(self, x, states, keep):
         """x [B, bins, H, W] -> (flows: 4 x [B, 2, H, W], new states: 4 x [B, C_i, h_i, w_i], tape | None)."""
-        a, plan = self.arch, self.plan
+        plan = self.plan
         _lib.require_device_tensor(x, "network input")
         x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.to(torch.float32)
         B, _, H, W = x.shape
         ph, pw = plan.padding(H, W)
         if ph or pw:        # E-RAFT style padding at the top / left (reference models/model_util.py:52-65)
@@ -198,159 +169,104 @@ class PassEngine:
             xp[:, :, ph:, pw:] = x
         else:
             xp = x
-        tape = _Tape() if keep else None
-        cur, hn_all = xp, []
-        for i, enc in enumerate(a.encoders):
-            e = self.conv_fwd(enc.conv._packed, (enc.conv.conv2d.weight,), (enc.conv.conv2d.bias,), cur, None, plan.stride, "relu")
-            h = states[i]
-            if h is None:
-                h = self.zero_state(e.shape, e.device)
-            u, r, o, hn = self.cell_fwd(enc.recurrent_block, e, h.contiguous())
-            if keep:
-                tape.enc.append((cur, e, h, u, r, o, hn))
-            hn_all.append(hn)
-            cur = hn
-        for rb in a.resblocks:
-            mid = self.conv_fwd(rb._packed1, (rb.conv1.weight,), (rb.conv1.bias,), cur, None, 1, "relu")
-            lin = self.conv_fwd(rb._packed2, (rb.conv2.weight,), (rb.conv2.bias,), mid, None, 1, None)
-            y = self.add_act(lin, cur, "relu")
-            if keep:
-                tape.res.append((cur, mid, y))
-            cur = y
-        flows, pred = [], None
-        nlev = len(a.decoders)
-        for k, (dec, head) in enumerate(zip(a.decoders, a.preds)):
-            skip = hn_all[nlev - 1 - k]
-            upx = self.upsample(cur, skip, 2)
-            upp = self.upsample(pred, None, 2) if pred is not None else None
-            x0, x1 = (upp, upx) if upp is not None else (upx, None)
-            d = self.conv_fwd(dec._packed, (dec.conv2d.weight,), (dec.conv2d.bias,), x0, x1, 1, "relu")
-            p = self.conv_fwd(head._packed, (head.conv2d.weight,), (head.conv2d.bias,), d, None, 1, plan.final_activation)
-            s = 2 ** (nlev - 1 - k)
-            mul = float(s) * a.flow_scale          # resolution factor (model.py:76-81) x the caller's flow scaling
-            flows.append(self.upsample(p, None, s, mul=mul, crop=(ph, pw)))
-            if keep:
-                tape.dec.append((cur.shape, x0, x1, d, p, s, mul))
-            cur, pred = d, p
+        pl = self.make_plan(B, H + ph, W + pw, ph, pw)
+        ntape, _, wsb, fo, so, _, _ = self.layout(pl)
+        n = plan.levels
+        st, h, w = [], H + ph, W + pw
+        for i in range(n):
+            h, w = h // 2, w // 2
+            s = states[i]
+            if s is None:
+                s = self.zero_state((B, plan.width[i], h, w), x.device)
+            else:
+                _lib.require_device_tensor(s, "recurrent state")
+                if s.dtype != torch.float32 or not s.is_contiguous():
+                    s = s.to(torch.float32).contiguous()
+                if tuple(s.shape) != (B, plan.width[i], h, w):
+                    raise RuntimeError(f"recurrent state {i} has shape {tuple(s.shape)}, expected {(B, plan.width[i], h, w)}")
+            st.append(s)
+        arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
+        tape = torch.empty((ntape,), dtype=torch.float32, device=x.device)
+        ws = self.workspace(wsb, x.device)
+        rc = _lib.lib().tef_net_pass_forward(ctypes.byref(pl), xp.data_ptr(), arr, tape.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _lib.stream_ptr())
+        _lib.check(rc, "tef_net_pass_forward")
+        fshape = (B, plan.nout, H, W)
+        flows = [tape[fo[k]:fo[k] + B * plan.nout * H * W].view(fshape) for k in range(n)]
+        new_states = [tape[so[i]:so[i] + st[i].numel()].view(st[i].shape) for i in range(n)]
+        rec = None
         if keep:
-            tape.geom = (ph, pw)
-        return flows, hn_all, tape
+            rec = _Tape()
+            rec.plan, rec.xp, rec.states_in, rec.states_arr, rec.tape = pl, xp, st, arr, tape
+            rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
+        return flows, new_states, rec
 
-    def backward(self, tape, dflows, dstates, sink, want_dx=False):
-        """-> (gradients w.r.t. the incoming states (4), gradient w.r.t. the padded network input or None).  Parameter
-        gradients go through `sink`.  want_dx: also run the first encoder's input-gradient contraction (the reference's
-        autograd delivers d loss / d input when the caller asks for it, models/arch.py:217-227)."""
-        a = self.arch
-        ph, pw = tape.geom
-        nlev = len(a.decoders)
-        skip_grads = [None] * nlev          # d loss / d (features + encoder skip) of decoder k, shared by both addends
-        d_prev_pred = None                  # gradient arriving at prediction k from decoder k + 1
-        d_feat = None                       # gradient arriving at decoder k's output from decoder k + 1
-        for k in range(nlev - 1, -1, -1):
-            dec, head = a.decoders[k], a.preds[k]
-            src_shape, x0, x1, d, p, s, mul = tape.dec[k]
-            srcs = []
-            if dflows[k] is not None:
-                srcs.append(self.upsample_bwd(dflows[k].contiguous(), p.shape, s, mul=mul, crop=(ph, pw)))
-            if d_prev_pred is not None:
-                srcs.append(d_prev_pred)
-            feat_srcs = [d_feat] if d_feat is not None else []
-            if srcs:
-                gp = self.grad_act(srcs, p, self.plan.final_activation, sink.bias_target(head.conv2d.bias))
-                dd, _ = self.conv_bwd(head._packed, (head.conv2d.weight,), gp, d, None, 1, True, sink)
-                feat_srcs.insert(0, dd)
-            if not feat_srcs:           # nothing reaches this level (all its flow gradients absent): the chain is dead here
-                skip_grads[k] = None
-                d_prev_pred = d_feat = None
-                continue
-            gd = self.grad_act(feat_srcs, d, "relu", sink.bias_target(dec.conv2d.bias))
-            dx0, dx1 = self.conv_bwd(dec._packed, (dec.conv2d.weight,), gd, x0, x1, 1, True, sink)
-            dupp, dupx = (dx0, dx1) if x1 is not None else (None, dx0)
-            skip_grads[k] = self.upsample_bwd(dupx, src_shape, 2)
-            d_feat = skip_grads[k]
-            d_prev_pred = self.upsample_bwd(dupp, tape.dec[k - 1][4].shape, 2) if dupp is not None else None
-        # residual blocks, last first; `extra` = gradients reaching the block input besides its first convolution
-        srcs = [skip_grads[0]] if skip_grads[0] is not None else []
-        for rb, (xin, mid, y) in zip(reversed(list(a.resblocks)), reversed(tape.res)):
-            if not srcs:
-                break
-            gy = self.grad_act(srcs, y, "relu", sink.bias_target(rb.conv2.bias))
-            dmid, _ = self.conv_bwd(rb._packed2, (rb.conv2.weight,), gy, mid, None, 1, True, sink)
-            gmid = self.grad_act([dmid], mid, "relu", sink.bias_target(rb.conv1.bias))
-            dxin, _ = self.conv_bwd(rb._packed1, (rb.conv1.weight,), gmid, xin, None, 1, True, sink)
-            srcs = [dxin, gy]
-        # encoders, deepest first
-        dh_in = [None] * nlev
-        from_above = srcs                   # gradient of the deepest state through the residual blocks
-        for i in range(nlev - 1, -1, -1):
-            enc = a.encoders[i]
-            xin, e, h, u, r, o, hn = tape.enc[i]
-            sources = list(from_above)
-            sg = skip_grads[nlev - 1 - i]
-            # (the deepest state is decoder 0's skip addend AND the input of the residual blocks; without residual blocks
-            # `from_above` is that same gradient once more — features + skip = 2 x the state — and it is added twice)
-            if sg is not None:
-                sources.append(sg)
-            if dstates[i] is not None:
-                sources.append(dstates[i].contiguous())
-            if not sources:
-                from_above = []
-                continue
-            de, dh_in[i] = self.cell_bwd(enc.recurrent_block, e, h, u, r, o, sources, sink)
-            ge = self.grad_act([de], e, "relu", sink.bias_target(enc.conv.conv2d.bias))
-            dxin, _ = self.conv_bwd(enc.conv._packed, (enc.conv.conv2d.weight,), ge, xin, None, self.plan.stride,
-                                    i > 0 or want_dx, sink)
-            from_above = [dxin] if dxin is not None else []
-        # (what is left in `from_above` after level 0 is the gradient of the padded input)
-        return dh_in, (from_above[0] if want_dx and from_above else None)
+    def backward(self, rec, dflows, dstates, params, want_dx):
+        """-> (gradients w.r.t. the incoming states, gradient w.r.t. the network input or None, parameter gradients for
+        autograd).  Parameter gradients are added into the parameters' own .grad buffers when the training loop owns them
+        (`direct_grads`: nothing is handed to autograd), otherwise into one fresh zero buffer whose views are returned."""
+        a, plan = self.arch, self.plan
+        n = plan.levels
+        pl = rec.plan
+        direct = a.direct_grads and all(p.grad is not None and p.grad.is_contiguous() for p in params if p.requires_grad)
+        fresh = None
+        if direct:
+            self._grad_targets(pl, lambda p: p.grad if p.requires_grad else None, a.deferred_wgrad)
+        else:
+            tot = sum(p.numel() for p in params if p.requires_grad)
+            flat = torch.zeros((tot,), dtype=torch.float32, device=rec.tape.device)
+            fresh, o = {}, 0
+            for p in params:
+                if p.requires_grad:
+                    fresh[id(p)] = flat[o:o + p.numel()].view_as(p)
+                    o += p.numel()
+            self._grad_targets(pl, lambda p: fresh.get(id(p)), False)
+        _, ngt, wsb, _, _, do, dxo = self.layout(pl)
+        gtape = torch.empty((ngt,), dtype=torch.float32, device=rec.tape.device)
+        dfl = [None if g is None else g.to(torch.float32).contiguous() for g in dflows]
+        dst = [None if g is None else g.to(torch.float32).contiguous() for g in dstates]
+        a_dfl = (ctypes.c_void_p * n)(*[_p(g) for g in dfl])
+        a_dst = (ctypes.c_void_p * n)(*[_p(g) for g in dst])
+        ran = ctypes.c_ulonglong(0)
+        dsv = (ctypes.c_int * n)()
+        dxv = ctypes.c_int(0)
+        ws = self.workspace(wsb, rec.tape.device)
+        rc = _lib.lib().tef_net_pass_backward(ctypes.byref(pl), rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(), a_dfl,
+                                              a_dst, 1 if want_dx else 0, gtape.data_ptr(), ctypes.byref(ran), dsv,
+                                              ctypes.byref(dxv), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "tef_net_pass_backward")
+        dh = [gtape[do[i]:do[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) if dsv[i] else None for i in range(n)]
+        dx = None
+        if want_dx:
+            ph, pw = rec.geom
+            if dxv.value:
+                dx = gtape[dxo:dxo + rec.xp.numel()].view(rec.xp.shape)[:, :, ph:, pw:]
+            else:       # no gradient reached the first encoder: zeros, like autograd's own
+                dx = torch.zeros(rec.x_shape, dtype=torch.float32, device=rec.tape.device)
+        if direct and a.deferred_wgrad:
+            if self._pending and (self._pending[0][0].B, self._pending[0][0].H, self._pending[0][0].W) != (pl.B, pl.H, pl.W):
+                self.flush_window()
+            self._pending.append((pl, rec, gtape, ran.value))       # (keeps the arenas alive until the flush)
+            sm._DEFERRED_ENGINES.add(self)
+        grads = [None] * len(params) if direct else [fresh.get(id(p)) for p in params]
+        return dh, dx, grads
 
-
-class GradSink:
-    """Where one backward pass puts its parameter gradients.
-
-    `direct`: the parameters own pre-allocated .grad buffers (train.Trainer's flat bucket) and the kernels add into them;
-    otherwise fresh zero tensors are filled and handed back to autograd.  `deferred` (with direct): weight gradients are
-    queued per layer and reduced over all passes of the window by submodules.flush_deferred_wgrads()."""
-
-    def __init__(self, params, direct, deferred):
-        self.direct, self.deferred = direct, deferred and direct
-        self.fresh = {}
-        self.params = params
-
-    def _target(self, p):
-        if self.direct:
-            return p.grad
-        t = self.fresh.get(id(p))
-        if t is None:
-            t = self.fresh[id(p)] = torch.zeros_like(p)
-        return t
-
-    def bias_target(self, b):
-        if b is None or not b.requires_grad:
-            return None
-        return self._target(b)
-
-    def weight_targets(self, packer, weights, desc, part):
-        """-> [dw, dw2] device tensors to accumulate into now, or [None, None] when the layer's gradient is queued."""
-        if not all(w.requires_grad for w in weights):
-            return [None, None]
-        if self.deferred and _lib.lib().tef_conv_wgrad_parts_supported(ctypes.byref(desc)):
-            meta = (desc, [w.grad for w in weights], weights[0].shape[0] if len(weights) == 2 else desc.N)
-            if packer.pending and (packer.pending_meta[0].B, packer.pending_meta[0].H, packer.pending_meta[0].W) != (desc.B, desc.H, desc.W):
-                sm.flush_deferred_wgrads(packer)
-            packer.pending_meta = meta
-            packer.pending.append(part)
-            sm._DEFERRED.add(packer)
-            if len(packer.pending) == sm._MAX_PARTS:
-                sm.flush_deferred_wgrads(packer)
-            return [None, None]
-        t = [self._target(w) for w in weights]
-        return t + [None] * (2 - len(t))
-
-    def grads(self):
-        if self.direct:
-            return [None] * len(self.params)
-        return [self.fresh.get(id(p)) for p in self.params]
+    def flush_window(self):
+        """The deferred weight gradients of every backward call since the last flush: one reduction per layer over all
+        passes (tef_net_window_wgrads)."""
+        pend, self._pending = self._pending, []
+        sm._DEFERRED_ENGINES.discard(self)
+        if not pend:
+            return
+        npass = len(pend)
+        xs = (ctypes.c_void_p * npass)(*[r.xp.data_ptr() for _, r, _, _ in pend])
+        sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p))
+                                                          for _, r, _, _ in pend])
+        tapes = (ctypes.c_void_p * npass)(*[r.tape.data_ptr() for _, r, _, _ in pend])
+        gtapes = (ctypes.c_void_p * npass)(*[g.data_ptr() for _, _, g, _ in pend])
+        rans = (ctypes.c_ulonglong * npass)(*[m for _, _, _, m in pend])
+        rc = _lib.lib().tef_net_window_wgrads(ctypes.byref(pend[-1][0]), npass, xs, sts, tapes, gtapes, rans, _lib.stream_ptr())
+        _lib.check(rc, "tef_net_window_wgrads")
 
 
 class _PassFn(torch.autograd.Function):
@@ -359,29 +275,21 @@ class _PassFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, engine, nstates, x, *rest):
         states = list(rest[:nstates])
-        flows, new_states, tape = engine.forward(x, states, keep=True)
-        ctx.engine, ctx.tape, ctx.nstates = engine, tape, nstates
+        flows, new_states, rec = engine.forward(x, states, keep=True)
+        ctx.engine, ctx.rec, ctx.nstates = engine, rec, nstates
         ctx.params = rest[nstates:]
         ctx.state_given = [s is not None for s in states]
-        ctx.x_shape = tuple(x.shape) if x.requires_grad else None
+        ctx.want_dx = bool(x.requires_grad)
         return tuple(flows) + tuple(new_states)
 
     @staticmethod
     def backward(ctx, *grads):
         engine, n = ctx.engine, ctx.nstates
         nflow = len(grads) - n
-        params = ctx.params
-        direct = all(p.grad is not None and p.grad.is_contiguous() for p in params if p.requires_grad) and engine.arch.direct_grads
-        sink = GradSink(params, direct, engine.arch.deferred_wgrad)
-        ph, pw = ctx.tape.geom
-        dh, dxp = engine.backward(ctx.tape, list(grads[:nflow]), list(grads[nflow:]), sink, want_dx=ctx.x_shape is not None)
-        ctx.tape = None
+        dh, dx, pg = engine.backward(ctx.rec, list(grads[:nflow]), list(grads[nflow:]), ctx.params, ctx.want_dx)
+        ctx.rec = None               # (a deferred window keeps its own reference until the flush)
         dh = [g if given else None for g, given in zip(dh, ctx.state_given)]
-        dx = None
-        if ctx.x_shape is not None:
-            # no gradient reached the first encoder (every flow / state gradient absent): zeros, like autograd's own
-            dx = dxp[:, :, ph:, pw:] if dxp is not None else torch.zeros(ctx.x_shape, dtype=torch.float32, device=params[0].device)
-        return (None, None, dx) + tuple(dh) + tuple(sink.grads())
+        return (None, None, dx) + tuple(dh) + tuple(pg)
 
 
 def run_pass(engine, x, states):

@@ -212,11 +212,15 @@ class _ConvFn(torch.autograd.Function):
 
 _MAX_PARTS = 16        # TEF_CONV_MAX_PARTS (include/tef.h)
 _DEFERRED = set()      # packers with queued weight-gradient parts
+_DEFERRED_ENGINES = set()      # pass engines (models/engine.py) holding the backward calls of an unfinished window
 
 
 def flush_deferred_wgrads(packer=None):
     """Run the queued weight gradients (all layers, or one): one tef_conv_wgrad_parts launch per layer over every backward
     call since the last flush.  Call after loss.backward() and before the gradients are read (all-reduce, clip, step)."""
+    if packer is None:
+        for eng in list(_DEFERRED_ENGINES):      # the fused passes of the window: one tef_net_window_wgrads per engine
+            eng.flush_window()
     todo = [packer] if packer is not None else list(_DEFERRED)
     lib = _lib.lib()
     for pk in todo:
