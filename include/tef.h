@@ -113,6 +113,15 @@ int tef_pack_flow(const float *flow, long stride_b, long stride_c, int B, int H,
 int tef_pack_flows(const float *const *flows, const long *stride_b, const long *stride_c, int F, int B, int H, int W,
                    float *planar, float *yx, void *stream);
 
+/* One pass of Iterative.update / Linear.update (loss/flow.py:443-476 / :233-288) as ONE call: the F flow maps of the
+ * pass (tef_pack_flows) and its two event lists (tef_pack_events, in-place time shift by pass_idx included) — three
+ * launches from one host call instead of three calls with their argument marshalling.  grad / det: the SoA stores of the
+ * window (written at slots slot0 / dslot0 on); planar / yx: this pass's slices of the window's flow buffers. */
+int tef_update_pass(const float *const *flows, const long *stride_b, const long *stride_c, int F, int B, int H, int W,
+                    float *planar, float *yx, float *ev, const float *pm, int N, const float *ts_override, float *dev,
+                    const float *dpm, int Nd, const float *dts_override, int pass_idx, int slot0, int dslot0,
+                    const tef_events *grad, const tef_events *det, void *stream);
+
 /* Workspace (bytes) needed by tef_loss_forward + tef_loss_backward for this window. */
 size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg);
 

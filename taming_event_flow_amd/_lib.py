@@ -92,6 +92,10 @@ SIGNATURES = {
     "tef_pack_flows": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long),
                                       ctypes.POINTER(ctypes.c_long), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       _fp, _fp, _fp]),
+    "tef_update_pass": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_long),
+                                       ctypes.POINTER(ctypes.c_long), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_int, ctypes.POINTER(Events), ctypes.POINTER(Events), _fp]),
     "tef_encode_events": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
     "tef_encode_event_lists": (ctypes.c_int, [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -2349,6 +2349,28 @@ int tef_pack_flows(const float *const *flows, const long *stride_b, const long *
     return tef::check_launch("pack_flows_kernel");
 }
 
+int tef_update_pass(const float *const *flows, const long *stride_b, const long *stride_c, int F, int B, int H, int W,
+                    float *planar, float *yx, float *ev, const float *pm, int N, const float *ts_override, float *dev,
+                    const float *dpm, int Nd, const float *dts_override, int pass_idx, int slot0, int dslot0,
+                    const tef_events *grad, const tef_events *det, void *stream)
+{
+    if (!grad || !det) return tef::fail("tef_update_pass: null event store"), TEF_ERR_INVALID;
+    if (int rc = tef_pack_flows(flows, stride_b, stride_c, F, B, H, W, planar, yx, stream)) return rc;
+    if (N > 0) {
+        if (int rc = tef_pack_events(ev, pm, B, N, (float)pass_idx, ts_override, pass_idx, slot0, grad->cap, H, W, (float *)grad->ts,
+                                     (float *)grad->y, (float *)grad->x, (float *)grad->mp, (float *)grad->mn, (uint8_t *)grad->bin,
+                                     (int *)grad->cls, stream))
+            return rc;
+    }
+    if (Nd > 0) {
+        if (int rc = tef_pack_events(dev, dpm, B, Nd, (float)pass_idx, dts_override, pass_idx, dslot0, det->cap, H, W, (float *)det->ts,
+                                     (float *)det->y, (float *)det->x, (float *)det->mp, (float *)det->mn, (uint8_t *)det->bin,
+                                     (int *)det->cls, stream))
+            return rc;
+    }
+    return 0;
+}
+
 int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,
                      void *workspace, size_t workspace_bytes, float *loss_out, void *stream)
 {

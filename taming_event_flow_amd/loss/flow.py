@@ -12,6 +12,7 @@ buffers, bookkeeping and the autograd boundary.  There is no PyTorch/CPU fallbac
 """
 
 import ctypes
+import sys
 
 import torch
 
@@ -26,17 +27,18 @@ __all__ = ["BaseEventWarping", "Linear", "Iterative"]
 class _SoA:
     """Growable structure-of-arrays event store for one list (grad or detached) of one window."""
 
-    def __init__(self, B, device, res):
+    def __init__(self, B, device, res, cap_hint=0):
         self.B, self.device, self.res = B, device, res
         self.cap = 0
         self.n = 0
+        self.cap_hint = cap_hint      # slots the previous window of this module needed: allocated in one go
         self.off = [0]
         self.ts = self.y = self.x = self.mp = self.mn = self.bin = None
         # per (sample, pass): ends of the pos-only / neg-only / both-polarity runs (written by tef_pack_events)
         self.cls = torch.zeros((B, _lib.TEF_MAX_PASSES, 3), dtype=torch.int32, device=device)
 
     def _grow(self, need):
-        cap = max(need, 2 * self.cap, 1024)
+        cap = max(need, 2 * self.cap, 1024, self.cap_hint)
         new = [torch.empty((self.B, cap), dtype=torch.float32, device=self.device) for _ in range(5)]
         nbin = torch.empty((cap,), dtype=torch.uint8, device=self.device)
         if self.n:
@@ -74,6 +76,17 @@ class _SoA:
         self.n += Np
         self.off.append(self.n)
 
+    def reserve(self, N):
+        """Room for a pass of N events (padded to a multiple of 64 slots); -> its first slot."""
+        Np = (N + 63) & ~63
+        if self.n + Np > self.cap:
+            self._grow(self.n + Np)
+        return self.n
+
+    def commit(self, N):
+        self.n += (N + 63) & ~63
+        self.off.append(self.n)
+
     def struct(self):
         if self.cap == 0:
             self._grow(1)
@@ -84,12 +97,12 @@ class _SoA:
 class _Window:
     """Device state of one loss window (everything the kernels read)."""
 
-    def __init__(self, B, device, res):
+    def __init__(self, B, device, res, hints=(0, 0)):
         self.flows = None          # planar      [P][F][B][2][H][W]  (smoothing terms, gradient layout)
         self.flows_yx = None       # interleaved [P][F][B][H][W][2]  (flow_y, flow_x) for the lookups
         self.flow_refs = []        # autograd handles, flow_refs[t][i]
-        self.grad = _SoA(B, device, res)
-        self.det = _SoA(B, device, res)
+        self.grad = _SoA(B, device, res, hints[0])
+        self.det = _SoA(B, device, res, hints[1])
         self.workspace = None
         self.scratch = None
         self.cfg = None
@@ -181,7 +194,7 @@ class BaseEventWarping(torch.nn.Module):
         B, F = self.batch_size, self._num_flows
         win = self._win
         if win is None:
-            win = self._win = _Window(B, self.device, self.res)
+            win = self._win = _Window(B, self.device, self.res, getattr(self, "_hints", (0, 0)))
         if win.flows is None:
             _lib.require_device_tensor(flow_list[0], "flow map")
             win.flows = torch.empty((P, F, B, 2, H, W), dtype=torch.float32, device=flow_list[0].device)
@@ -211,6 +224,8 @@ class BaseEventWarping(torch.nn.Module):
         win.flow_refs.append(refs)
 
     def reset_base(self):
+        if self._win is not None:      # the next window starts with stores of the size this one ended with
+            self._hints = (max(self._win.grad.n, getattr(self, "_hints", (0, 0))[0]), max(self._win.det.n, getattr(self, "_hints", (0, 0))[1]))
         self._passes = 0
         self._win = None
 
@@ -234,6 +249,61 @@ class BaseEventWarping(torch.nn.Module):
             win.keep = getattr(win, "keep", []) + [ovr, d_ovr]       # alive until the pack kernels have run
         win.grad.append(event_list, pol_mask, self._passes, ovr)
         win.det.append(d_event_list, d_pol_mask, self._passes, d_ovr)
+        self._passes += 1
+
+    def _update_pass(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
+        """One pass of update(): flow maps + both event lists handed to the library in ONE call (tef_update_pass) when the
+        caller's tensors are in the layout the reference's loader produces (contiguous fp32); anything else takes the
+        call-by-call path, which converts."""
+        F = len(flow_list)
+        H, W = self.res
+
+        def plain(t, last):
+            return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.shape[2] == last and t.is_contiguous()
+                    and t.data_ptr() % 16 == 0)
+
+        fast = (F <= 16 and plain(event_list, 4) and plain(pol_mask, 2) and plain(d_event_list, 4) and plain(d_pol_mask, 2)
+                and event_list.shape[0] == self.batch_size and d_event_list.shape[0] == self.batch_size
+                and pol_mask.shape[:2] == event_list.shape[:2] and d_pol_mask.shape[:2] == d_event_list.shape[:2]
+                and all(f.is_cuda and f.dtype == torch.float32 and tuple(f.shape) == (self.batch_size, 2, H, W)
+                        and f.stride(3) == 1 and f.stride(2) == W for f in flow_list))
+        if not fast or (self._num_flows is not None and F != self._num_flows) or self._passes >= max(self.passes_loss):
+            self.update_base(flow_list)          # (also where malformed calls get their error messages)
+            self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
+            return
+        if self._num_flows is None:
+            self._num_flows = F
+        P, B = max(self.passes_loss), self.batch_size
+        win = self._win
+        if win is None:
+            win = self._win = _Window(B, self.device, self.res, getattr(self, "_hints", (0, 0)))
+        if win.flows is None:
+            win.flows = torch.empty((P, F, B, 2, H, W), dtype=torch.float32, device=flow_list[0].device)
+            win.flows_yx = torch.empty((P, F, B, H, W, 2), dtype=torch.float32, device=flow_list[0].device)
+        t = self._passes
+        N, Nd = event_list.shape[1], d_event_list.shape[1]
+        ovr = d_ovr = None
+        if self.config["loss"]["round_ts"]:
+            if N > 0:
+                ovr = ((event_list[:, :, 0].min() + float(t)) + 0.5).reshape(1).contiguous()
+            if Nd > 0:
+                d_ovr = ((d_event_list[:, :, 0].min() + float(t)) + 0.5).reshape(1).contiguous()
+            win.keep = getattr(win, "keep", []) + [ovr, d_ovr]       # alive until the pack kernels have run
+        slot0, dslot0 = win.grad.reserve(N), win.det.reserve(Nd)
+        srcs = [f.detach() for f in flow_list]
+        ptrs = (ctypes.c_void_p * F)(*[s_.data_ptr() for s_ in srcs])
+        sb = (ctypes.c_long * F)(*[s_.stride(0) for s_ in srcs])
+        sc = (ctypes.c_long * F)(*[s_.stride(1) for s_ in srcs])
+        g, d = win.grad.struct(), win.det.struct()
+        rc = _lib.lib().tef_update_pass(ptrs, sb, sc, F, B, H, W, win.flows[t].data_ptr(), win.flows_yx[t].data_ptr(),
+                                        event_list.data_ptr(), pol_mask.data_ptr(), N, None if ovr is None else ovr.data_ptr(),
+                                        d_event_list.data_ptr(), d_pol_mask.data_ptr(), Nd,
+                                        None if d_ovr is None else d_ovr.data_ptr(), t, slot0, dslot0, ctypes.byref(g),
+                                        ctypes.byref(d), _lib.stream_ptr())
+        _lib.check(rc, "tef_update_pass")
+        win.grad.commit(N)
+        win.det.commit(Nd)
+        win.flow_refs.append(list(flow_list))
         self._passes += 1
 
     def _smooth_weights(self, P):
@@ -269,11 +339,15 @@ class BaseEventWarping(torch.nn.Module):
         nbytes = lib.tef_loss_workspace_bytes(ctypes.byref(cfg))
         if nbytes == 0:
             _lib.check(-1, "tef_loss_workspace_bytes")
-        win.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=win.flows.device)
+        # the window keeps its workspace (0.7 GB at the BASELINE size) across evaluations; an autograd graph of an earlier
+        # evaluation that is still alive holds a reference to the one it ran on, and then a fresh one is taken
+        if win.workspace is None or win.workspace.numel() != nbytes or sys.getrefcount(win.workspace) > 2:
+            win.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=win.flows.device)
         ws, wt = self._smooth_weights(P)
         if ws >= 0 or wt >= 0:
-            win.scratch = torch.empty((lib.tef_smoothing_scratch_bytes(ctypes.byref(cfg)),), dtype=torch.uint8,
-                                      device=win.flows.device)
+            nscr = lib.tef_smoothing_scratch_bytes(ctypes.byref(cfg))
+            if win.scratch is None or win.scratch.numel() != nscr or sys.getrefcount(win.scratch) > 2:
+                win.scratch = torch.empty((nscr,), dtype=torch.uint8, device=win.flows.device)
         flat = [f for refs in win.flow_refs for f in refs]
         return _CMLossFn.apply(self, win, *flat)
 
@@ -289,8 +363,7 @@ class Linear(BaseEventWarping):
     def update(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
         """reference loss/flow.py:233-288.  The per-event flow lookup of :268-283 happens inside the HIP forward
         (the map of the event's own pass is the "latest" map at update time)."""
-        self.update_base(flow_list)
-        self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
+        self._update_pass(flow_list, event_list, pol_mask, d_event_list, d_pol_mask)
 
     def reset(self):
         self.reset_base()
@@ -316,8 +389,7 @@ class Iterative(BaseEventWarping):
 
     def update(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
         """reference loss/flow.py:443-476"""
-        self.update_base(flow_list)
-        self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
+        self._update_pass(flow_list, event_list, pol_mask, d_event_list, d_pol_mask)
 
     def reset(self):
         self.reset_base()

@@ -61,7 +61,9 @@ def _bilinear_upsample(grid, H, W):
     b = g[..., y0[:, None], x0[None, :] + 1]
     c = g[..., y0[:, None] + 1, x0[None, :]]
     d = g[..., y0[:, None] + 1, x0[None, :] + 1]
-    return (a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx).astype(np.float32)
+    # (C-contiguous like a network output: fancy indexing leaves a permuted memory layout behind, and a flow map in that
+    # layout makes update() take its converting, call-by-call path)
+    return np.ascontiguousarray((a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx).astype(np.float32))
 
 
 def make_flow(rng, B, H, W, sigma=2.0, kind="smooth", grid=8):

@@ -57,7 +57,7 @@ if "--graph" in sys.argv:
 for _ in range(20):
     step()
 torch.cuda.synchronize()
-n = 300
+n = int(os.environ.get("N_STEPS", "300"))
 t0 = time.perf_counter()
 for _ in range(n):
     step()
