@@ -365,6 +365,17 @@ int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran,
                           void *stream);
 
+/* ---- optimiser step of the training window on flat buffers (train_flow.py:127-131) ----------------------------------
+ * tef_l2_norm: out[0] = ||x||_2 (double partial sums in `scratch`, tef_l2_norm_scratch_bytes, fixed summation order);
+ * step (optional) is incremented by one: the counter of the Adam update that follows.
+ * tef_adam_clip_step: clip_grad_norm_ (g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clipping), torch.optim.Adam
+ * with amsgrad=False / weight_decay=0 (exp_avg m, exp_avg_sq v, bias corrections from the device counter `step`, which
+ * makes the call graph-capturable) and zero_grad (g <- 0), one launch over n elements. */
+size_t tef_l2_norm_scratch_bytes(void);
+int tef_l2_norm(const float *x, size_t n, void *scratch, float *out, float *step, void *stream);
+int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const float *norm, float max_norm, float lr,
+                       float beta1, float beta2, float eps, const float *step, void *stream);
+
 /* ---- validation metrics (loss/flow_val.py; evaluation only, batch 1, no gradients) ---------------------------------
  * Flow maps are planar [H][W] (fx, fy separately); event lists are loc [N][2] = (y, x), ts [N], mask [N][2]. */
 /* one warping step: flow lookup at loc (flow_out [N][2] = (f_y, f_x) if not NULL); if do_warp: loc += (tref - ts) * flow,

@@ -239,6 +239,15 @@ def flush_deferred_wgrads(packer=None):
         _DEFERRED.discard(pk)
 
 
+def invalidate_packed(module):
+    """Forget the packed GEMM operands of every convolution of `module`: for optimisers that update the parameters with
+    their own kernels (parallel.FusedAdam), which does not bump the version counters the packed copies are keyed on."""
+    for m in module.modules():
+        for v in vars(m).values():
+            if isinstance(v, PackedWeights):
+                v.invalidate()
+
+
 def enable_deferred_wgrad(module, on=True):
     """With enable_direct_grads: queue the weight gradients of the convolutions of `module` during backward and compute
     them per layer in flush_deferred_wgrads() (the caller must call it after every backward)."""

@@ -49,6 +49,51 @@ class FlatGradBucket:
         return norm
 
 
+class FusedAdam:
+    """torch.optim.Adam (defaults: betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad) + clip_grad_norm_ +
+    zero_grad on FLAT buffers, three launches of libtef_hip.so (tef_l2_norm, tef_adam_clip_step) instead of ~12 ATen
+    launches over 60 tensors.  The parameters are re-pointed at views of one flat buffer (like the gradients of
+    FlatGradBucket); the step counter lives on the device, so the step can be captured into a hipGraph.  The packed GEMM
+    operands of the convolutions are keyed on the parameters' version counters, which a kernel behind autograd's back
+    does not bump: the caller invalidates them after every step (models.submodules.invalidate_packed)."""
+
+    def __init__(self, bucket, lr, betas=(0.9, 0.999), eps=1e-8):
+        import ctypes
+
+        try:
+            from . import _lib
+        except ImportError:
+            import _lib
+        self._lib, self._ct = _lib, ctypes
+        self.bucket, self.lr, self.betas, self.eps = bucket, float(lr), betas, float(eps)
+        flat_g = bucket.flat
+        self.flat_p = torch.empty_like(flat_g)
+        o = 0
+        for p in bucket.params:                      # parameters become views of the flat buffer (values kept)
+            view = self.flat_p[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            o += p.numel()
+        self.m = torch.zeros_like(flat_g)
+        self.v = torch.zeros_like(flat_g)
+        self.step_count = torch.zeros((1,), dtype=torch.float32, device=flat_g.device)
+        self.norm = torch.zeros((1,), dtype=torch.float32, device=flat_g.device)
+        self.scratch = torch.empty((_lib.lib().tef_l2_norm_scratch_bytes(),), dtype=torch.uint8, device=flat_g.device)
+
+    def step(self, max_norm):
+        """Clip the (already reduced) flat gradient to `max_norm` (None: no clipping), apply Adam, clear the gradient.
+        -> the gradient's global norm before clipping (a 1-element device tensor, overwritten by the next step)."""
+        lib, n = self._lib.lib(), self.bucket.flat.numel()
+        st = self._lib.stream_ptr()
+        self._lib.check(lib.tef_l2_norm(self.bucket.flat.data_ptr(), n, self.scratch.data_ptr(), self.norm.data_ptr(),
+                                        self.step_count.data_ptr(), st), "tef_l2_norm")
+        self._lib.check(lib.tef_adam_clip_step(self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.m.data_ptr(),
+                                               self.v.data_ptr(), n, self.norm.data_ptr(),
+                                               -1.0 if max_norm is None else float(max_norm), self.lr, self.betas[0],
+                                               self.betas[1], self.eps, self.step_count.data_ptr(), st), "tef_adam_clip_step")
+        return self.norm.view(())
+
+
 _FLAG_GROUP = None
 
 

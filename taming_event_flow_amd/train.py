@@ -119,7 +119,16 @@ class Trainer:
         opt_kwargs = {"lr": config["optimizer"]["lr"]}
         if config["optimizer"].get("capturable"):
             opt_kwargs["capturable"] = True      # optimiser state stays on the device: the window can live in a hipGraph
-        self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
+        # Adam with its defaults (the reference's configs/train_flow.yml) on a HIP device: clip + step + zero_grad as three
+        # launches over the flat buffers (parallel.FusedAdam); anything else goes to torch.optim
+        self.fused_opt = None
+        extra = set(config["optimizer"]) - {"name", "lr", "capturable"}
+        if (config["optimizer"]["name"] == "Adam" and not extra and torch.device(device).type == "cuda"
+                and os.environ.get("TEF_TORCH_ADAM", "0") != "1"):
+            self.fused_opt = parallel.FusedAdam(self.bucket, config["optimizer"]["lr"])
+            self.optimizer = None
+        else:
+            self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
         self.last_grad_norm = None
 
@@ -232,9 +241,13 @@ class Trainer:
     def _apply_update(self):
         """train_flow.py:127-137 on the (already reduced) flat gradient: clip, step, clear, cut the graph."""
         cfg = self.cfg
-        if cfg["loss"]["clip_grad"] is not None:
-            self.last_grad_norm = self.bucket.clip_(cfg["loss"]["clip_grad"])
-        self.optimizer.step()
-        self.bucket.zero()                              # optimizer.zero_grad() keeping the flat views
+        if self.fused_opt is not None:
+            self.last_grad_norm = self.fused_opt.step(cfg["loss"]["clip_grad"])      # clip + Adam + zero_grad
+            submodules.invalidate_packed(self.model)
+        else:
+            if cfg["loss"]["clip_grad"] is not None:
+                self.last_grad_norm = self.bucket.clip_(cfg["loss"]["clip_grad"])
+            self.optimizer.step()
+            self.bucket.zero()                          # optimizer.zero_grad() keeping the flat views
         self.model.detach_states()
         self.loss_function.reset()
