@@ -279,7 +279,7 @@ def main():
     # the eager launch path is timed FIRST, in the state a drop-in caller of the loss module sees (after the graph captures
     # below the same probe reads 1.1 ms on a 0.65 ms path: capture leaves the process with stream / allocator state that
     # slows the eager steps that follow — an artefact of measuring both paths in one process, not a property of either)
-    eager_probe = round(probe_ms(step), 4)
+    eager_probe = round(min(probe_ms(step), probe_ms(step)), 4)      # (best of two: the first seconds of a fresh box are slow)
     graphs, probe = [], None
     if a.step_graph != "off":
         try:
