@@ -406,12 +406,29 @@ int tef_val_average_flow(const float *maps_x, const float *maps_y, int P, int H,
 int tef_pol_iwe(const float *flow, const float *event_list, const float *pol_mask, int B, int N, int H, int W,
                 int round_idx, int round_flow, float *out, void *stream);
 /* Stand-alone forms of the interpolation primitives for callers that use them one by one (utils/iwe.py:63-113
- * get_interpolation, :116-136 interpolate; forward only — the differentiable path is the fused loss).
+ * get_interpolation, :116-136 interpolate; forward forms — their gradients are the *_backward entry points below).
  * loc [B][n][2] = (y, x).  Bilinear: idx / weights [B][4n] (corner blocks TL, TR, BL, BR along the event axis, linear pixel
  * index as a float like the reference, 0 with weight 0 outside the frame); round_idx: [B][n], nearest pixel, weight 1 / 0.
  * tef_scatter_add: out [B][HW] = 0, then out[b][idx] += weights (* mask, [B][n'] or NULL). */
 int tef_interp_corners(const float *loc, int B, int n, int H, int W, int round_idx, float *idx, float *weights, void *stream);
 int tef_scatter_add(const float *idx, const float *weights, const float *mask, int B, int n, int HW, float *out, void *stream);
+/* The same primitives as DIFFERENTIABLE operators (csrc/tef_prims.hip) for callers that build a loss of their own from
+ * utils/iwe.py's functions (the training loss itself runs the fused kernels behind tef_loss_forward / _backward):
+ *   tef_event_flow            get_event_flow (utils/iwe.py:17-40) for a whole batch: maps fx, fy [B][H][W], loc [B][N][2] =
+ *                             (y, x) -> out [B][N][2] = (f_y, f_x); bilinear, align_corners, taps outside the frame read 0
+ *   tef_event_flow_backward   gout [B][N][2] -> dfx, dfy [B][H][W] (ACCUMULATED with float atomics: zero them first; both
+ *                             or neither) and dloc [B][N][2] (the lookup's position Jacobian; NULL to skip)
+ *   tef_interp_corners_backward  get_interpolation (:63-113), bilinear branch: gweights [B][4n] -> dloc [B][n][2]; autograd
+ *                             through max(0, 1 - |d|) as torch runs it (slope halved exactly at |d| = 1, abs'(0) = 0, corners
+ *                             outside the frame contribute nothing); indices carry no gradient
+ *   tef_scatter_add_backward  interpolate (:116-136): gimg [B][HW] -> dweights = gimg[idx] * mask, dmask = gimg[idx] *
+ *                             weights (either NULL to skip; mask NULL = no mask) */
+int tef_event_flow(const float *fx, const float *fy, int B, int H, int W, const float *loc, int N, float *out, void *stream);
+int tef_event_flow_backward(const float *fx, const float *fy, int B, int H, int W, const float *loc, int N, const float *gout,
+                            float *dfx, float *dfy, float *dloc, void *stream);
+int tef_interp_corners_backward(const float *loc, int B, int n, int H, int W, const float *gweights, float *dloc, void *stream);
+int tef_scatter_add_backward(const float *idx, const float *weights, const float *mask, int B, int n, int HW, const float *gimg,
+                             float *dweights, float *dmask, void *stream);
 /* average endpoint error over pixels with valid ground truth (and events).  flow_val.py:276-314 */
 int tef_val_aee(const float *pred, const float *gt, const float *event_mask, int mask_passes, int H, int W, float *out,
                 void *stream);

@@ -181,6 +181,11 @@ SIGNATURES = {
     "tef_interp_corners": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp,
                                           _fp]),
     "tef_scatter_add": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
+    "tef_event_flow": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp]),
+    "tef_event_flow_backward": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, ctypes.c_int, _fp, _fp, _fp,
+                                               _fp, _fp]),
+    "tef_interp_corners_backward": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "tef_scatter_add_backward": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, _fp]),
     "tef_val_aee": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
     "tef_loss_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(LossCfg)]),
     "tef_loss_forward": (ctypes.c_int, [ctypes.POINTER(LossCfg), _fp, ctypes.POINTER(Events), ctypes.POINTER(Events),

@@ -1,11 +1,12 @@
 """Drop-in for the reference's ``utils/iwe.py``.
 
-``compute_pol_iwe`` / ``deblur_events`` (:139-257; eval_flow.py:104-111, visualisation) are one fused launch.  The
-training-time primitives (:5-136) live fused inside the loss kernels (tef_loss.hip); for callers that import them one
-by one they are also available here as stand-alone, FORWARD-ONLY functions on the HIP kernels of tef_val.hip — the
-differentiable path is the loss module (``loss.flow``), these carry no autograd graph.  In the reference they are
-ordinary differentiable torch functions: a call that WOULD need a gradient here (grad mode on and an input that
-requires grad) raises instead of silently returning a constant."""
+``compute_pol_iwe`` / ``deblur_events`` (:139-257; eval_flow.py:104-111, visualisation) are one fused, forward-only launch.
+The training-time primitives (:5-136) live fused inside the loss kernels (tef_loss.hip) — that is the fast path, and
+what ``loss.flow.Linear`` / ``Iterative`` run.  For callers that import the primitives one by one and build a loss of
+their own they are also available here as stand-alone, DIFFERENTIABLE functions like the reference's: autograd nodes on
+the HIP kernels of csrc/tef_val.hip (forward) and csrc/tef_prims.hip (backward), with the reference's gradient
+conventions (grid_sample's position Jacobian with zero padding, torch.max / abs sub-gradients at the ties).  The two
+visualisation functions stay forward-only and refuse a call that would need a gradient."""
 
 import torch
 
@@ -50,30 +51,50 @@ def deblur_events(flow, event_list, res, round_idx=True, polarity_mask=None, rou
     return compute_pol_iwe(flow, event_list, res, pm, round_idx, round_flow)[:, 0:1]
 
 
-# ---- the training-time primitives, stand-alone and forward-only (reference :5-136) ---------------------------------------
+# ---- the training-time primitives, stand-alone and differentiable (reference :5-136) -----------------------------------
+def _f32(t):
+    return t.to(torch.float32).contiguous()
+
+
 def event_propagation(events_ts, events_idx, flow, tref):
     """Linear warp of event locations to `tref` with their per-event flow (reference :5-14)."""
     return events_idx + (tref - events_ts) * flow
 
 
+class _EventFlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fx, fy, loc):
+        B, H, W = fx.shape
+        N = loc.shape[1]
+        out = torch.empty((B, N, 2), dtype=torch.float32, device=loc.device)
+        rc = _lib.lib().tef_event_flow(fx.data_ptr(), fy.data_ptr(), B, H, W, loc.data_ptr(), N, out.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "tef_event_flow")
+        ctx.save_for_backward(fx, fy, loc)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        fx, fy, loc = ctx.saved_tensors
+        B, H, W = fx.shape
+        N = loc.shape[1]
+        gout = _f32(gout)
+        need_maps = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dfx = torch.zeros_like(fx) if need_maps else None
+        dfy = torch.zeros_like(fy) if need_maps else None
+        dloc = torch.empty_like(loc) if ctx.needs_input_grad[2] else None
+        rc = _lib.lib().tef_event_flow_backward(fx.data_ptr(), fy.data_ptr(), B, H, W, loc.data_ptr(), N, gout.data_ptr(),
+                                                dfx.data_ptr() if need_maps else None, dfy.data_ptr() if need_maps else None,
+                                                dloc.data_ptr() if dloc is not None else None, _lib.stream_ptr())
+        _lib.check(rc, "tef_event_flow_backward")
+        return (dfx if ctx.needs_input_grad[0] else None, dfy if ctx.needs_input_grad[1] else None, dloc)
+
+
 def get_event_flow(flow_map_x, flow_map_y, event_loc):
     """Bilinear lookup (align_corners, zero padding) of [B, H, W] flow maps at [B, N, 2] (y, x) -> [B, N, 2] (f_y, f_x)
-    (reference :17-40)."""
-    _forward_only("get_event_flow", flow_map_x=flow_map_x, flow_map_y=flow_map_y, event_loc=event_loc)
+    (reference :17-40); gradients to both maps and to the locations."""
     for name, t in (("flow_map_x", flow_map_x), ("flow_map_y", flow_map_y), ("event_loc", event_loc)):
         _lib.require_device_tensor(t, name)
-    fx, fy = flow_map_x.detach().to(torch.float32).contiguous(), flow_map_y.detach().to(torch.float32).contiguous()
-    loc = event_loc.detach().to(torch.float32).contiguous()
-    B, H, W = fx.shape
-    N = loc.shape[1]
-    out = torch.empty((B, N, 2), dtype=torch.float32, device=loc.device)
-    lib = _lib.lib()
-    for b in range(B):            # the validation kernel is per sample (flow_val.py runs at batch 1)
-        if N:
-            rc = lib.tef_val_event_step(fx[b].data_ptr(), fy[b].data_ptr(), H, W, loc[b].data_ptr(), None, None, N, 0.0, 0,
-                                        out[b].data_ptr(), _lib.stream_ptr())
-            _lib.check(rc, "tef_val_event_step")
-    return out
+    return _EventFlowFn.apply(_f32(flow_map_x), _f32(flow_map_y), _f32(event_loc))
 
 
 def purge_unfeasible(event_loc, event_pol_mask, res):
@@ -83,35 +104,77 @@ def purge_unfeasible(event_loc, event_pol_mask, res):
     return event_loc * inside, event_pol_mask * inside
 
 
+class _InterpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loc, H, W, round_idx):
+        B, N = loc.shape[0], loc.shape[1]
+        n_out = N if round_idx else 4 * N
+        idx = torch.empty((B, n_out, 1), dtype=torch.float32, device=loc.device)
+        wgt = torch.empty((B, n_out, 1), dtype=torch.float32, device=loc.device)
+        rc = _lib.lib().tef_interp_corners(loc.data_ptr(), B, N, H, W, 1 if round_idx else 0, idx.data_ptr(), wgt.data_ptr(),
+                                           _lib.stream_ptr())
+        _lib.check(rc, "tef_interp_corners")
+        ctx.geom = (H, W, round_idx)
+        ctx.save_for_backward(loc)
+        ctx.mark_non_differentiable(idx)          # floor / round: no gradient (reference :74-94)
+        return idx, wgt
+
+    @staticmethod
+    def backward(ctx, _gidx, gw):
+        (loc,) = ctx.saved_tensors
+        H, W, round_idx = ctx.geom
+        if round_idx:                             # weights = ones * mask (reference :76-80): constant in the locations
+            return None, None, None, None
+        B, N = loc.shape[0], loc.shape[1]
+        gw = _f32(gw)
+        dloc = torch.empty_like(loc)
+        rc = _lib.lib().tef_interp_corners_backward(loc.data_ptr(), B, N, H, W, gw.data_ptr(), dloc.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "tef_interp_corners_backward")
+        return dloc, None, None, None
+
+
 def get_interpolation(warped_events, res, round_idx=False, zeros=None):
     """Scatter indices and bilinear (or nearest-pixel) weights of [B, N, 2] locations (reference :63-113):
-    -> idx, weights [B, 4N, 1] (corner blocks TL, TR, BL, BR) or [B, N, 1] with round_idx."""
-    _forward_only("get_interpolation", warped_events=warped_events)
+    -> idx, weights [B, 4N, 1] (corner blocks TL, TR, BL, BR) or [B, N, 1] with round_idx; the weights are differentiable
+    in the locations."""
     _lib.require_device_tensor(warped_events, "warped_events")
-    loc = warped_events.detach().to(torch.float32).contiguous()
-    B, N = loc.shape[0], loc.shape[1]
-    n_out = N if round_idx else 4 * N
-    idx = torch.empty((B, n_out, 1), dtype=torch.float32, device=loc.device)
-    wgt = torch.empty((B, n_out, 1), dtype=torch.float32, device=loc.device)
-    rc = _lib.lib().tef_interp_corners(loc.data_ptr(), B, N, int(res[0]), int(res[1]), 1 if round_idx else 0, idx.data_ptr(),
-                                       wgt.data_ptr(), _lib.stream_ptr())
-    _lib.check(rc, "tef_interp_corners")
-    return idx, wgt
+    return _InterpFn.apply(_f32(warped_events), int(res[0]), int(res[1]), bool(round_idx))
+
+
+class _ScatterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, wgt, pm, HW):
+        B, n = idx.shape[0], idx.shape[1]
+        out = torch.empty((B, HW), dtype=torch.float32, device=idx.device)
+        rc = _lib.lib().tef_scatter_add(idx.data_ptr(), wgt.data_ptr(), pm.data_ptr() if pm is not None else None, B, n, HW,
+                                        out.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc, "tef_scatter_add")
+        ctx.HW = HW
+        ctx.has_mask = pm is not None
+        ctx.save_for_backward(idx, wgt, pm)
+        return out
+
+    @staticmethod
+    def backward(ctx, gimg):
+        idx, wgt, pm = ctx.saved_tensors
+        B, n = idx.shape[0], idx.shape[1]
+        gimg = _f32(gimg)
+        dw = torch.empty_like(wgt) if ctx.needs_input_grad[1] else None
+        dpm = torch.empty_like(pm) if (ctx.has_mask and ctx.needs_input_grad[2]) else None
+        rc = _lib.lib().tef_scatter_add_backward(idx.data_ptr(), wgt.data_ptr(), pm.data_ptr() if ctx.has_mask else None, B, n,
+                                                 ctx.HW, gimg.data_ptr(), dw.data_ptr() if dw is not None else None,
+                                                 dpm.data_ptr() if dpm is not None else None, _lib.stream_ptr())
+        _lib.check(rc, "tef_scatter_add_backward")
+        return None, dw, dpm, None
 
 
 def interpolate(idx, weights, res, polarity_mask=None, zeros=None):
-    """Image [B, 1, H, W] of the weights scattered to their indices (reference :116-136)."""
-    _forward_only("interpolate", idx=idx, weights=weights, polarity_mask=polarity_mask, zeros=zeros)
+    """Image [B, 1, H, W] of the weights scattered to their indices (reference :116-136); differentiable in the weights,
+    the polarity mask and `zeros`."""
     _lib.require_device_tensor(idx, "idx")
-    B, n = idx.shape[0], idx.shape[1]
-    HW = int(res[0]) * int(res[1])
-    ix, w = idx.detach().to(torch.float32).contiguous(), weights.detach().to(torch.float32).contiguous()
-    pm = polarity_mask.detach().to(torch.float32).contiguous() if polarity_mask is not None else None
-    out = torch.empty((B, HW), dtype=torch.float32, device=idx.device)
-    rc = _lib.lib().tef_scatter_add(ix.data_ptr(), w.data_ptr(), pm.data_ptr() if pm is not None else None, B, n, HW,
-                                    out.data_ptr(), _lib.stream_ptr())
-    _lib.check(rc, "tef_scatter_add")
-    out = out.view(B, 1, int(res[0]), int(res[1]))
+    H, W = int(res[0]), int(res[1])
+    pm = _f32(polarity_mask) if polarity_mask is not None else None
+    out = _ScatterFn.apply(_f32(idx.detach()), _f32(weights), pm, H * W).view(idx.shape[0], 1, H, W)
     if zeros is not None:
         out = out + zeros.view_as(out)
     return out

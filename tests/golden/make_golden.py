@@ -170,8 +170,35 @@ def save_primitives(seed=11):
     a = iwe_ts / (iwe + 1e-9)
     fl = L.focus_loss(iwe, a)
     out.update(fmt_ts=tsl.numpy(), fmt_iwe=iwe.numpy(), fmt_iwe_ts=iwe_ts.numpy(), focus=np.float32(fl.item()))
+    # a loss built from the primitives one by one (what a caller of utils/iwe.py writes by hand): lookup -> propagate ->
+    # purge -> corners -> two per-polarity images and their timestamp images -> focus loss; gradients to both flow maps
+    # and to the event locations.  (Drawn after everything above so that the earlier arrays keep their values.)
+    cfx = torch.tensor((1.5 * rng.standard_normal((B, H, W))).astype(np.float32), requires_grad=True)
+    cfy = torch.tensor((1.5 * rng.standard_normal((B, H, W))).astype(np.float32), requires_grad=True)
+    cloc = np.stack([rng.random((B, N)) * (H - 1), rng.random((B, N)) * (W - 1)], -1).astype(np.float32)
+    cloc[:, :6] = np.round(cloc[:, :6])
+    cloc_t = torch.tensor(cloc, requires_grad=True)
+    cts = torch.tensor(rng.random((B, N, 1)).astype(np.float32))
+    cpm = torch.tensor(np.eye(2, dtype=np.float32)[(rng.random((B, N)) < 0.5).astype(int)])
+    flow = ref_iwe.get_event_flow(cfx, cfy, cloc_t)
+    warped = ref_iwe.event_propagation(cts, cloc_t, flow, 1.0)
+    warped, wpm = ref_iwe.purge_unfeasible(warped, cpm, (H, W))
+    cidx, cw = ref_iwe.get_interpolation(warped, (H, W))
+    tau = torch.cat([1.0 - (1.0 - cts)] * 4, 1)
+    imgs, timgs = [], []
+    for c in range(2):
+        m4 = torch.cat([wpm[:, :, c:c + 1]] * 4, 1)
+        imgs.append(ref_iwe.interpolate(cidx.long(), cw, (H, W), polarity_mask=m4))
+        timgs.append(ref_iwe.interpolate(cidx.long(), cw * tau, (H, W), polarity_mask=m4))
+    ciwe, ciwe_ts = torch.cat(imgs, 1), torch.cat(timgs, 1)
+    closs = L.focus_loss(ciwe, ciwe_ts / (ciwe + 1e-9))
+    closs.backward()
+    out.update(chain_fx=cfx.detach().numpy(), chain_fy=cfy.detach().numpy(), chain_loc=cloc, chain_ts=cts.numpy(),
+               chain_pm=cpm.numpy(), chain_iwe=ciwe.detach().numpy(), chain_iwe_ts=ciwe_ts.detach().numpy(),
+               chain_loss=np.float32(closs.item()), chain_dfx=cfx.grad.numpy(), chain_dfy=cfy.grad.numpy(),
+               chain_dloc=cloc_t.grad.numpy())
     np.savez_compressed(os.path.join(HERE, "primitives.npz"), **out)
-    print("primitives: focus=%.6f" % fl.item())
+    print("primitives: focus=%.6f chain=%.6f" % (fl.item(), closs.item()))
 
 
 def save_encodings(seed=12):
@@ -200,6 +227,9 @@ def main():
         # the BASELINE resolution and window (128x128, P = 10, 10 000 gradient + 2 000 detached events per pass), one sample
         save_seeded_case("it_two_128_p10", "Iterative", 128, 128, 1, 10, 2, 1, "two", 10000, 2000, seed=31)
         save_seeded_case("lin_128_p10", "Linear", 128, 128, 1, 10, 1, 1, "two", 10000, 2000, seed=32)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--primitives":
+        save_primitives()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--unscaled":
         save_loss_case("it_two_unscaled", "Iterative", 16, 20, 2, 6, 2, 1, "two", 180, 40, seed=14, loss_scaling=False)
