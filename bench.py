@@ -878,7 +878,15 @@ def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         ev = a.batch * a.passes * (a.events + a.detached) * world
+        # the per-pass `new_seq` agreement of the eager Trainer loop (train_flow.py:83-87 for the global batch): a blocking
+        # all-reduce(MAX) on the host-side group, once per pass
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            parallel.any_rank(False)
+        flag_ms = 1e3 * (time.perf_counter() - t0) / 20
         out.update({
+            "new_seq_exchange_ms_per_pass": round(flag_ms, 4),
             "dp_train_window_ms": round(ms, 3), "dp_train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": windows,
             "allreduce_ms": round(ar_ms, 3), "allreduce_bytes": nbytes,
             # bus bandwidth of a ring all-reduce: every rank sends and receives 2 (N - 1) / N of the buffer

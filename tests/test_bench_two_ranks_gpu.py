@@ -38,6 +38,7 @@ def test_loss_mode_two_ranks():
     assert x["rccl_world_size"] == 2 and x["rank_checksum"] == x["rank_checksum_expected"] == 3.0
     assert x["dp_train_window_ms"] > 0 and x["allreduce_ms"] > 0 and x["allreduce_GBps"] > 0
     assert x["allreduce_bytes"] == 4 * 31_365_352 and x["replicas_bit_identical"]
+    assert 0 < x["new_seq_exchange_ms_per_pass"] < 50
 
 
 def test_train_mode_two_ranks_graph():
