@@ -360,6 +360,27 @@ int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *co
                           const float *const *dflows, const float *const *dstates, int want_dx, float *gtape,
                           unsigned long long *ran, int *dstate_valid, int *dx_valid, void *workspace,
                           size_t workspace_bytes, void *stream);
+/* The two halves of a pass as separate calls, so that a caller can put them on two streams: the encoders of pass t + 1 do
+ * not depend on the residual blocks / decoders / heads of pass t (only the recurrent states cross passes,
+ * models/arch.py:225-227), so the halves of consecutive passes can fill each other's launch ramps and tails.
+ * part: TEF_NET_ENCODERS (heads + ConvGRU cells: reads x and states_in, writes the new states into the tape),
+ * TEF_NET_DECODERS (residual blocks, decoders, prediction heads, flows: reads the new states from the SAME tape), or both
+ * (= tef_net_pass_forward / _backward).  The halves of one pass share the pass's tape and gradient arena; the caller orders
+ * them (decoders after encoders going forward, encoders after decoders going backward) and gives each stream its own
+ * workspace.
+ * Backward, decoder half: dflows -> dstate_off[i] = offset (floats) in gtape of what this half sends to NEW state i, as ONE
+ * tensor per level (-1: nothing), x / states_in / dstates / dx_valid unused (may be NULL).  The caller adds the gradients
+ * arriving from the next pass (autograd does) and hands the sums to the encoder half as `dstates`:
+ * encoder half: dstates = TOTAL gradient w.r.t. new state i -> dstate_off[i] = offset of d loss / d INCOMING state i (-1:
+ * none), dx as in tef_net_pass_backward; dflows unused.  `ran` of the two calls are OR-ed for tef_net_window_wgrads. */
+#define TEF_NET_ENCODERS 1
+#define TEF_NET_DECODERS 2
+int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, const float *const *states_in, float *tape,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, const float *const *states_in, const float *tape,
+                               const float *const *dflows, const float *const *dstates, int want_dx, float *gtape,
+                               unsigned long long *ran, long long *dstate_off, int *dx_valid, void *workspace,
+                               size_t workspace_bytes, void *stream);
 /* the deferred weight gradients of a BPTT window: per layer one reduction over the pixels of all npass backward calls */
 int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran,

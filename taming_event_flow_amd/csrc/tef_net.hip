@@ -81,6 +81,7 @@ struct GTape {
     size_t g_e[L], g_ur[L], g_o[L], de[L], dh[L], dxin[L];
     size_t gy[R], gmid[R], dmid[R], dres[R];
     size_t gp[L], gd[L], fup[L], dd[L], dx0[L], dx1[L], skip[L], dprev[L];
+    size_t dtop;        // decoder half run alone: the deepest state's gradient addends summed (residual chain + skip)
     size_t total;
 };
 
@@ -138,6 +139,7 @@ GTape make_gtape(const tef_net_plan *p, const Geo &g)
         t.skip[k] = take(o, pl * g.src[k]);
         t.dprev[k] = take(o, k ? pl * p->nout : 0);
     }
+    t.dtop = take(o, g.n[g.top]);
     t.total = o;
     return t;
 }
@@ -255,20 +257,32 @@ int tef_net_layout(const tef_net_plan *p, size_t *flow_off, size_t *state_off, s
 int tef_net_pass_forward(const tef_net_plan *p, const float *x, const float *const *states_in, float *tape, void *ws,
                          size_t ws_bytes, void *stream)
 {
+    return tef_net_pass_forward_part(p, TEF_NET_ENCODERS | TEF_NET_DECODERS, x, states_in, tape, ws, ws_bytes, stream);
+}
+
+int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, const float *const *states_in, float *tape,
+                              void *ws, size_t ws_bytes, void *stream)
+{
     Geo g;
     if (!make_geo(p, &g)) return TEF_ERR_INVALID;
-    if (!x || !states_in || !tape || !ws) return tef::fail("tef_net_pass_forward: null pointer"), TEF_ERR_INVALID;
+    if (!(part & (TEF_NET_ENCODERS | TEF_NET_DECODERS))) return tef::fail("tef_net_pass_forward: no part selected"), TEF_ERR_INVALID;
+    if (!tape || !ws || ((part & TEF_NET_ENCODERS) && (!x || !states_in)))
+        return tef::fail("tef_net_pass_forward: null pointer"), TEF_ERR_INVALID;
     if (ws_bytes < workspace_need(p, g)) return tef::fail("tef_net_pass_forward: workspace too small"), TEF_ERR_WORKSPACE;
     const Tape t = make_tape(p, g);
     const Descs D = make_descs(p, g, 1);
-    const float *cur = x;
-    for (int i = 0; i < g.lv; ++i) {
-        if (!states_in[i]) return tef::fail("tef_net_pass_forward: null state (pass zeros for a fresh sequence)"), TEF_ERR_INVALID;
-        TEF_TRY(tef_conv_forward(&D.head[i], cur, nullptr, nullptr, p->head[i].wp, p->head[i].bias, tape + t.e[i], ws, ws_bytes, stream));
-        TEF_TRY(tef_convgru_cell_fwd(&D.gru[i], tape + t.e[i], states_in[i], p->gate_ur[i].wp, p->gate_o[i].wp, p->gate_ur[i].bias,
-                                     p->gate_o[i].bias, tape + t.u[i], tape + t.r[i], tape + t.o[i], tape + t.hn[i], ws, ws_bytes, stream));
-        cur = tape + t.hn[i];
+    if (part & TEF_NET_ENCODERS) {
+        const float *cur = x;
+        for (int i = 0; i < g.lv; ++i) {
+            if (!states_in[i]) return tef::fail("tef_net_pass_forward: null state (pass zeros for a fresh sequence)"), TEF_ERR_INVALID;
+            TEF_TRY(tef_conv_forward(&D.head[i], cur, nullptr, nullptr, p->head[i].wp, p->head[i].bias, tape + t.e[i], ws, ws_bytes, stream));
+            TEF_TRY(tef_convgru_cell_fwd(&D.gru[i], tape + t.e[i], states_in[i], p->gate_ur[i].wp, p->gate_o[i].wp, p->gate_ur[i].bias,
+                                         p->gate_o[i].bias, tape + t.u[i], tape + t.r[i], tape + t.o[i], tape + t.hn[i], ws, ws_bytes, stream));
+            cur = tape + t.hn[i];
+        }
     }
+    if (!(part & TEF_NET_DECODERS)) return 0;
+    const float *cur = tape + t.hn[g.top];           // (the new states of this pass: written by the encoder half)
     tef_conv_desc dres = D.res;
     for (int j = 0; j < g.nres; ++j) {
         dres.act = TEF_ACT_RELU;
@@ -301,9 +315,25 @@ int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *co
                           unsigned long long *ran_out, int *dstate_valid, int *dx_valid, void *ws, size_t ws_bytes,
                           void *stream)
 {
+    long long off[L];
+    if (!dstate_valid) return tef::fail("tef_net_pass_backward: null pointer"), TEF_ERR_INVALID;
+    const int rc = tef_net_pass_backward_part(p, TEF_NET_ENCODERS | TEF_NET_DECODERS, x, states_in, tape, dflows, dstates, want_dx,
+                                              gtape, ran_out, off, dx_valid, ws, ws_bytes, stream);
+    if (rc == 0)
+        for (int i = 0; i < p->levels; ++i) dstate_valid[i] = off[i] >= 0;
+    return rc;
+}
+
+int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, const float *const *states_in, const float *tape,
+                               const float *const *dflows, const float *const *dstates, int want_dx, float *gtape,
+                               unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws, size_t ws_bytes,
+                               void *stream)
+{
     Geo g;
     if (!make_geo(p, &g)) return TEF_ERR_INVALID;
-    if (!x || !states_in || !tape || !dflows || !dstates || !gtape || !ws)
+    const bool enc = part & TEF_NET_ENCODERS, dec = part & TEF_NET_DECODERS;
+    if (!enc && !dec) return tef::fail("tef_net_pass_backward: no part selected"), TEF_ERR_INVALID;
+    if (!tape || !gtape || !ws || !dstate_off || (dec && !dflows) || (enc && (!x || !states_in || !dstates || !dx_valid)))
         return tef::fail("tef_net_pass_backward: null pointer"), TEF_ERR_INVALID;
     if (ws_bytes < workspace_need(p, g)) return tef::fail("tef_net_pass_backward: workspace too small"), TEF_ERR_WORKSPACE;
     const Tape t = make_tape(p, g);
@@ -313,7 +343,7 @@ int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *co
     const float *skip_grads[L] = {nullptr};   // d loss / d (features + encoder skip) of decoder k, shared by both addends
     const float *d_prev_pred = nullptr;       // gradient arriving at prediction k from decoder k + 1
     const float *d_feat = nullptr;            // gradient arriving at decoder k's output from decoder k + 1
-    for (int k = g.lv - 1; k >= 0; --k) {
+    for (int k = g.lv - 1; k >= 0 && dec; --k) {
         const int lvl = g.lvl[k], hw = g.hs[k] * g.ws[k];
         const float *srcs[4];
         int ns = 0;
@@ -355,7 +385,7 @@ int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *co
     int ns = 0;
     if (skip_grads[0]) srcs[ns++] = skip_grads[0];
     const int hwt = g.h[g.top] * g.w[g.top], Ct = g.C[g.top];
-    for (int j = g.nres - 1; j >= 0 && ns; --j) {
+    for (int j = g.nres - 1; j >= 0 && ns && dec; --j) {
         const float *xin = j ? tape + t.y[j - 1] : tape + t.hn[g.top];
         TEF_TRY(tef_grad_act(srcs, ns, tape + t.y[j], TEF_ACT_RELU, g.B, Ct, hwt, gtape + q.gy[j], p->res2[j].db, stream));
         TEF_TRY(conv_bwd(D.res, p->res2[j], gtape + q.gy[j], tape + t.mid[j], nullptr, gtape + q.dmid[j], nullptr, ws, ws_bytes, stream));
@@ -369,7 +399,23 @@ int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *co
     }
     // encoders, deepest first.  (The deepest state is decoder 0's skip addend AND the input of the residual blocks; without
     // residual blocks `srcs` is that same gradient once more — features + skip = 2 x the state — and it is added twice.)
-    for (int i = 0; i < g.lv; ++i) dstate_valid[i] = 0;
+    for (int i = 0; i < g.lv; ++i) dstate_off[i] = -1;
+    if (!enc) {
+        // Decoder half alone: what it sends to the new state of each level, as ONE tensor per level for the caller's
+        // autograd (the encoder half, run later with these added to the next pass's gradients, sums nothing itself).
+        // Levels below the top receive their decoder's skip gradient; the deepest state also feeds the residual chain.
+        for (int i = 0; i < g.top; ++i)
+            if (skip_grads[g.lv - 1 - i]) dstate_off[i] = (long long)q.skip[g.lv - 1 - i];
+        if (skip_grads[0]) srcs[ns++] = skip_grads[0];
+        if (ns == 1) {
+            dstate_off[g.top] = (long long)(srcs[0] - gtape);
+        } else if (ns > 1) {
+            TEF_TRY(tef_grad_act(srcs, ns, nullptr, TEF_ACT_NONE, g.B, Ct, hwt, gtape + q.dtop, nullptr, stream));
+            dstate_off[g.top] = (long long)q.dtop;
+        }
+        if (ran_out) *ran_out = ran;
+        return 0;
+    }
     *dx_valid = 0;
     for (int i = g.lv - 1; i >= 0; --i) {
         const float *sources[4];
@@ -387,7 +433,7 @@ int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *co
                                      p->gate_ur[i].w2, p->gate_o[i].w2, gtape + q.g_ur[i], gtape + q.g_o[i], gtape + q.de[i], gtape + q.dh[i],
                                      dur ? nullptr : p->gate_ur[i].dw, dur ? nullptr : p->gate_ur[i].dw2, dog ? nullptr : p->gate_o[i].dw,
                                      p->gate_ur[i].db, p->gate_ur[i].db2, p->gate_o[i].db, ws, ws_bytes, stream));
-        dstate_valid[i] = 1;
+        dstate_off[i] = (long long)q.dh[i];
         ran |= bit_ur(i) | bit_og(i);
         const float *one[1] = {gtape + q.de[i]};
         TEF_TRY(tef_grad_act(one, 1, tape + t.e[i], TEF_ACT_RELU, g.B, g.C[i], g.h[i] * g.w[i], gtape + q.g_e[i], p->head[i].db, stream));

@@ -18,6 +18,14 @@ bound by the host (49 ms of Python per window for 38 ms of GPU work).  Now the l
 
 This file only fills the plan (pointers of packed weights, biases, gradient targets), owns the arenas and is the autograd
 boundary.  No ATen arithmetic runs inside a pass (padding a non-multiple-of-16 input is one strided copy).
+
+Two streams (opt-in, `PassEngine.side_stream`; train.Trainer switches it on): only the recurrent states cross passes
+(reference models/arch.py:225-227), so the residual blocks / decoders / heads of pass t are independent of the encoders
+of pass t + 1.  The pass is then TWO autograd nodes — `_EncFn` on the caller's stream, `_DecFn` on the side stream
+(`tef_net_pass_forward_part` / `_backward_part`) — and autograd itself runs each node's backward on the stream of its
+forward, so the halves of consecutive passes overlap in both directions and fill each other's launch ramps and tails.
+The flows then live on the side stream: whoever consumes them either works on that stream or waits for it
+(`PassEngine.join`); without `defer_join` the pass waits itself before returning.
 """
 
 import ctypes
@@ -41,23 +49,34 @@ def _p(t):
 class _Tape:
     """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
-    __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape")
+    __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape", "gtape", "ran", "targets_set", "queued",
+                 "stream")
 
 
 class PassEngine:
     def __init__(self, arch):
         self.arch = arch
         self.plan = arch.plan
-        self._ws = None
+        self._ws = {}                 # one workspace per stream the engine launches on
+        self.side_stream = None       # set: passes that record a graph run as two nodes on two streams (module docstring)
+        self.defer_join = False       # with side_stream: leave the flows on the side stream (the caller joins)
+        self.debug_delay = None       # tests: (cycles, cycles) of spinning put in front of the (encoder, decoder) halves
         self._zeros = {}
         self._layout = {}
         self._pending = []            # backward calls of the current window whose weight gradients are still deferred
 
     # ---- buffers -----------------------------------------------------------------------------------------------
     def workspace(self, nbytes, device):
-        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
-            self._ws = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
-        return self._ws
+        key = torch.cuda.current_stream().cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes or ws.device != device:
+            ws = self._ws[key] = torch.empty((max(nbytes, 1 << 20),), dtype=torch.uint8, device=device)
+        return ws
+
+    def join(self):
+        """Make the current stream wait for the side stream (the decoder halves issued so far)."""
+        if self.side_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.side_stream)
 
     def zero_state(self, shape, device):
         key = (tuple(shape), device)
@@ -155,66 +174,85 @@ class PassEngine:
             tgt(pl.pred[k], (head.conv2d.weight,), (head.conv2d.bias,))
 
     # ---- the pass ----------------------------------------------------------------------------------------------
-    def forward(self, x, states, keep):
-        """x [B, bins, H, W] -> (flows: 4 x [B, 2, H, W], new states: 4 x [B, C_i, h_i, w_i], tape | None)."""
+    def forward(self, x, states, keep, part=3, rec=None):
+        """x [B, bins, H, W] -> (flows: 4 x [B, 2, H, W], new states: 4 x [B, C_i, h_i, w_i], tape | None).
+        part 1 (encoders only): flows is None, the record is always returned; part 2 (the rest of the pass `rec` began,
+        on the current stream): new states is None."""
         plan = self.plan
-        _lib.require_device_tensor(x, "network input")
-        x = x.contiguous()
-        if x.dtype != torch.float32:
-            x = x.to(torch.float32)
-        B, _, H, W = x.shape
-        ph, pw = plan.padding(H, W)
-        if ph or pw:        # E-RAFT style padding at the top / left (reference models/model_util.py:52-65)
-            xp = x.new_zeros((B, x.shape[1], H + ph, W + pw))
-            xp[:, :, ph:, pw:] = x
-        else:
-            xp = x
-        pl = self.make_plan(B, H + ph, W + pw, ph, pw)
-        ntape, _, wsb, fo, so, _, _ = self.layout(pl)
         n = plan.levels
-        st, h, w = [], H + ph, W + pw
-        for i in range(n):
-            h, w = h // 2, w // 2
-            s = states[i]
-            if s is None:
-                s = self.zero_state((B, plan.width[i], h, w), x.device)
+        if part & 1:
+            _lib.require_device_tensor(x, "network input")
+            x = x.contiguous()
+            if x.dtype != torch.float32:
+                x = x.to(torch.float32)
+            B, _, H, W = x.shape
+            ph, pw = plan.padding(H, W)
+            if ph or pw:        # E-RAFT style padding at the top / left (reference models/model_util.py:52-65)
+                xp = x.new_zeros((B, x.shape[1], H + ph, W + pw))
+                xp[:, :, ph:, pw:] = x
             else:
-                _lib.require_device_tensor(s, "recurrent state")
-                if s.dtype != torch.float32 or not s.is_contiguous():
-                    s = s.to(torch.float32).contiguous()
-                if tuple(s.shape) != (B, plan.width[i], h, w):
-                    raise RuntimeError(f"recurrent state {i} has shape {tuple(s.shape)}, expected {(B, plan.width[i], h, w)}")
-            st.append(s)
-        arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
-        tape = torch.empty((ntape,), dtype=torch.float32, device=x.device)
-        ws = self.workspace(wsb, x.device)
-        rc = _lib.lib().tef_net_pass_forward(ctypes.byref(pl), xp.data_ptr(), arr, tape.data_ptr(), ws.data_ptr(), ws.numel(),
-                                             _lib.stream_ptr())
-        _lib.check(rc, "tef_net_pass_forward")
-        fshape = (B, plan.nout, H, W)
-        flows = [tape[fo[k]:fo[k] + B * plan.nout * H * W].view(fshape) for k in range(n)]
-        new_states = [tape[so[i]:so[i] + st[i].numel()].view(st[i].shape) for i in range(n)]
-        rec = None
-        if keep:
+                xp = x
+            pl = self.make_plan(B, H + ph, W + pw, ph, pw)
+            ntape = self.layout(pl)[0]
+            st, h, w = [], H + ph, W + pw
+            for i in range(n):
+                h, w = h // 2, w // 2
+                s = states[i]
+                if s is None:
+                    s = self.zero_state((B, plan.width[i], h, w), x.device)
+                else:
+                    _lib.require_device_tensor(s, "recurrent state")
+                    if s.dtype != torch.float32 or not s.is_contiguous():
+                        s = s.to(torch.float32).contiguous()
+                    if tuple(s.shape) != (B, plan.width[i], h, w):
+                        raise RuntimeError(f"recurrent state {i} has shape {tuple(s.shape)}, expected {(B, plan.width[i], h, w)}")
+                st.append(s)
             rec = _Tape()
-            rec.plan, rec.xp, rec.states_in, rec.states_arr, rec.tape = pl, xp, st, arr, tape
+            rec.plan, rec.xp, rec.states_in, rec.tape = pl, xp, st, torch.empty((ntape,), dtype=torch.float32, device=x.device)
+            rec.states_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
-        return flows, new_states, rec
+            rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
+        pl = rec.plan
+        _, _, wsb, fo, so, _, _ = self.layout(pl)
+        B, H, W = rec.x_shape[0], rec.x_shape[2], rec.x_shape[3]
+        ws = self.workspace(wsb, rec.tape.device)
+        if part == 3:
+            rc = _lib.lib().tef_net_pass_forward(ctypes.byref(pl), rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        else:
+            rc = _lib.lib().tef_net_pass_forward_part(ctypes.byref(pl), part, rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "tef_net_pass_forward")
+        flows = new_states = None
+        if part & 2:
+            fshape = (B, plan.nout, H, W)
+            flows = [rec.tape[fo[k]:fo[k] + B * plan.nout * H * W].view(fshape) for k in range(n)]
+        if part & 1:
+            new_states = [rec.tape[so[i]:so[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) for i in range(n)]
+        return flows, new_states, (rec if (keep or part != 3) else None)
 
-    def backward(self, rec, dflows, dstates, params, want_dx):
+    def backward(self, rec, dflows, dstates, params, want_dx, part=3):
         """-> (gradients w.r.t. the incoming states, gradient w.r.t. the network input or None, parameter gradients for
         autograd).  Parameter gradients are added into the parameters' own .grad buffers when the training loop owns them
-        (`direct_grads`: nothing is handed to autograd), otherwise into one fresh zero buffer whose views are returned."""
+        (`direct_grads`: nothing is handed to autograd), otherwise into one fresh zero buffer whose views are returned.
+        part 2 (decoder half, two-stream passes; direct gradients only): the first result is what the half sends to each
+        NEW state (one tensor or None per level); part 1 (encoder half): `dstates` are the total gradients of the new
+        states."""
         a, plan = self.arch, self.plan
         n = plan.levels
         pl = rec.plan
+        dev = rec.tape.device
         direct = a.direct_grads and all(p.grad is not None and p.grad.is_contiguous() for p in params if p.requires_grad)
+        if part != 3 and not direct:
+            raise RuntimeError("two-stream passes accumulate parameter gradients in place: they need direct_grads")
         fresh = None
         if direct:
-            self._grad_targets(pl, lambda p: p.grad if p.requires_grad else None, a.deferred_wgrad)
+            if not rec.targets_set:
+                self._grad_targets(pl, lambda p: p.grad if p.requires_grad else None, a.deferred_wgrad)
+                rec.targets_set = True
         else:
             tot = sum(p.numel() for p in params if p.requires_grad)
-            flat = torch.zeros((tot,), dtype=torch.float32, device=rec.tape.device)
+            flat = torch.zeros((tot,), dtype=torch.float32, device=dev)
             fresh, o = {}, 0
             for p in params:
                 if p.requires_grad:
@@ -222,31 +260,43 @@ class PassEngine:
                     o += p.numel()
             self._grad_targets(pl, lambda p: fresh.get(id(p)), False)
         _, ngt, wsb, _, _, do, dxo = self.layout(pl)
-        gtape = torch.empty((ngt,), dtype=torch.float32, device=rec.tape.device)
-        dfl = [None if g is None else g.to(torch.float32).contiguous() for g in dflows]
-        dst = [None if g is None else g.to(torch.float32).contiguous() for g in dstates]
+        if self.debug_delay and part != 3 and self.debug_delay[part - 1]:
+            torch.cuda._sleep(int(self.debug_delay[part - 1]))
+        if rec.gtape is None:
+            rec.gtape = torch.empty((ngt,), dtype=torch.float32, device=dev)
+        gtape = rec.gtape
+        if part != 3 and rec.stream is not None:      # the halves of a pass share the arenas across their two streams
+            cur = torch.cuda.current_stream()
+            if cur != rec.stream:
+                gtape.record_stream(rec.stream)
+                gtape.record_stream(cur)
+        dfl = [None if g is None else g.to(torch.float32).contiguous() for g in (dflows or [None] * n)]
+        dst = [None if g is None else g.to(torch.float32).contiguous() for g in (dstates or [None] * n)]
         a_dfl = (ctypes.c_void_p * n)(*[_p(g) for g in dfl])
         a_dst = (ctypes.c_void_p * n)(*[_p(g) for g in dst])
         ran = ctypes.c_ulonglong(0)
-        dsv = (ctypes.c_int * n)()
+        off = (ctypes.c_longlong * n)()
         dxv = ctypes.c_int(0)
-        ws = self.workspace(wsb, rec.tape.device)
-        rc = _lib.lib().tef_net_pass_backward(ctypes.byref(pl), rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(), a_dfl,
-                                              a_dst, 1 if want_dx else 0, gtape.data_ptr(), ctypes.byref(ran), dsv,
-                                              ctypes.byref(dxv), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        ws = self.workspace(wsb, dev)
+        rc = _lib.lib().tef_net_pass_backward_part(ctypes.byref(pl), part, rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(),
+                                                   a_dfl, a_dst, 1 if want_dx else 0, gtape.data_ptr(), ctypes.byref(ran), off,
+                                                   ctypes.byref(dxv), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "tef_net_pass_backward")
-        dh = [gtape[do[i]:do[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) if dsv[i] else None for i in range(n)]
+        rec.ran |= ran.value
+        dh = [gtape[off[i]:off[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) if off[i] >= 0 else None
+              for i in range(n)]
         dx = None
-        if want_dx:
+        if want_dx and (part & 1):
             ph, pw = rec.geom
             if dxv.value:
                 dx = gtape[dxo:dxo + rec.xp.numel()].view(rec.xp.shape)[:, :, ph:, pw:]
             else:       # no gradient reached the first encoder: zeros, like autograd's own
-                dx = torch.zeros(rec.x_shape, dtype=torch.float32, device=rec.tape.device)
-        if direct and a.deferred_wgrad:
-            if self._pending and (self._pending[0][0].B, self._pending[0][0].H, self._pending[0][0].W) != (pl.B, pl.H, pl.W):
+                dx = torch.zeros(rec.x_shape, dtype=torch.float32, device=dev)
+        if direct and a.deferred_wgrad and not rec.queued:
+            if self._pending and (self._pending[0].plan.B, self._pending[0].plan.H, self._pending[0].plan.W) != (pl.B, pl.H, pl.W):
                 self.flush_window()
-            self._pending.append((pl, rec, gtape, ran.value))       # (keeps the arenas alive until the flush)
+            self._pending.append(rec)       # (keeps the arenas alive until the flush)
+            rec.queued = True
             sm._DEFERRED_ENGINES.add(self)
         grads = [None] * len(params) if direct else [fresh.get(id(p)) for p in params]
         return dh, dx, grads
@@ -259,13 +309,12 @@ class PassEngine:
         if not pend:
             return
         npass = len(pend)
-        xs = (ctypes.c_void_p * npass)(*[r.xp.data_ptr() for _, r, _, _ in pend])
-        sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p))
-                                                          for _, r, _, _ in pend])
-        tapes = (ctypes.c_void_p * npass)(*[r.tape.data_ptr() for _, r, _, _ in pend])
-        gtapes = (ctypes.c_void_p * npass)(*[g.data_ptr() for _, _, g, _ in pend])
-        rans = (ctypes.c_ulonglong * npass)(*[m for _, _, _, m in pend])
-        rc = _lib.lib().tef_net_window_wgrads(ctypes.byref(pend[-1][0]), npass, xs, sts, tapes, gtapes, rans, _lib.stream_ptr())
+        xs = (ctypes.c_void_p * npass)(*[r.xp.data_ptr() for r in pend])
+        sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p)) for r in pend])
+        tapes = (ctypes.c_void_p * npass)(*[r.tape.data_ptr() for r in pend])
+        gtapes = (ctypes.c_void_p * npass)(*[r.gtape.data_ptr() for r in pend])
+        rans = (ctypes.c_ulonglong * npass)(*[r.ran for r in pend])
+        rc = _lib.lib().tef_net_window_wgrads(ctypes.byref(pend[-1].plan), npass, xs, sts, tapes, gtapes, rans, _lib.stream_ptr())
         _lib.check(rc, "tef_net_window_wgrads")
 
 
@@ -292,6 +341,49 @@ class _PassFn(torch.autograd.Function):
         return (None, None, dx) + tuple(dh) + tuple(pg)
 
 
+class _EncFn(torch.autograd.Function):
+    """Two-stream pass, first node: (input, 4 incoming states, parameters...) -> 4 new states.  `holder` receives the
+    pass's record for `_DecFn`."""
+
+    @staticmethod
+    def forward(ctx, engine, nstates, holder, x, *rest):
+        states = list(rest[:nstates])
+        _, new_states, rec = engine.forward(x, states, keep=True, part=1)
+        holder.append(rec)
+        ctx.engine, ctx.rec, ctx.nstates = engine, rec, nstates
+        ctx.params = rest[nstates:]
+        ctx.state_given = [s is not None for s in states]
+        ctx.want_dx = bool(x.requires_grad)
+        return tuple(new_states)
+
+    @staticmethod
+    def backward(ctx, *dstates):
+        dh, dx, pg = ctx.engine.backward(ctx.rec, None, list(dstates), ctx.params, ctx.want_dx, part=1)
+        ctx.rec = None
+        dh = [g if given else None for g, given in zip(dh, ctx.state_given)]
+        return (None, None, None, dx) + tuple(dh) + tuple(pg)
+
+
+class _DecFn(torch.autograd.Function):
+    """Two-stream pass, second node, on the side stream: (4 new states, parameters...) -> 4 flows."""
+
+    @staticmethod
+    def forward(ctx, engine, rec, nstates, *rest):
+        cur = torch.cuda.current_stream()
+        if cur != rec.stream:
+            rec.tape.record_stream(cur)
+        flows, _, _ = engine.forward(None, None, keep=True, part=2, rec=rec)
+        ctx.engine, ctx.rec, ctx.nstates = engine, rec, nstates
+        ctx.params = rest[nstates:]
+        return tuple(flows)
+
+    @staticmethod
+    def backward(ctx, *dflows):
+        ds, _, pg = ctx.engine.backward(ctx.rec, list(dflows), None, ctx.params, False, part=2)
+        ctx.rec = None
+        return (None, None, None) + tuple(ds) + tuple(pg)
+
+
 def run_pass(engine, x, states):
     """Differentiable pass when gradients are enabled, plain launches otherwise."""
     params = [p for p in engine.arch.parameters()]
@@ -300,6 +392,23 @@ def run_pass(engine, x, states):
     if not needs:
         flows, new_states, _ = engine.forward(x, list(states), keep=False)
         return flows, new_states
+    side = engine.side_stream
+    if side is not None and engine.arch.direct_grads and all(p.grad is not None and p.grad.is_contiguous()
+                                                             for p in params if p.requires_grad):
+        holder = []
+        delay = engine.debug_delay or (0, 0)
+        if delay[0]:
+            torch.cuda._sleep(int(delay[0]))
+        new_states = _EncFn.apply(engine, len(states), holder, x, *states, *params)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if delay[1]:
+                torch.cuda._sleep(int(delay[1]))
+            flows = _DecFn.apply(engine, holder[0], len(states), *new_states, *params)
+        if not engine.defer_join:
+            main.wait_stream(side)
+        return list(flows), list(new_states)
     out = _PassFn.apply(engine, len(states), x, *states, *params)
     nflow = len(out) - len(states)
     return list(out[:nflow]), list(out[nflow:])

@@ -131,6 +131,14 @@ class Trainer:
             self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
         self.last_grad_norm = None
+        # Two streams per window (models/engine.py): the decoder half of pass t, and the loss container's update() behind
+        # it, run on a side stream beside the encoders of pass t + 1; BPTT mirrors it through autograd's own stream
+        # handling.  TEF_TWO_STREAMS=0 keeps every launch on one stream.
+        self.dec_stream = None
+        eng = getattr(getattr(self.model, "arch", None), "engine", None)
+        if eng is not None and torch.device(device).type == "cuda" and os.environ.get("TEF_TWO_STREAMS", "1") != "0":
+            self.dec_stream = torch.cuda.Stream(device=device)
+            eng.side_stream = self.dec_stream
 
     def reset(self):
         """train_flow.py:83-87"""
@@ -222,13 +230,32 @@ class Trainer:
         arch = getattr(self.model, "arch", None)
         if hasattr(arch, "flow_scale"):
             arch.flow_scale = float(cfg["loss"]["flow_scaling"])
-            flows = self.model(inputs["net_input"])["flow"]
-            arch.flow_scale = 1.0
+            if self.dec_stream is not None:
+                arch.engine.defer_join = True      # (only here: anyone else calling the model gets joined flows)
+            try:
+                flows = self.model(inputs["net_input"])["flow"]
+            finally:
+                arch.flow_scale = 1.0
+                if self.dec_stream is not None:
+                    arch.engine.defer_join = False
         else:
             flows = [f * cfg["loss"]["flow_scaling"] for f in self.model(inputs["net_input"])["flow"]]
-        self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
-                                  inputs["d_event_list_pol_mask"])
-        return self.loss_function.num_passes >= cfg["data"]["passes_loss"]
+        if self.dec_stream is None:
+            self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
+                                      inputs["d_event_list_pol_mask"])
+            return self.loss_function.num_passes >= cfg["data"]["passes_loss"]
+        # the flows are on the side stream (behind this pass's decoders): so is the container's update; the window's loss
+        # (and everything after it) waits for the side stream once, when the window is complete
+        for k in ("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask"):
+            if isinstance(inputs[k], torch.Tensor) and inputs[k].is_cuda:
+                inputs[k].record_stream(self.dec_stream)       # (the caller may drop them before the side stream read them)
+        with torch.cuda.stream(self.dec_stream):
+            self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
+                                      inputs["d_event_list_pol_mask"])
+        complete = self.loss_function.num_passes >= cfg["data"]["passes_loss"]
+        if complete:
+            torch.cuda.current_stream().wait_stream(self.dec_stream)
+        return complete
 
     def _backward_window(self):
         """train_flow.py:120-125: loss over the window, BPTT backward (local shard of the batch)."""
