@@ -709,15 +709,32 @@ def bench_eval(a, torch, dist, dev, rank, world, lib):
                      "ts": torch.tensor((np.sort(rng.random(N)) + k).astype(np.float32), device=dev),
                      "ps": torch.tensor(rng.integers(0, 2, N).astype(np.float32), device=dev)})
 
+    # two streams (models/engine.py): the decoder half of pass t and the validation update behind it run on a side stream
+    # beside the loader stage and the encoders of pass t + 1; TEF_TWO_STREAMS=0: everything on one stream
+    side = torch.cuda.Stream(device=dev) if os.environ.get("TEF_TWO_STREAMS", "1") != "0" else None
+    eng = model.arch.engine
+    model.arch.flow_scale = float(cfg["loss"]["flow_scaling"])      # (eval_flow.py's multiply rides on the last kernel)
+
     def window():
         model.reset_states()
         crit.reset()
         with torch.no_grad():
             for r in raws:
                 b = collate_raw_events(r["xs"], r["ys"], r["ts"], r["ps"], [0, N], (H, W))
-                x = model(b["net_input"])
-                flows = [f * cfg["loss"]["flow_scaling"] for f in x["flow"]]
-                crit.update(flows, b["event_list"], b["event_list_pol_mask"], b["event_mask"])
+                if side is None:
+                    crit.update(model(b["net_input"])["flow"], b["event_list"], b["event_list_pol_mask"], b["event_mask"])
+                    continue
+                eng.side_stream, eng.defer_join = side, True
+                try:
+                    flows = model(b["net_input"])["flow"]
+                finally:
+                    eng.defer_join = False
+                for k in ("event_list", "event_list_pol_mask", "event_mask"):
+                    b[k].record_stream(side)
+                with torch.cuda.stream(side):
+                    crit.update(flows, b["event_list"], b["event_list_pol_mask"], b["event_mask"])
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
             return crit.fwl(), crit.rsat()
 
     def barrier():

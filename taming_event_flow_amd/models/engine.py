@@ -389,10 +389,17 @@ def run_pass(engine, x, states):
     params = [p for p in engine.arch.parameters()]
     needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params) or
                                          any(s is not None and s.requires_grad for s in states))
-    if not needs:
-        flows, new_states, _ = engine.forward(x, list(states), keep=False)
-        return flows, new_states
     side = engine.side_stream
+    if not needs:
+        if side is None or not engine.defer_join:       # (without gradients the split only pays when the caller overlaps)
+            flows, new_states, _ = engine.forward(x, list(states), keep=False)
+            return flows, new_states
+        _, new_states, rec = engine.forward(x, list(states), keep=False, part=1)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            rec.tape.record_stream(side)
+            flows, _, _ = engine.forward(None, None, keep=False, part=2, rec=rec)
+        return flows, new_states
     if side is not None and engine.arch.direct_grads and all(p.grad is not None and p.grad.is_contiguous()
                                                              for p in params if p.requires_grad):
         holder = []
