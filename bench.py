@@ -177,13 +177,25 @@ def init_ranks(a):
     return torch, dist, dev, rank, world
 
 
+def watchdog():
+    """(Re-)arm the progress watchdog.  A rank that stops making progress (a wedged collective, a deadlocked stream) must
+    not sit in a metered lease: TEF_BENCH_WATCHDOG_S seconds (default 600) after the last call every thread's stack goes to
+    stderr and the process exits non-zero, which takes the launcher and the other ranks down with it.  Called at the phase
+    boundaries of a run (rendezvous, staging, warm-up, timed region, extras)."""
+    import faulthandler
+
+    faulthandler.dump_traceback_later(float(os.environ.get("TEF_BENCH_WATCHDOG_S", "600")), exit=True)
+
+
 def main():
     a = parse()
     if a.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(a))
+    watchdog()
     torch, dist, dev, rank, world = init_ranks(a)
+    watchdog()
 
     import __graft_entry__ as ge
 
@@ -254,6 +266,7 @@ def main():
         return loss, grads
 
     def barrier():
+        watchdog()           # a phase boundary: re-arm
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -610,6 +623,7 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
             window = captured
 
     def barrier():
+        watchdog()           # a phase boundary: re-arm
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -631,12 +645,13 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
     kern = {}
     if not a.no_kernel_events:
         lib.tef_profile_enable(1)
-        if a.graph:          # a graph replay carries no per-launch events: one eager window on the same static inputs
-            for b in window.inputs:
-                tr.step({k: v.clone() for k, v in b.items()}, new_seq=False)
-        else:
-            window()
-        torch.cuda.synchronize()
+        with one_stream(tr):     # (a kernel's events measure its own duration only when nothing runs beside it)
+            if a.graph:          # a graph replay carries no per-launch events: one eager window on the same static inputs
+                for b in window.inputs:
+                    tr.step({k: v.clone() for k, v in b.items()}, new_seq=False)
+            else:
+                window()
+            torch.cuda.synchronize()
         lib.tef_profile_collect()
         for s in range(lib.tef_profile_slots()):
             n = lib.tef_profile_calls(s)
@@ -658,7 +673,10 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
             ach = flops / (tot_ms * 1e-3) / 1e12
             roofline = {"kernel": "conv gemm_nt (fwd+dgrad+wgrad)", "bound": "mfma", "achieved": round(ach, 2),
                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
-                        "traffic": None, "gemm_ms_per_window": {k: round(v, 3) for k, v in gemm_ms.items()}}
+                        "traffic": None, "gemm_ms_per_window": {k: round(v, 3) for k, v in gemm_ms.items()},
+                        "note": "kernel durations from one profiled window on ONE stream; the timed windows run the "
+                                "Trainer's two streams" if tr.dec_stream is not None else "one stream",
+                        "window_achieved": round(flops / (1e-3 * 1e3 * elapsed / a.steps) / 1e12, 2)}
         out = {
             "metric": "events/sec through the full training window (RecEVFlowNet + IWE/contrast-max loss), 128x128 bs=8",
             "value": round(ev_step * a.steps * world / elapsed, 1), "unit": "events/s", "n_gpus": world,
@@ -668,7 +686,8 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
                                    f"loss + BPTT backward + all-reduce(SUM) + clip + Adam, {a.res[0]}x{a.res[1]}, "
                                    f"B={a.batch}/GPU, N={a.events}+{a.detached} (BASELINE.json configs[2]/[3])",
                        "global_batch": a.batch * world, "parallelism": f"dp{world} (RCCL all-reduce SUM of 125.5 MB grads)",
-                       "launch": "hipGraph replay of the whole window" if a.graph else "eager"},
+                       "launch": "hipGraph replay of the whole window" if a.graph else "eager",
+                       "streams": 2 if tr.dec_stream is not None else 1},
             "loss": round(float(tr.last_loss.item()), 6),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 3),
             "conv_gflop_per_pass_fwd": round(fl_pass / 1e9, 2),
@@ -738,6 +757,7 @@ def bench_eval(a, torch, dist, dev, rank, world, lib):
             return crit.fwl(), crit.rsat()
 
     def barrier():
+        watchdog()           # a phase boundary: re-arm
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -771,6 +791,28 @@ def bench_eval(a, torch, dist, dev, rank, world, lib):
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def one_stream(tr):
+    """Context: the Trainer's passes on ONE stream (per-kernel HIP events only measure a kernel's own duration when nothing
+    runs beside it; the timed windows use the Trainer's two streams)."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def ctx():
+        eng = getattr(getattr(tr.model, "arch", None), "engine", None)
+        saved = (tr.dec_stream, eng.side_stream if eng is not None else None)
+        tr.dec_stream = None
+        if eng is not None:
+            eng.side_stream = None
+        try:
+            yield
+        finally:
+            tr.dec_stream = saved[0]
+            if eng is not None:
+                eng.side_stream = saved[1]
+
+    return ctx()
 
 
 def train_extra(a, torch, dev):
@@ -816,22 +858,29 @@ def train_extra(a, torch, dev):
         eager_ms = 1e3 * (time.perf_counter() - t0) / 3
         # the conv kernels' own time needs per-launch events, which a graph replay does not carry: one more eager window
         lib.tef_profile_enable(1)
-        eager_window()
-        torch.cuda.synchronize()
+        with one_stream(tr):
+            eager_window()
+            torch.cuda.synchronize()
         lib.tef_profile_collect()
         conv_ms = sum(lib.tef_profile_ms(s_) for s_ in range(lib.tef_profile_slots())
                       if lib.tef_profile_name(s_).decode().startswith("conv_"))
         lib.tef_profile_enable(0)
         flops = 3 * conv_flops_per_pass(a.batch, a.res[0], a.res[1]) * a.passes
         ev = a.batch * a.passes * (a.events + a.detached)
+        tr_streams = tr.dec_stream is not None
         del tr, window
         torch.cuda.empty_cache()
         return {"workload": "training window as one hipGraph (bench.py --mode train --graph): RecEVFlowNet fwd + loss + BPTT "
                             "+ clip + Adam, BASELINE configs[2]",
                 "train_window_ms": round(ms, 3), "train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": n,
                 "train_window_eager_ms": round(eager_ms, 3), "train_window_eager_host_enqueue_ms": round(1e3 * t_host / 3, 3),
+                # the kernels' own durations: HIP events around every convolution launch of one window run on ONE stream
                 "conv_ms_per_window_eager": round(conv_ms, 3), "conv_tflops": round(flops / (conv_ms * 1e-3) / 1e12, 2),
-                "conv_frac_of_fp32_mfma_peak": round(flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+                "conv_frac_of_fp32_mfma_peak": round(flops / (conv_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                # the same flops over the WHOLE window (two streams, every other launch included)
+                "window_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                "window_frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "streams": 2 if tr_streams else 1}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
 

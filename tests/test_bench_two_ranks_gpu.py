@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(args):
-    env = dict(os.environ, TEF_BENCH_BACKEND="gloo", TEF_BENCH_SHARE_GPU="1")
+    # (a wedged rank dumps its stacks and exits after 300 s without progress: the failure below then shows where)
+    env = dict(os.environ, TEF_BENCH_BACKEND="gloo", TEF_BENCH_SHARE_GPU="1", TEF_BENCH_WATCHDOG_S="300")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env,

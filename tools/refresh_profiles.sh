@@ -14,8 +14,9 @@ timeout 300 python bench.py --mode train --steps 5 --warmup 2 > $O/${R}_train_be
 timeout 300 python bench.py --mode train --graph --steps 10 --warmup 2 > $O/${R}_train_bench_graph.json 2> $O/train_graph.err
 timeout 300 python bench.py --mode eval --steps 5 --warmup 2 > $O/${R}_eval_bench.json 2> $O/eval.err
 timeout 300 python tools/conv_bench.py > $O/${R}_conv_bench.txt 2>/dev/null
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_train_bench_under_rocprof.json 2> $O/train_prof.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eval_stats -- python3 bench.py --mode eval --steps 3 --warmup 1 > $O/${R}_eval_bench_under_rocprof.json 2> $O/eval_prof.err
+# (kernel durations are a kernel's own only when nothing runs beside it: the profiled training run keeps to ONE stream)
+TEF_TWO_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python3 bench.py --mode train --steps 3 --warmup 1 --no-cpu-baseline > $O/${R}_train_bench_under_rocprof.json 2> $O/train_prof.err
+TEF_TWO_STREAMS=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eval_stats -- python3 bench.py --mode eval --steps 3 --warmup 1 > $O/${R}_eval_bench_under_rocprof.json 2> $O/eval_prof.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/loss_stats -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-train-extra > $O/${R}_loss_bench_under_rocprof.json 2> $O/loss_prof.err
 # HBM traffic: one counter per pass (MI355X_MICROARCH.md, HBM section)
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train-extra --no-kernel-events > /dev/null 2> $O/pmc_fetch.err
