@@ -24,7 +24,7 @@ def _digest_errors(params_grad_flat, params, gnorm, ghead):
         e_own = max(e_own, abs(n - gnorm[i]) / max(gnorm[i], 1e-12))
         h = np.zeros(32)
         h[: min(32, g.size)] = g[:32]
-        e_head = max(e_head, np.abs(h - ghead[i]).max() / max(np.abs(ghead[i]).max(), 1e-3 * gnorm[i]))
+        e_head = max(e_head, np.abs(h - ghead[i]).max() / max(np.abs(ghead[i]).max(), 1e-3 * gnorm[i], 1e-30))
     return e_glob, e_own, e_head
 
 
