@@ -801,16 +801,16 @@ def one_stream(tr):
     @contextlib.contextmanager
     def ctx():
         eng = getattr(getattr(tr.model, "arch", None), "engine", None)
-        saved = (tr.dec_stream, eng.side_stream if eng is not None else None)
+        saved = (tr.dec_stream, eng.side_stream if eng is not None else None, eng.wgrad_stream if eng is not None else None)
         tr.dec_stream = None
         if eng is not None:
-            eng.side_stream = None
+            eng.side_stream = eng.wgrad_stream = None
         try:
             yield
         finally:
             tr.dec_stream = saved[0]
             if eng is not None:
-                eng.side_stream = saved[1]
+                eng.side_stream, eng.wgrad_stream = saved[1], saved[2]
 
     return ctx()
 

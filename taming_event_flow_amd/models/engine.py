@@ -60,7 +60,12 @@ class PassEngine:
         self._ws = {}                 # one workspace per stream the engine launches on
         self.side_stream = None       # set: passes that record a graph run as two nodes on two streams (module docstring)
         self.defer_join = False       # with side_stream: leave the flows on the side stream (the caller joins)
-        self.debug_delay = None       # tests: (cycles, cycles) of spinning put in front of the (encoder, decoder) halves
+        self.debug_delay = None       # tests: cycles of spinning put in front of the (encoder halves, decoder halves[, weight-gradient groups])
+        # two-stream windows: the deferred weight gradients of every `wgrad_group` finished backward passes are reduced on
+        # `wgrad_stream` while BPTT goes on (the encoder chain leaves the side stream idle about half of the time and
+        # a long reduction fills it better than its turn at the end, alone); None / 0: one reduction per layer over the
+        # whole window at the flush
+        self.wgrad_stream, self.wgrad_group = None, 0
         self._zeros = {}
         self._layout = {}
         self._pending = []            # backward calls of the current window whose weight gradients are still deferred
@@ -298,16 +303,36 @@ class PassEngine:
             self._pending.append(rec)       # (keeps the arenas alive until the flush)
             rec.queued = True
             sm._DEFERRED_ENGINES.add(self)
+        if rec.queued and part == 1 and self.wgrad_stream is not None and self.wgrad_group:
+            # (backward walks the passes last to first and a pass's encoder half is its last piece: when this record is
+            # the newest one queued, every queued pass is complete)
+            done = self._pending.index(rec) + 1
+            if done >= self.wgrad_group and done == len(self._pending):
+                self.flush_window(self.wgrad_stream)
         grads = [None] * len(params) if direct else [fresh.get(id(p)) for p in params]
         return dh, dx, grads
 
-    def flush_window(self):
+    def flush_window(self, stream=None):
         """The deferred weight gradients of every backward call since the last flush: one reduction per layer over all
-        passes (tef_net_window_wgrads)."""
+        passes (tef_net_window_wgrads) — on the current stream, or on `stream` once it has caught up with the current
+        one (the caller makes its stream wait for `stream` before the gradients are read)."""
         pend, self._pending = self._pending, []
         sm._DEFERRED_ENGINES.discard(self)
         if not pend:
             return
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                if self.debug_delay and len(self.debug_delay) > 2 and self.debug_delay[2]:
+                    torch.cuda._sleep(int(self.debug_delay[2]))
+                for r in pend:          # the arenas are released right after this call: not before `stream` has read them
+                    for t in [r.tape, r.gtape, r.xp] + list(r.states_in):
+                        t.record_stream(stream)
+                self._launch_wgrads(pend)
+            return
+        self._launch_wgrads(pend)
+
+    def _launch_wgrads(self, pend):
         npass = len(pend)
         xs = (ctypes.c_void_p * npass)(*[r.xp.data_ptr() for r in pend])
         sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p)) for r in pend])

@@ -134,11 +134,17 @@ class Trainer:
         # Two streams per window (models/engine.py): the decoder half of pass t, and the loss container's update() behind
         # it, run on a side stream beside the encoders of pass t + 1; BPTT mirrors it through autograd's own stream
         # handling.  TEF_TWO_STREAMS=0 keeps every launch on one stream.
-        self.dec_stream = None
+        self.dec_stream = self.wgrad_stream = None
         eng = getattr(getattr(self.model, "arch", None), "engine", None)
         if eng is not None and torch.device(device).type == "cuda" and os.environ.get("TEF_TWO_STREAMS", "1") != "0":
             self.dec_stream = torch.cuda.Stream(device=device)
             eng.side_stream = self.dec_stream
+            # ... and a third one for the deferred weight gradients: every TEF_WGRAD_GROUP (default 3) finished backward
+            # passes are reduced beside the rest of BPTT instead of all of them after it (0: after it)
+            group = int(os.environ.get("TEF_WGRAD_GROUP", "3"))
+            if self.deferred_wgrad and group > 0:
+                self.wgrad_stream = torch.cuda.Stream(device=device)
+                eng.wgrad_stream, eng.wgrad_group = self.wgrad_stream, group
 
     def reset(self):
         """train_flow.py:83-87"""
@@ -263,6 +269,8 @@ class Trainer:
         loss.backward()
         if self.deferred_wgrad:
             submodules.flush_deferred_wgrads()
+            if self.wgrad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
         self.last_loss = loss.detach()
 
     def _apply_update(self):

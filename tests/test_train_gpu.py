@@ -221,7 +221,7 @@ def _trace_run(two_streams, delay):
             del os.environ["TEF_TWO_STREAMS"]
         else:
             os.environ["TEF_TWO_STREAMS"] = old
-    assert (tr.dec_stream is not None) == two_streams
+    assert (tr.dec_stream is not None) == two_streams and (tr.wgrad_stream is not None) == two_streams
     tr.model.arch.engine.debug_delay = delay
     sd = tr.model.state_dict()
     w = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], int(z["seed"]))
@@ -242,16 +242,17 @@ def _trace_run(two_streams, delay):
 
 
 def test_two_stream_window_has_no_race():
-    """The two-stream window (models/engine.py: encoders of pass t + 1 beside the decoders of pass t, autograd mirroring it
-    in BPTT) against the same window on one stream, with either stream held back by a spinning kernel in front of every
-    half pass: a missing dependency or a buffer released under a lagging stream shows as a different loss / gradient."""
+    """The multi-stream window (models/engine.py: encoders of pass t + 1 beside the decoders of pass t, autograd mirroring
+    it in BPTT, groups of deferred weight gradients on a third stream) against the same window on one stream, with one of
+    the streams held back by a spinning kernel in front of every piece of its work: a missing dependency or a buffer
+    released under a lagging stream shows as a different loss / gradient."""
     assert torch.cuda.is_available()
     import __graft_entry__ as g
 
     g.build()
     ref = _trace_run(False, None)
     spin = 30_000_000                  # ~12 ms per half pass
-    for delay in (None, (0, spin), (spin, 0)):
+    for delay in (None, (0, spin, 0), (spin, 0, 0), (0, 0, 4 * spin)):
         got = _trace_run(True, delay)
         err = np.abs(got - ref) / np.abs(ref)
         # (the second window's gradient norm moves by ~5e-5 between two IDENTICAL one-stream runs: float atomics in the
