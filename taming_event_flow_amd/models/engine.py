@@ -96,31 +96,39 @@ class PassEngine:
         bias = packer.bias(biases)
         nc.wp, nc.w2, nc.bias = wp.data_ptr(), wt.data_ptr(), _p(bias)
 
-    def make_plan(self, B, Hp, Wp, ph, pw):
+    def make_plan(self, B, Hp, Wp, ph, pw, part=3, pl=None):
         """struct tef_net_plan for a (padded) input of B x bins x Hp x Wp: geometry + the packed weights / biases of
-        every convolution (re-packed by PackedWeights only when a parameter changed)."""
+        every convolution (re-packed by PackedWeights only when a parameter changed).  part 1: geometry and the encoders'
+        layers only; part 2 completes the plan `pl` with the residual blocks, decoders and heads — on the stream of the
+        caller, so that after an optimiser step the decoder half's weights are re-packed beside the first encoders
+        instead of in front of them."""
         a, np_ = self.arch, self.plan
-        pl = _lib.NetPlan()
-        pl.B, pl.H, pl.W = B, Hp, Wp
-        pl.bins, pl.levels, pl.nres, pl.nout = np_.num_bins, np_.levels, np_.nres, np_.nout
-        pl.final_act = ACT[np_.final_activation]
-        pl.crop_top, pl.crop_left, pl.flow_scale = ph, pw, float(a.flow_scale)
         dec_rows = np_.of("dec")
-        for i, c in enumerate(np_.width):
-            pl.width[i] = c
-            pl.dec_out[i] = dec_rows[i].cout
+        if part & 1:
+            pl = _lib.NetPlan()
+            pl.B, pl.H, pl.W = B, Hp, Wp
+            pl.bins, pl.levels, pl.nres, pl.nout = np_.num_bins, np_.levels, np_.nres, np_.nout
+            pl.final_act = ACT[np_.final_activation]
+            pl.crop_top, pl.crop_left, pl.flow_scale = ph, pw, float(a.flow_scale)
+            for i, c in enumerate(np_.width):
+                pl.width[i] = c
+                pl.dec_out[i] = dec_rows[i].cout
         cin, h, w = np_.num_bins, Hp, Wp
         for i, enc in enumerate(a.encoders):
             c = np_.width[i]
-            self._conv_fields(pl.head[i], enc.conv._packed, (enc.conv.conv2d.weight,), (enc.conv.conv2d.bias,),
-                              _lib.ConvDesc(B, cin, 0, h, w, c, 3, np_.stride, ACT["relu"]))
+            if part & 1:
+                self._conv_fields(pl.head[i], enc.conv._packed, (enc.conv.conv2d.weight,), (enc.conv.conv2d.bias,),
+                                  _lib.ConvDesc(B, cin, 0, h, w, c, 3, np_.stride, ACT["relu"]))
             h, w = h // 2, w // 2
             g = enc.recurrent_block
-            self._conv_fields(pl.gate_ur[i], g._packed_ur, (g.update_gate.weight, g.reset_gate.weight),
-                              (g.update_gate.bias, g.reset_gate.bias), _lib.ConvDesc(B, c, c, h, w, 2 * c, 3, 1, ACT["sigmoid"]))
-            self._conv_fields(pl.gate_o[i], g._packed_o, (g.out_gate.weight,), (g.out_gate.bias,),
-                              _lib.ConvDesc(B, c, c, h, w, c, 3, 1, ACT["tanh"]))
+            if part & 1:
+                self._conv_fields(pl.gate_ur[i], g._packed_ur, (g.update_gate.weight, g.reset_gate.weight),
+                                  (g.update_gate.bias, g.reset_gate.bias), _lib.ConvDesc(B, c, c, h, w, 2 * c, 3, 1, ACT["sigmoid"]))
+                self._conv_fields(pl.gate_o[i], g._packed_o, (g.out_gate.weight,), (g.out_gate.bias,),
+                                  _lib.ConvDesc(B, c, c, h, w, c, 3, 1, ACT["tanh"]))
             cin = c
+        if not (part & 2):
+            return pl
         top = np_.width[-1]
         for j, rb in enumerate(a.resblocks):
             d = _lib.ConvDesc(B, top, 0, h, w, top, 3, 1, ACT["relu"])
@@ -197,7 +205,7 @@ class PassEngine:
                 xp[:, :, ph:, pw:] = x
             else:
                 xp = x
-            pl = self.make_plan(B, H + ph, W + pw, ph, pw)
+            pl = self.make_plan(B, H + ph, W + pw, ph, pw, part)
             ntape = self.layout(pl)[0]
             st, h, w = [], H + ph, W + pw
             for i in range(n):
@@ -218,6 +226,8 @@ class PassEngine:
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
             rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
         pl = rec.plan
+        if part == 2:
+            self.make_plan(pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left, 2, pl)
         _, _, wsb, fo, so, _, _ = self.layout(pl)
         B, H, W = rec.x_shape[0], rec.x_shape[2], rec.x_shape[3]
         ws = self.workspace(wsb, rec.tape.device)
