@@ -675,7 +675,7 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
                         "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4),
                         "traffic": None, "gemm_ms_per_window": {k: round(v, 3) for k, v in gemm_ms.items()},
                         "note": "kernel durations from one profiled window on ONE stream; the timed windows run the "
-                                "Trainer's two streams" if tr.dec_stream is not None else "one stream",
+                                "Trainer's streams" if tr.dec_stream is not None else "one stream",
                         "window_achieved": round(flops / (1e-3 * 1e3 * elapsed / a.steps) / 1e12, 2)}
         out = {
             "metric": "events/sec through the full training window (RecEVFlowNet + IWE/contrast-max loss), 128x128 bs=8",
@@ -687,7 +687,7 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
                                    f"B={a.batch}/GPU, N={a.events}+{a.detached} (BASELINE.json configs[2]/[3])",
                        "global_batch": a.batch * world, "parallelism": f"dp{world} (RCCL all-reduce SUM of 125.5 MB grads)",
                        "launch": "hipGraph replay of the whole window" if a.graph else "eager",
-                       "streams": 2 if tr.dec_stream is not None else 1},
+                       "streams": 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)},
             "loss": round(float(tr.last_loss.item()), 6),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 3),
             "conv_gflop_per_pass_fwd": round(fl_pass / 1e9, 2),
@@ -867,7 +867,7 @@ def train_extra(a, torch, dev):
         lib.tef_profile_enable(0)
         flops = 3 * conv_flops_per_pass(a.batch, a.res[0], a.res[1]) * a.passes
         ev = a.batch * a.passes * (a.events + a.detached)
-        tr_streams = tr.dec_stream is not None
+        tr_streams = 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)
         del tr, window
         torch.cuda.empty_cache()
         return {"workload": "training window as one hipGraph (bench.py --mode train --graph): RecEVFlowNet fwd + loss + BPTT "
@@ -880,7 +880,7 @@ def train_extra(a, torch, dev):
                 # the same flops over the WHOLE window (two streams, every other launch included)
                 "window_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                 "window_frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                "streams": 2 if tr_streams else 1}
+                "streams": tr_streams}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
 
