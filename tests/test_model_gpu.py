@@ -172,6 +172,49 @@ def test_fused_pass_matches_layer_by_layer(dev):
 
 
 @pytest.mark.parametrize("nres", [2, 0])
+def test_two_node_pass_matches_fused(dev, nres):
+    """The pass as two autograd nodes on two streams (models/engine.py `_EncFn` / `_DecFn` on `tef_net_pass_*_part`; what
+    train.Trainer runs) against the one-node pass: three recurrent passes, a head of each pass without gradient, the
+    input's gradient wanted; flows and states bit-identical, gradients to fp32 summation order (the decoder half hands
+    autograd one tensor per level instead of adding in the cell kernel).  With and without residual blocks (without, the
+    deepest state enters decoder 0 twice)."""
+    from taming_event_flow_amd import parallel
+    from taming_event_flow_amd.models import submodules
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    rng = np.random.default_rng(23 + nres)
+    xs_np = [rng.poisson(0.4, (2, 2, 32, 48)).astype(np.float32) for _ in range(3)]
+    rs = [[torch.tensor(rng.standard_normal((2, 2, 32, 48)).astype(np.float32), device=dev) for _ in range(4)] for _ in range(3)]
+
+    def run(two):
+        net = load_weights(RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01, "num_residual_blocks": nres}, 2), 9, dev)
+        net.train()
+        bucket = parallel.FlatGradBucket(net.parameters())         # in-place parameter gradients (what the split needs)
+        submodules.enable_direct_grads(net)
+        net.arch.engine.side_stream = torch.cuda.Stream() if two else None
+        xs = [torch.tensor(x, device=dev, requires_grad=True) for x in xs_np]
+        loss, flows_all = 0, []
+        for t in range(3):
+            flows = net(xs[t])["flow"]                               # (joined: defer_join is off)
+            flows_all.append([f.detach().clone() for f in flows])
+            loss = loss + sum((f * r).sum() for f, r in zip(flows[1:], rs[t][1:]))
+        loss.backward()
+        torch.cuda.synchronize()
+        return flows_all, [s.detach().clone() for s in net.arch.states], bucket.flat.clone(), [x.grad.clone() for x in xs]
+
+    fa, sa, ga, xa = run(True)
+    fb, sb, gb, xb = run(False)
+    for t in range(3):
+        for i in range(4):
+            assert torch.equal(fa[t][i], fb[t][i]), (t, i)
+    for a, b in zip(sa, sb):
+        assert torch.equal(a, b)
+    assert rel_err(ga.cpu().numpy(), gb.cpu().numpy()) <= 2e-5
+    for a, b in zip(xa, xb):
+        assert float(b.abs().max()) > 0 and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+
+
+@pytest.mark.parametrize("nres", [2, 0])
 def test_input_gradient_and_no_residual_blocks(dev, nres):
     """d loss / d network input through the fused pass (the reference's autograd delivers it, models/arch.py:217-227;
     round 2 returned None silently) against the layer-by-layer path, and the architecture without residual blocks, where
