@@ -303,11 +303,20 @@ def main():
                     step(k)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            # One capture stream for every graph, and the rest of this run on that stream: the flow maps are LEAF tensors
+            # here, their AccumulateGrad nodes are created while a step is captured — on the capture stream — and the
+            # captured outputs keep them alive.  An eager step on any OTHER stream then makes autograd order the two
+            # streams for each of the 40 gradients (41 event records per step from the autograd thread, ~10 us of command
+            # processor time each: a kernel trace shows a 430 us hole behind every eager step, 1.12 ms instead of 0.66).
+            # In a training loop the flows are network outputs, not leaves.
+            cap_stream = torch.cuda.Stream()
             for k in range(len(staged)):
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph):
+                with torch.cuda.graph(gph, stream=cap_stream):
                     out = step(k)
                 graphs.append((gph, out))
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            torch.cuda.set_stream(cap_stream)
         except Exception as e:                                    # noqa: BLE001
             print(f"[bench] step graph capture failed ({e!r}); running every step eagerly", file=sys.stderr)
             graphs = []
@@ -350,7 +359,7 @@ def main():
         try:
             for k in range(len(staged)):
                 gph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gph):
+                with torch.cuda.graph(gph, stream=cap_stream):
                     for j in range(G):
                         out = step(k + j)
                 groups.append((gph, out))
@@ -375,10 +384,17 @@ def main():
     # SURVEY.md section 8d asks for the median over >= 20 steps beside the wall-clock mean that `value` is made of
     # (a short run still profiles at least three steps, so the per-kernel times — and the roofline fractions made of them —
     # are means over several launches, never one sample)
-    event_every = max(1, min(a.event_every, (a.steps + 2) // 3))
+    event_every = max(1, min(a.event_every, a.steps // 3))
+    nprof = 0 if a.no_kernel_events else max(1, min(a.steps, a.steps // event_every))
 
     def is_profiled(k):
-        return not a.no_kernel_events and k % event_every == 0
+        # The profiled steps are the LAST `nprof` steps of the timed region, one after the other.  They are launched eagerly
+        # (a graph replay carries no per-launch events), and a kernel trace of a 20-step run shows what that costs: ~70 us of
+        # small gaps inside an eager step, nothing when a graph follows a graph — and a 425 us idle gap whenever a graph
+        # launch follows eager launches.  Spread over the region (steps 5 / 11 / 17) that was three such gaps, 0.73 ms per
+        # step instead of 0.66; at the end of the region no graph follows them.  (Their host time, ~0.8 ms each, hides behind
+        # the graph replays queued before them.)
+        return k >= a.steps - nprof
 
     # the timed region as a list of units: (first step, number of steps, how it is launched)
     units, k = [], 0
@@ -404,7 +420,7 @@ def main():
     dbg = [] if os.environ.get("TEF_BENCH_DEBUG") == "1" else None
     for u, (k, n, how) in enumerate(units):
         if dbg is not None:
-            dbg.append((how, time.perf_counter()))
+            dbg.append((how + (" idle" if torch.cuda.current_stream().query() else ""), time.perf_counter()))
         if not a.no_kernel_events:
             lib.tef_profile_pause(0 if how == "eager" and is_profiled(k) else 1)
         if dbg is not None and how == "eager":
@@ -424,13 +440,21 @@ def main():
             if dbg is not None and os.environ.get("TEF_BENCH_DEBUG_SPLIT") == "1":
                 tz = time.perf_counter()
                 na = torch.cuda.memory_stats()["num_device_alloc"]
+                seg0 = {(s_["address"], s_["total_size"]) for s_ in torch.cuda.memory_snapshot()}
                 ta = time.perf_counter()
                 print("[bench] memory_stats %.3f ms" % (1e3 * (ta - tz)), file=sys.stderr)
                 L_, fl_ = staged[k % len(staged)]
+                q0 = torch.cuda.current_stream().query()
                 loss_ = L_()
+                q1 = torch.cuda.current_stream().query()
                 tb = time.perf_counter()
                 last, last_grads = loss_, torch.autograd.grad(loss_, [f for row in fl_ for f in row])
                 tc = time.perf_counter()
+                print("[bench] stream idle before forward / after forward / after backward:", q0, q1, torch.cuda.current_stream().query(),
+                      file=sys.stderr)
+                seg1 = {(s_["address"], s_["total_size"]) for s_ in torch.cuda.memory_snapshot()}
+                print("[bench] new segments:", sorted(sz for _, sz in seg1 - seg0), "released:", sorted(sz for _, sz in seg0 - seg1),
+                      file=sys.stderr)
                 print("[bench] eager unit %d: forward %.2f ms, backward %.2f ms, device allocations %d" % (
                     u, 1e3 * (tb - ta), 1e3 * (tc - tb), torch.cuda.memory_stats()["num_device_alloc"] - na), file=sys.stderr)
             else:
@@ -446,6 +470,11 @@ def main():
               file=sys.stderr)
     barrier()
     elapsed = time.perf_counter() - t0
+    if dbg is not None:
+        print("[bench] device ms per unit:", [(how, n, round(e0.elapsed_time(e1), 3)) for (k, n, how), (e0, e1) in zip(units, unit_events)],
+              file=sys.stderr)
+        print("[bench] gaps between units (device ms):", [round(unit_events[i][1].elapsed_time(unit_events[i + 1][0]), 3)
+                                                          for i in range(len(units) - 1)], file=sys.stderr)
     step_ms = sorted(ms for (k, n, how), (e0, e1) in zip(units, unit_events) for ms in [e0.elapsed_time(e1) / n] * n)
     step_ms_median = step_ms[len(step_ms) // 2]
     lib.tef_profile_collect()
@@ -477,7 +506,7 @@ def main():
         alg, splats = algorithmic_bytes(a, delta)
         kernels = {}
         for name, (ms, n) in kern.items():
-            e = {"ms": round(ms, 5), "calls_per_step": round(n / a.steps, 3)}
+            e = {"ms": round(ms, 5), "calls_per_step": round(n / a.steps, 3), "samples": n}
             if name in alg and a.warping == "Iterative":
                 e["algorithmic_bytes"] = alg[name]
                 e["GBps"] = round(alg[name] / (ms * 1e-3) / 1e9, 1)
@@ -501,7 +530,7 @@ def main():
                        "parallelism": f"dp{world} (batch-sharded, no data-path collective)",
                        "launch": (("hipGraph replay, %d consecutive steps per graph" % G if groups else
                                    "hipGraph replay of the step") +
-                                  ("; every %d-th step eager with per-kernel HIP events" % event_every
+                                  ("; the last %d steps eager with per-kernel HIP events" % nprof
                                    if not a.no_kernel_events else "")) if graphs else "eager"},
             "loss": round(loss_val, 6),
             "ms_per_step_hip_event_median": round(step_ms_median, 4),
@@ -515,7 +544,7 @@ def main():
             "launch_probe": probe,
             # the eager launch path (what a drop-in caller of the loss module runs: Python + ctypes + 7 launches per step)
             "eager_ms": eager_probe,
-            "kernel_events_every": None if a.no_kernel_events else event_every,
+            "kernel_event_steps": nprof,        # the last steps of the timed region, launched eagerly
             "roofline": roofline,
             "kernels": kernels,
         }
