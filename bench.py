@@ -572,7 +572,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
             out["cpu_baseline_1thread"] = cpu_baseline(a, host_windows[0], threads=1, seconds=min(a.cpu_seconds, 6.0), batch=2)
         if world == 1 and not a.no_train_extra and a.warping == "Iterative":
-            out["extra"] = train_extra(a, torch, dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(torch.cuda.default_stream(dev)):      # (where a training loop runs; not the capture stream above)
+                out["extra"] = train_extra(a, torch, dev)
         elif dp_extra is not None:
             out["extra"] = dp_extra
         print(json.dumps(out), flush=True)
