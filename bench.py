@@ -262,8 +262,10 @@ def main():
         # there the flows are network outputs, not leaves)
         L, flows = staged[k % len(staged)]
         loss = L()
-        grads = torch.autograd.grad(loss, [f for row in flows for f in row])
+        grads = torch.autograd.grad(loss, [f for row in flows for f in row], grad_outputs=one)      # (no ones_like launch per step)
         return loss, grads
+
+    one = torch.ones((), dtype=torch.float32, device=dev)
 
     def barrier():
         watchdog()           # a phase boundary: re-arm

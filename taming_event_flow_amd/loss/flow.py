@@ -115,7 +115,7 @@ class _CMLossFn(torch.autograd.Function):
     def forward(ctx, module, win, *flows):
         lib = _lib.lib()
         cfg = win.cfg
-        loss = torch.zeros((), dtype=torch.float32, device=win.flows.device)
+        loss = torch.empty((), dtype=torch.float32, device=win.flows.device)      # (written, not accumulated: no fill launch)
         g, d = win.grad.struct(), win.det.struct()
         rc = lib.tef_loss_forward(ctypes.byref(cfg), win.flows_yx.data_ptr(), ctypes.byref(g), ctypes.byref(d),
                                   win.workspace.data_ptr(), win.workspace.numel(), loss.data_ptr(), _lib.stream_ptr())
