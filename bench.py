@@ -501,7 +501,9 @@ def main():
     # the gradient all-reduce; the DP TRAINING window does, and every rank takes part in measuring it
     dp_extra = None
     if world > 1 and not a.no_train_extra and a.warping == "Iterative":
-        dp_extra = dp_train_extra(a, torch, dist, dev, rank, world)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.default_stream(dev)):      # (where a training loop runs; not the capture stream above)
+            dp_extra = dp_train_extra(a, torch, dist, dev, rank, world)
 
     if rank == 0:
         delta = a.passes // 2
