@@ -253,6 +253,10 @@ class PassEngine:
         part 2 (decoder half, two-stream passes; direct gradients only): the first result is what the half sends to each
         NEW state (one tensor or None per level); part 1 (encoder half): `dstates` are the total gradients of the new
         states."""
+        if rec is None:
+            raise RuntimeError("RecEVFlowNet pass: backward a second time through the same pass — its activation arena is "
+                               "released after the first backward (retain_graph=True is not supported by the fused pass; "
+                               "model.arch(x) runs the network through ordinary autograd nodes)")
         a, plan = self.arch, self.plan
         n = plan.levels
         pl = rec.plan
@@ -328,6 +332,8 @@ class PassEngine:
         one (the caller makes its stream wait for `stream` before the gradients are read)."""
         pend, self._pending = self._pending, []
         sm._DEFERRED_ENGINES.discard(self)
+        for r in pend:
+            r.queued = False
         if not pend:
             return
         if stream is not None:

@@ -214,6 +214,26 @@ def test_two_node_pass_matches_fused(dev, nres):
         assert float(b.abs().max()) > 0 and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.parametrize("two", [False, True])
+def test_backward_twice_is_refused(dev, two):
+    """The fused pass releases its activation arena after its backward (a BPTT window holds ten of them): a second
+    backward through the same pass (retain_graph=True) is refused with an explanation, not answered from freed memory."""
+    from taming_event_flow_amd import parallel
+    from taming_event_flow_amd.models import submodules
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    net = load_weights(RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2), 9, dev)
+    net.train()
+    parallel.FlatGradBucket(net.parameters())
+    submodules.enable_direct_grads(net)
+    net.arch.engine.side_stream = torch.cuda.Stream() if two else None
+    x = torch.rand(2, 2, 32, 32, device=dev)
+    loss = sum(f.sum() for f in net(x)["flow"])
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+
+
 @pytest.mark.parametrize("nres", [2, 0])
 def test_input_gradient_and_no_residual_blocks(dev, nres):
     """d loss / d network input through the fused pass (the reference's autograd delivers it, models/arch.py:217-227;
