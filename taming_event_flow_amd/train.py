@@ -103,7 +103,7 @@ class CapturedWindow:
 class Trainer:
     """model + loss + optimiser wired like reference train_flow.py:60-70, plus the DP gradient bucket."""
 
-    def __init__(self, config, device, model=None, loss_function=None):
+    def __init__(self, config, device, model=None, loss_function=None, streams=None):
         self.cfg, self.device = config, device
         num_bins = 2 if config["data"]["voxel"] is None else config["data"]["voxel"]
         if model is None:
@@ -136,7 +136,9 @@ class Trainer:
         # handling.  TEF_TWO_STREAMS=0 keeps every launch on one stream.
         self.dec_stream = self.wgrad_stream = None
         eng = getattr(getattr(self.model, "arch", None), "engine", None)
-        if eng is not None and torch.device(device).type == "cuda" and os.environ.get("TEF_TWO_STREAMS", "1") != "0":
+        if streams is None:      # (an explicit argument wins over the environment switch)
+            streams = os.environ.get("TEF_TWO_STREAMS", "1") != "0"
+        if eng is not None and torch.device(device).type == "cuda" and streams:
             self.dec_stream = torch.cuda.Stream(device=device)
             eng.side_stream = self.dec_stream
             # ... and a third one for the deferred weight gradients: every TEF_WGRAD_GROUP (default 3) finished backward

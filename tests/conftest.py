@@ -15,6 +15,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _collect_between_tests():
+    """Release what a test leaves behind (trainers with their streams and hipGraphs, autograd records holding device
+    arenas) right after it, with the device idle — not at whatever allocation the cycle collector wakes up on.  An
+    intermittent glibc abort ("corrupted size vs. prev_size", ~1 run in 10, in pytest's own session-finish code after every
+    test had passed) went away with this; it never showed outside pytest, where the same objects are released in order."""
+    yield
+    import gc
+
+    gc.collect()
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 def load_case(name):
     """Load a golden loss case -> (meta dict, window lists, loss, dflows)."""
     import json

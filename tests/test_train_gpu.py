@@ -1,5 +1,6 @@
 """GPU parity of the training-window semantics (reference train_flow.py:80-156) on the full HIP path:
 HIP encoder -> RecEVFlowNet (MFMA convs) -> Iterative loss (HIP) -> backward -> clip -> Adam, two windows."""
+import gc
 import os
 
 import numpy as np
@@ -212,15 +213,9 @@ def _trace_run(two_streams, delay):
         "optimizer": {"name": "Adam", "lr": float(z["lr"])},
         "loader": {"batch_size": B, "resolution": [H, W], "max_num_grad_events": None, "seed": 0},
     }
-    old = os.environ.get("TEF_TWO_STREAMS")
-    os.environ["TEF_TWO_STREAMS"] = "1" if two_streams else "0"
-    try:
-        tr = train.Trainer(cfg, dev)
-    finally:
-        if old is None:
-            del os.environ["TEF_TWO_STREAMS"]
-        else:
-            os.environ["TEF_TWO_STREAMS"] = old
+    # (the switch is a constructor argument here: changing os.environ under a process whose HIP runtime threads are alive
+    # is a setenv / getenv race)
+    tr = train.Trainer(cfg, dev, streams=two_streams)
     assert (tr.dec_stream is not None) == two_streams and (tr.wgrad_stream is not None) == two_streams
     tr.model.arch.engine.debug_delay = delay
     sd = tr.model.state_dict()
@@ -268,8 +263,7 @@ def test_multi_stream_window_matches_one_stream(warping, scales, smooth, graph):
     """train.Trainer's multi-stream window against TEF_TWO_STREAMS=0 on configurations the golden traces do not cover:
     the Linear loss (its update() samples the newest flow map — on the side stream), two temporal scales, the smoothing
     priors (they read the container's planar flow copies), ragged event counts with detached events, and the window as
-    a captured hipGraph.  Same weights, same synthetic passes, two windows (a third one's gradient norm is 40x larger and
-    moves by percents with the summation order of the first two updates: it measures conditioning, not streams)."""
+    a captured hipGraph.  Same weights, same synthetic passes, three windows chained through the recurrent state."""
     assert torch.cuda.is_available()
     import copy
 
@@ -286,42 +280,42 @@ def test_multi_stream_window_matches_one_stream(warping, scales, smooth, graph):
     if smooth:
         cfg["loss"].update(flow_spat_smooth_weight=0.001, flow_temp_smooth_weight=0.1)
     cfg["optimizer"]["capturable"] = graph
+    # lr = 0: the windows differ through the recurrent state only.  (With a learning rate, Adam's first steps move every
+    # weight by +-lr whatever its gradient's size; weights whose gradient is noise go either way with the summation order of
+    # the float atomics, and the next window's gradient norm lands on one of a few values several percent apart — in the
+    # one-stream run just as much, from one process to the next.)
+    cfg["optimizer"]["lr"] = 0.0
 
     def run(streams):
-        old = os.environ.get("TEF_TWO_STREAMS")
-        os.environ["TEF_TWO_STREAMS"] = "1" if streams else "0"
-        try:
-            torch.manual_seed(7)
-            tr = train.Trainer(cfg, dev)
-        finally:
-            if old is None:
-                del os.environ["TEF_TWO_STREAMS"]
-            else:
-                os.environ["TEF_TWO_STREAMS"] = old
+        torch.manual_seed(7)
+        tr = train.Trainer(cfg, dev, streams=streams)
         src = train.SyntheticSequences(cfg, dev, 2000, seq_len=10 ** 9, seed=3, jitter=300)
         tr.reset()
         out = []
         if graph:
             win = tr.capture_window([src.next() for _ in range(4)], warmup=1)
-            for _ in range(2):
+            for _ in range(3):
                 for b in win.inputs:
                     for k, v in src.next().items():
                         b[k].copy_(v)
                 win()
                 out += [float(tr.last_loss.item()), float(tr.last_grad_norm.item())]
         else:
-            for _ in range(2):
+            for _ in range(3):
                 for _ in range(4):
                     tr.step(src.next(), new_seq=False)
                 out += [float(tr.last_loss.item()), float(tr.last_grad_norm.item())]
+        # release the trainer (streams, hipGraphs, arenas, autograd records) HERE, with the device idle, not whenever the
+        # cycle collector happens to run
+        if graph:
+            del win
+        del tr, src
+        gc.collect()
+        torch.cuda.synchronize()
         return np.array(out)
 
     one, multi = run(False), run(True)
     err = np.abs(multi - one) / np.abs(one)
     print("relative differences (loss, gradient norm per window):", err)
-    # (window 0 sees identical weights; later windows see weights that went through Adam steps on gradients which differ
-    # in summation order — float atomics, and the decoder half's state gradients added by autograd instead of in the cell
-    # kernel)
-    first = 1 if graph else 0           # (capture_window runs one whole eager window, optimiser step included, before capturing)
-    tol_loss, tol_norm = [1e-6, 3e-5, 2e-4][first:first + 2], [1e-4, 3e-3, 3e-2][first:first + 2]
+    tol_loss, tol_norm = 1e-6, 1e-5
     assert np.isfinite(multi).all() and (err[0::2] <= tol_loss).all() and (err[1::2] <= tol_norm).all(), (one, multi)
