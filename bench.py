@@ -177,6 +177,17 @@ def init_ranks(a):
     return torch, dist, dev, rank, world
 
 
+def release_now(torch):
+    """Collect what a finished phase left behind (trainers with their streams and hipGraphs, autograd records holding device
+    arenas) with the device idle, instead of at whatever allocation wakes the cycle collector (tests/conftest.py tells why)."""
+    import gc
+
+    torch.cuda.synchronize()
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+
 def watchdog():
     """(Re-)arm the progress watchdog.  A rank that stops making progress (a wedged collective, a deadlocked stream) must
     not sit in a metered lease: TEF_BENCH_WATCHDOG_S seconds (default 600) after the last call every thread's stack goes to
@@ -904,7 +915,7 @@ def train_extra(a, torch, dev):
         ev = a.batch * a.passes * (a.events + a.detached)
         tr_streams = 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)
         del tr, window
-        torch.cuda.empty_cache()
+        release_now(torch)
         return {"workload": "training window as one hipGraph (bench.py --mode train --graph): RecEVFlowNet fwd + loss + BPTT "
                             "+ clip + Adam, BASELINE configs[2]",
                 "train_window_ms": round(ms, 3), "train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": n,
@@ -998,7 +1009,7 @@ def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
     except Exception as e:                                    # noqa: BLE001
         out["error"] = repr(e)
     del tr, window
-    torch.cuda.empty_cache()
+    release_now(torch)
     return out
 
 
