@@ -150,6 +150,8 @@ class Trainer:
 
     def reset(self):
         """train_flow.py:83-87"""
+        if self.dec_stream is not None:      # (a window cut short: its decoder halves / updates may still be running)
+            torch.cuda.current_stream().wait_stream(self.dec_stream)
         self.loss_function.reset()
         self.model.reset_states()
         self.bucket.zero()
