@@ -319,3 +319,43 @@ def test_multi_stream_window_matches_one_stream(warping, scales, smooth, graph):
     print("relative differences (loss, gradient norm per window):", err)
     tol_loss, tol_norm = 1e-6, 1e-5
     assert np.isfinite(multi).all() and (err[0::2] <= tol_loss).all() and (err[1::2] <= tol_norm).all(), (one, multi)
+
+
+def test_window_cut_short_by_new_seq():
+    """train_flow.py:83-87: a new sequence resets the loss container, the recurrent state and the gradients in the middle
+    of a window.  With the decoder halves and update() calls of the abandoned passes still in flight on the side stream,
+    the reset has to wait for them: multi-stream against one stream (lr = 0, two passes abandoned, then two whole windows)."""
+    assert torch.cuda.is_available()
+    import copy
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import train
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"].update(batch_size=2, resolution=[64, 64], max_num_grad_events=1500)
+    cfg["data"].update(passes_loss=4)
+    cfg["optimizer"]["lr"] = 0.0
+
+    def run(streams):
+        torch.manual_seed(7)
+        tr = train.Trainer(cfg, dev, streams=streams)
+        tr.model.arch.engine.debug_delay = (0, 20_000_000, 0) if streams else None      # the side stream lags
+        src = train.SyntheticSequences(cfg, dev, 2000, seq_len=10 ** 9, seed=3, jitter=300)
+        tr.reset()
+        out = []
+        for t in range(2 + 8):
+            stepped = tr.step(src.next(), new_seq=(t == 2))
+            if stepped:
+                out += [float(tr.last_loss.item()), float(tr.last_grad_norm.item())]
+        del tr, src
+        gc.collect()
+        torch.cuda.synchronize()
+        return np.array(out)
+
+    one, multi = run(False), run(True)
+    assert len(one) == 4 and np.isfinite(multi).all()
+    err = np.abs(multi - one) / np.abs(one)
+    assert (err[0::2] <= 1e-6).all() and (err[1::2] <= 1e-5).all(), (one, multi)
