@@ -66,3 +66,48 @@ def test_encodings():
     for bins in (2, 5, 9):
         v = oracle.events_to_voxel(z["xs"], z["ys"], z["ts"], z["ps"], bins, H, W)
         assert rel_err(v, z[f"voxel{bins}"]) < 1e-6
+
+
+def test_primitives_chain_gradients():
+    """A focus loss assembled from the primitives one by one (tests/golden/make_golden.py --primitives: lookup ->
+    event_propagation -> purge_unfeasible -> corners -> per-polarity images -> loss/flow.py:112-129) — the oracle's
+    gradient primitives chained by hand against the gradients the reference's autograd recorded: d loss / d both flow maps
+    and d loss / d event locations."""
+    z = np.load(os.path.join(GOLDEN, "primitives.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    fx, fy, loc, ts, pm = z["chain_fx"], z["chain_fy"], z["chain_loc"], z["chain_ts"], z["chain_pm"]
+    B, N = loc.shape[:2]
+    flow = oracle.get_event_flow(fx, fy, loc)
+    dt = (1.0 - ts).astype(np.float32)                                        # event_propagation to tref = 1
+    warped = (loc + dt * flow).astype(np.float32)
+    inside = ((warped[..., 0:1] >= 0) & (warped[..., 0:1] <= H - 1.0) & (warped[..., 1:2] >= 0) & (warped[..., 1:2] <= W - 1.0))
+    inside = inside.astype(np.float32)
+    warped, wpm = warped * inside, pm * inside                                 # purge_unfeasible
+    idx, w = oracle.get_interpolation(warped, H, W)
+    ii = idx[:, :, 0].astype(np.int64)
+    tau = np.concatenate([ts] * 4, 1)                                          # 1 - |1 - ts| / 1
+    C = np.zeros((B, 2, H * W), np.float64)
+    T = np.zeros((B, 2, H * W), np.float64)
+    for c in range(2):
+        m4 = np.concatenate([wpm[:, :, c:c + 1]] * 4, 1)
+        for b in range(B):
+            np.add.at(C[b, c], ii[b], (w[b, :, 0] * m4[b, :, 0]).astype(np.float64))
+            np.add.at(T[b, c], ii[b], (w[b, :, 0] * tau[b, :, 0] * m4[b, :, 0]).astype(np.float64))
+    assert rel_err(C.reshape(B, 2, H, W), z["chain_iwe"]) < 1e-5 and rel_err(T.reshape(B, 2, H, W), z["chain_iwe_ts"]) < 1e-5
+    A = T / (C + 1e-9)
+    n = ((C[:, 0] + C[:, 1]) != 0).sum(1) + 1e-9                               # pixels with events (no gradient through it)
+    loss = ((A ** 2).sum((1, 2)) / n).sum()
+    assert abs(loss - float(z["chain_loss"])) <= 1e-5 * abs(float(z["chain_loss"]))
+    dT = 2.0 * A / ((C + 1e-9) * n[:, None, None])
+    dC = -2.0 * A ** 2 / ((C + 1e-9) * n[:, None, None])
+    dw = np.zeros((B, 4 * N, 1), np.float64)
+    for c in range(2):
+        m4 = np.concatenate([wpm[:, :, c:c + 1]] * 4, 1)
+        for b in range(B):
+            dw[b, :, 0] += m4[b, :, 0] * (dC[b, c][ii[b]] + tau[b, :, 0] * dT[b, c][ii[b]])
+    _, _, dwarped = oracle.get_interpolation(warped, H, W, dw.astype(np.float32))
+    dwarped = dwarped * inside                                                 # loc * mask
+    _, dfx, dfy, dloc_lookup = oracle.get_event_flow(fx, fy, loc, (dwarped * dt).astype(np.float32))
+    dloc = dwarped + dloc_lookup
+    assert rel_err(dfx, z["chain_dfx"]) < 2e-5 and rel_err(dfy, z["chain_dfy"]) < 2e-5
+    assert rel_err(dloc, z["chain_dloc"]) < 2e-5
