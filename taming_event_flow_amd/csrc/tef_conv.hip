@@ -68,6 +68,9 @@ struct GemmArgs {
     // state bl_out = bl_h * (1 - bl_u) + v * bl_u is stored beside v (reference submodules.py:150); all null otherwise
     const float *bl_h, *bl_u;
     float *bl_out;
+    // halo kernel: this launch covers rows [row_off, row_end) of the problem (row_end = 0: all of them) — a row count just
+    // past a multiple of the tile height is worked as whole large tiles plus one launch of 32-row tiles (launch_halo_w)
+    int row_off, row_end;
 };
 
 __device__ __forceinline__ void store_blend(const GemmArgs &g, size_t idx, float v)
@@ -540,7 +543,8 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, h = lane >> 5;
-    const int row0 = blockIdx.y * TR, col0 = blockIdx.x * 128;
+    const int row0 = blockIdx.y * TR + g.row_off, col0 = blockIdx.x * 128;
+    const int row_end = g.row_end ? g.row_end : g.rows;
     const int WI = GEN ? g.G.SW : S * W;                  // (input) image width
     const int HWi = g.G.SH * WI;                          // pixels per input image (!GEN: a multiple of 128, or 128 / IPT)
     const int HWo = S == 1 ? HWi : g.G.OH * W;            // pixels per output image
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             int r = row0 + wr * WR + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (r >= g.rows) continue;
+            if (r >= row_end) continue;
             float v = acc[i][e];
             if (EPI == EPI_FWD && S2D) {        // depth-to-space: class (py, px) of channel ci -> pixel (2a + py, 2b + px)
                 const int wg = GEN ? WI : W, cls = r / g.s2d_ct, ci = r - cls * g.s2d_ct;
@@ -1554,6 +1558,29 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
     if (GEN) tiles = (unsigned)((g.G.SW + (1 << LOGW) - 1) >> LOGW) * ((g.G.SH + (128 >> LOGW) - 1) / (128 >> LOGW)) *
                      (g.G.npix / (g.G.SH * g.G.SW));
     dim3 grid(tiles, 1, z);
+    // A row count just past whole tiles — the decoders' input gradients: 2 prediction channels beside 64 / 128 / 256 feature
+    // channels — would pay a whole extra 128-row tile (or half of its only one) for 2 rows: 33-49 % of the launch's MFMA work.
+    // The whole tiles run as they are, the remainder as a second launch of 32-row tiles.
+    if (!S2D && g.row_end == 0 && g.rows > 64 && g.rows % 64 > 0 && g.rows % 64 <= 32 &&
+        ((g.rows - g.rows % 64) % 128 == 0 || g.rows - g.rows % 64 == 64)) {
+        const int main_rows = g.rows - g.rows % 64;
+        GemmArgs a = g, b = g;
+        a.row_end = main_rows;
+        b.row_off = main_rows; b.row_end = g.rows;
+        if (main_rows == 64) {
+            hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, a);
+        } else {
+            grid.y = main_rows / 128;
+            hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, a);
+        }
+        if (int rc = tef::check_launch("conv3x3_halo_kernel")) return rc;
+        grid.y = 1;
+        if constexpr (GEN && LOGW == 3)      // (8 x 16 rectangles: the 288 halo elements need more than 256 threads)
+            hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(512), 0, st, b);
+        else
+            hipLaunchKernelGGL((conv3x3_halo_kernel<256, 32, 32, LOGW, IPT, EPI, GATED, GEN>), grid, dim3(256), 0, st, b);
+        return tef::check_launch("conv3x3_halo_kernel (row remainder)");
+    }
     const int tr = halo_row_tile(g.rows, g.cols);
     if (tr == 128) {
         grid.y = (g.rows + 127) / 128;
