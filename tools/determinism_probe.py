@@ -1,3 +1,12 @@
+#!/usr/bin/env python3
+"""Same training windows four ways — captured hipGraph / eager, one stream / the Trainer's streams — with lr = 0 (the
+windows then differ through the recurrent state only): the printed (loss, gradient norm) sequences must agree to fp32
+summation order.  With a learning rate they do not, from one PROCESS to the next, on any launch path: Adam's first steps
+move a weight by +-lr whatever its gradient's size, and the next window's gradient norm lands on one of a few values
+percents apart.
+
+    python tools/determinism_probe.py graph|eager        (TEF_TWO_STREAMS=0|1)
+"""
 import copy, os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
