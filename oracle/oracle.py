@@ -40,7 +40,7 @@ def build(force=False):
     fresh = os.path.exists(_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest
     if force or not fresh:
         subprocess.check_call(
-            ["gcc", "-O2", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC, "-lm"]
+            ["gcc", "-O2", "-mfma", "-fopenmp", "-fPIC", "-shared", "-ffp-contract=off", "-o", _LIB, _SRC, "-lm"]
         )
         with open(stamp, "w") as f:
             f.write(digest)

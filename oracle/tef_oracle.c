@@ -66,7 +66,11 @@ static inline float tef_tap_value(const float *map, const tef_taps *t)
 {
     float v00 = t->i00 >= 0 ? map[t->i00] : 0.0f, v01 = t->i01 >= 0 ? map[t->i01] : 0.0f;
     float v10 = t->i10 >= 0 ? map[t->i10] : 0.0f, v11 = t->i11 >= 0 ? map[t->i11] : 0.0f;
-    return v00 * t->w00 + v01 * t->w01 + v10 * t->w10 + v11 * t->w11;
+    /* ATen's vectorised CPU kernel is compiled with floating-point contraction: its
+     * `nw_val * nw + ne_val * ne + sw_val * sw + se_val * se` is ONE product followed by three fused multiply-adds
+     * (established bit for bit against torch 2.10 here: 0 mismatches in 200 000 random lookups, where the unfused sum
+     * differs in 35 % of them by an ulp — and an ulp of position is 1 % of a 1e-5 hat weight: round 4) */
+    return __builtin_fmaf(v11, t->w11, __builtin_fmaf(v10, t->w10, __builtin_fmaf(v01, t->w01, v00 * t->w00)));
 }
 
 /* d value / d(y, x) of the lookup (grid gradient of grid_sampler_2d backward) */
@@ -320,10 +324,17 @@ static void tef_image_backward(const tef_window *wd, int b, const tef_imgbuf *ib
         for (int k = 0; k < 4; ++k) {
             if (s.idx[k] < 0) continue;
             int p = s.idx[k];
-            /* dl/dw = sum_c m_c * K * 2 A (tau - A) R   (SURVEY.md §8a closed form) */
-            float dw = wd->mp[o] * (2.0f * ib->A[p] * (tau - ib->A[p]) * ib->R[p])
-                     + wd->mn[o] * (2.0f * ib->A[HW + p] * (tau - ib->A[HW + p]) * ib->R[HW + p]);
-            dw *= kimg;
+            /* autograd's own arithmetic, not the closed form 2 A (tau - A) / (C + eps): the division's backward gives
+             * dT = gA / (C + eps) and d(C + eps) = -gA * ((T / (C + eps)) / (C + eps)) per pixel (gA = g * 2 A from the
+             * square, g = the image's coefficient / n), and an event's weight collects dC + dT * tau from the four
+             * scatters (loss/flow.py:100-108, :727).  Mathematically the same; where a pixel holds a single event
+             * (tau - A ~ 1e-9 / C) the two forms round differently by 1e-7 of a term that is 1 / C times larger than the
+             * result — 1.4e-5 of the gradient's maximum on the BASELINE window, 8e-8 in this form (round 4) */
+            float c0 = ib->Cg[p] + ib->Cd[p] + TEF_EPS, c1 = ib->Cg[HW + p] + ib->Cd[HW + p] + TEF_EPS;
+            float ga0 = kimg * (2.0f * ib->A[p]), ga1 = kimg * (2.0f * ib->A[HW + p]);
+            float dT0 = ga0 / c0, dT1 = ga1 / c1;
+            float dC0 = -(ga0 * (ib->A[p] / c0)), dC1 = -(ga1 * (ib->A[HW + p] / c1));
+            float dw = (dC0 * wd->mp[o] + dC1 * wd->mn[o]) + (dT0 * wd->mp[o] + dT1 * wd->mn[o]) * tau;
             ay += dw * s.dwy[k];
             ax += dw * s.dwx[k];
             if (my) {       /* mass: the same expression with every term's magnitude */

@@ -288,9 +288,12 @@ __device__ __forceinline__ Quad2 load_quad_interior(const float2 *__restrict__ m
 // (flow_y, flow_x) at the tap position
 __device__ __forceinline__ float2 quad_value(const Quad2 &q, const Taps &t)
 {
+    // ATen's vectorised CPU kernel is compiled with contraction: nw_val * nw + ne_val * ne + sw_val * sw + se_val * se is
+    // ONE product and three fused multiply-adds, in that order (bit for bit against torch 2.10: 0 mismatches in 200 000
+    // lookups; the unfused sum differs by an ulp in 35 % of them, and an ulp of position is 1 % of a 1e-5 hat weight)
     float w00 = t.s * t.e, w01 = t.s * t.w, w10 = t.n * t.e, w11 = t.n * t.w;
-    return make_float2(q.v00.x * w00 + q.v01.x * w01 + q.v10.x * w10 + q.v11.x * w11,
-                       q.v00.y * w00 + q.v01.y * w01 + q.v10.y * w10 + q.v11.y * w11);
+    return make_float2(__builtin_fmaf(q.v11.x, w11, __builtin_fmaf(q.v10.x, w10, __builtin_fmaf(q.v01.x, w01, q.v00.x * w00))),
+                       __builtin_fmaf(q.v11.y, w11, __builtin_fmaf(q.v10.y, w10, __builtin_fmaf(q.v01.y, w01, q.v00.y * w00))));
 }
 
 // Jacobian of the lookup: jyy = d f_y/d y, jyx = d f_y/d x, jxy = d f_x/d y, jxx = d f_x/d x

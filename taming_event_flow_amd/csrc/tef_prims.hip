@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void event_flow_kernel(const float *__restrict
     const float *mx = fx + b * H * W, *my = fy + b * H * W;
     const Taps t = make_taps(loc[2 * e], loc[2 * e + 1], H, W);
     const float w00 = t.s * t.e, w01 = t.s * t.w, w10 = t.n * t.e, w11 = t.n * t.w;
-    out[2 * e] = tap(my, t.i00) * w00 + tap(my, t.i01) * w01 + tap(my, t.i10) * w10 + tap(my, t.i11) * w11;
-    out[2 * e + 1] = tap(mx, t.i00) * w00 + tap(mx, t.i01) * w01 + tap(mx, t.i10) * w10 + tap(mx, t.i11) * w11;
+    // one product + three fused multiply-adds, like ATen's (contracted) CPU kernel: see tef_loss.hip::quad_value
+    out[2 * e] = __builtin_fmaf(tap(my, t.i11), w11, __builtin_fmaf(tap(my, t.i10), w10, __builtin_fmaf(tap(my, t.i01), w01, tap(my, t.i00) * w00)));
+    out[2 * e + 1] = __builtin_fmaf(tap(mx, t.i11), w11, __builtin_fmaf(tap(mx, t.i10), w10, __builtin_fmaf(tap(mx, t.i01), w01, tap(mx, t.i00) * w00)));
 }
 
 // gout [B][N][2] = (d / d f_y, d / d f_x).  dfx / dfy += bilinear weights x gout (zeroed by the caller);

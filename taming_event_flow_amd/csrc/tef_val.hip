@@ -29,8 +29,9 @@ __device__ __forceinline__ void sample_flow(const float *__restrict__ fx, const 
     if (vy0 && vx1) { v01y = fy[y0 * W + x1]; v01x = fx[y0 * W + x1]; }
     if (vy1 && vx0) { v10y = fy[y1 * W + x0]; v10x = fx[y1 * W + x0]; }
     if (vy1 && vx1) { v11y = fy[y1 * W + x1]; v11x = fx[y1 * W + x1]; }
-    oy = v00y * (s * e) + v01y * (s * w) + v10y * (n * e) + v11y * (n * w);
-    ox = v00x * (s * e) + v01x * (s * w) + v10x * (n * e) + v11x * (n * w);
+    // one product + three fused multiply-adds, like ATen's (contracted) CPU kernel: see tef_loss.hip::quad_value
+    oy = __builtin_fmaf(v11y, n * w, __builtin_fmaf(v10y, n * e, __builtin_fmaf(v01y, s * w, v00y * (s * e))));
+    ox = __builtin_fmaf(v11x, n * w, __builtin_fmaf(v10x, n * e, __builtin_fmaf(v01x, s * w, v00x * (s * e))));
 }
 
 __device__ __forceinline__ bool inbounds(float y, float x, int H, int W)   // utils/iwe.py:52-57

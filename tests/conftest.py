@@ -73,6 +73,55 @@ ITERATIVE_CASES = [
 LINEAR_CASES = ["lin_s1_p6", "lin_s2_p8", "lin_smooth_terms", "lin_zero_flow", "lin_unscaled", "lin_nocomp_s2",
                 "lin_nocomp_p5_s2", "lin_p10_s3"]
 FULL_RES_CASES = ["it_two_128_p10", "lin_128_p10"]      # BASELINE resolution, inputs regenerated from a seed
+# the exact windows bench.py times (BASELINE configs[1]: B = 8, F = 4, P = 10, 10 000 events), run through the reference
+BENCH_WINDOW_CASES = ["bench_window_0", "bench_window_1"]
+
+
+def load_bench_window(name):
+    """A reference-recorded bench window (tests/golden/make_golden.py::save_bench_window) -> (meta, window, golden
+    arrays).  The inputs are regenerated exactly as bench.py makes them and checked against the recorded digest."""
+    import hashlib
+    import json
+
+    from taming_event_flow_amd import synth
+
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    rng = np.random.default_rng(meta["seed"])
+    win = synth.make_window(rng, meta["B"], meta["H"], meta["W"], meta["P"], meta["F"], meta["n_grad"], meta["n_det"],
+                            sigma=meta["sigma"], kind="smooth")
+    h = hashlib.sha256()
+    for t in range(meta["P"]):
+        for f in win["flows"][t]:
+            h.update(np.ascontiguousarray(f).tobytes())
+        for k in ("ev", "pm", "dev", "dpm"):
+            h.update(np.ascontiguousarray(win[k][t]).tobytes())
+    assert h.hexdigest() == meta["digest"], "regenerated inputs differ from the ones the reference was run on"
+    return meta, win, {k: z[k] for k in z.files if k != "meta"}
+
+
+def check_bench_window(meta, gold, loss, g, tol, lattice_tol=None):
+    """loss and d loss / d flow [P, F, B, 2, H, W] of a bench window against what the reference recorded: the loss, the
+    stride-s lattice of the gradient in max-norm (globally and per map), and per map the float64 sum / sum of squares
+    over ALL pixels relative to the map's sum of magnitudes (covers the pixels the lattice skips)."""
+    s = meta["stride"]
+    assert abs(loss - float(gold["loss"])) <= tol * abs(float(gold["loss"])), (loss, float(gold["loss"]))
+    lat = g[..., ::s, ::s]
+    ref = gold["dflows_lattice"]
+    assert lat.shape == ref.shape
+    e_lat = rel_err(lat, ref)
+    assert e_lat <= (lattice_tol or tol), e_lat
+    gmax = gold["dflows_max"]                                  # [P, F, B, 2] max |g| of every map over ALL its pixels
+    e_map = float((np.abs(lat.astype(np.float64) - ref).max(axis=(-1, -2)) / np.maximum(gmax, 1e-30)).max())
+    assert e_map <= 20 * tol, e_map
+    g64 = g.astype(np.float64)
+    e_sum = float((np.abs(g64.sum(axis=(-1, -2)) - gold["dflows_sum"]) / gold["dflows_abs_sum"]).max())
+    e_abs = float((np.abs(np.abs(g64).sum(axis=(-1, -2)) - gold["dflows_abs_sum"]) / gold["dflows_abs_sum"]).max())
+    e_sq = float((np.abs((g64 * g64).sum(axis=(-1, -2)) - gold["dflows_sq_sum"]) / gold["dflows_sq_sum"]).max())
+    e_max = float((np.abs(np.abs(g).max(axis=(-1, -2)) - gmax) / gmax).max())
+    assert e_sum <= tol and e_abs <= tol and e_sq <= 2 * tol and e_max <= 20 * tol, (e_sum, e_abs, e_sq, e_max)
+    return dict(loss=abs(loss - float(gold["loss"])) / abs(float(gold["loss"])), lattice=e_lat, per_map=e_map, sum=e_sum,
+                abs_sum=e_abs, sq_sum=e_sq, max=e_max)
 
 
 def rel_err(a, b):

@@ -120,6 +120,28 @@ def save_seeded_case(name, kind, H, W, B, P, F, S, mode, n_grad, n_det, seed, si
     print(f"{name}: loss={loss64:.7f} |g|max={np.abs(g).max():.4e} size={os.path.getsize(path)/1e3:.0f} kB")
 
 
+def save_bench_window(name, seed, B=8, H=128, W=128, P=10, F=4, N=10000, stride=4):
+    """The exact windows `bench.py` stages by default (BASELINE configs[1]/[2]: Iterative/two, 128x128, B = 8, P = 10,
+    F = 4, 10 000 events per pass and sample, smooth flows sigma = 2 px; `rng = default_rng(1000 * rank + window)`), run
+    through the reference.  Inputs are regenerated from the seed at test time and checked against the recorded digest;
+    of the 42 MB of d loss / d flow a stride-`stride` lattice is stored plus, per map, float64 sums of the gradient and of
+    its magnitude (so that every pixel is covered by some recorded number)."""
+    rng = np.random.default_rng(seed)
+    win = synth.make_window(rng, B, H, W, P, F, N, 0, sigma=2.0, kind="smooth")
+    cfg = make_config(H, W, B, P, 1, "two")
+    loss64, loss32, g = run_loss("Iterative", cfg, win)
+    g64 = g.astype(np.float64)
+    meta = dict(kind="Iterative", H=H, W=W, B=B, P=P, F=F, S=1, mode="two", spat=None, temp=None, round_ts=False,
+                seed=seed, loss=loss64, n_grad=N, n_det=0, sigma=2.0, seeded=True, stride=stride,
+                digest=window_digest(win))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(json.dumps(meta)), loss=loss32,
+                        dflows_lattice=np.ascontiguousarray(g[..., ::stride, ::stride]),
+                        dflows_sum=g64.sum(axis=(-1, -2)), dflows_abs_sum=np.abs(g64).sum(axis=(-1, -2)),
+                        dflows_sq_sum=(g64 * g64).sum(axis=(-1, -2)), dflows_max=np.abs(g).max(axis=(-1, -2)))
+    print(f"{name}: loss={loss64:.7f} |g|max={np.abs(g).max():.4e} size={os.path.getsize(path)/1e3:.0f} kB")
+
+
 def save_primitives(seed=11):
     """utils/iwe.py primitives on one small batch (values and gradients)."""
     rng = np.random.default_rng(seed)
@@ -227,6 +249,12 @@ def main():
         # the BASELINE resolution and window (128x128, P = 10, 10 000 gradient + 2 000 detached events per pass), one sample
         save_seeded_case("it_two_128_p10", "Iterative", 128, 128, 1, 10, 2, 1, "two", 10000, 2000, seed=31)
         save_seeded_case("lin_128_p10", "Linear", 128, 128, 1, 10, 1, 1, "two", 10000, 2000, seed=32)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--bench-windows":
+        # what bench.py times: rank 0's windows 0 and 1
+        torch.set_num_threads(8)
+        save_bench_window("bench_window_0", 0)
+        save_bench_window("bench_window_1", 1)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "--primitives":
         save_primitives()

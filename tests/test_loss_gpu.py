@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, elementwise_excess, load_case, rel_err
+from conftest import (BENCH_WINDOW_CASES, FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, check_bench_window, elementwise_excess,
+                      load_bench_window, load_case, rel_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -81,6 +82,16 @@ def test_golden_cases(name, dev):
     ex, where, got, want = elementwise_excess(g, dflows, mass)
     print(f"{name}: max-norm {rel_err(g, dflows):.2e}; element-wise excess {ex:.3f} at {where}: hip {got:.6e} reference {want:.6e}")
     assert ex <= 4.0, (ex, where, got, want)
+
+
+@pytest.mark.parametrize("name", BENCH_WINDOW_CASES)
+def test_bench_windows_against_reference(name, dev):
+    """The exact windows bench.py times (BASELINE configs[1]: B = 8, F = 4, P = 10, 10 000 events per pass and sample),
+    against what the reference itself returned for them (tests/golden/make_golden.py --bench-windows): loss, the stride-4
+    lattice of d loss / d flow and per-map float64 sums over every pixel."""
+    meta, win, gold = load_bench_window(name)
+    l, g, _ = run_hip("Iterative", make_cfg(meta), win, dev)
+    print(name, check_bench_window(meta, gold, l, g, TOL))
 
 
 def test_upstream_gradient_scaling(dev):

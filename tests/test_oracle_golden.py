@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, elementwise_excess, load_case, rel_err
+from conftest import (BENCH_WINDOW_CASES, GOLDEN, FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, check_bench_window,
+                      elementwise_excess, load_bench_window, load_case, rel_err)
 from oracle import oracle
 
 TOL = 1e-5
@@ -37,6 +38,16 @@ def test_loss_cases(name):
     if meta["spat"] is not None or meta["temp"] is not None:
         mass = mass + np.abs(w.smoothing(meta["spat"], meta["temp"])[1])
     assert elementwise_excess(d, dflows, mass)[0] <= 3.0
+
+
+@pytest.mark.parametrize("name", BENCH_WINDOW_CASES)
+def test_bench_windows(name):
+    """The windows bench.py times, at full size (B = 8, F = 4, P = 10, 10 000 events per pass and sample): the oracle
+    against the reference's recorded loss and gradient — the oracle is what bench.py's `cpu_baseline` leg runs."""
+    meta, win, gold = load_bench_window(name)
+    w = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=1, mode="two")
+    l, d = w.loss("Iterative", None, None)
+    print(name, check_bench_window(meta, gold, l, d, TOL, lattice_tol=5 * TOL))
 
 
 def test_primitives():
