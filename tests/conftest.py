@@ -131,21 +131,17 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def elementwise_excess(a, b, mass, rtol=1e-4, floor=1e-7):
-    """Element-wise parity of two flow-gradient arrays: max over the elements of |a - b| / (rtol * mass + floor * max|b|)
-    and where it is attained, -> (excess, index, a[index], b[index]); parity holds when excess <= 1.
-
-    `mass` (oracle.Window.gradient_mass) is, per pixel, the sum over the events of the ABSOLUTE contributions whose signed
-    sum is the gradient: the scale each element is resolved to.  The plain form |a - b| <= rtol |b| + floor max|b| is not
-    satisfiable by ANY fp32 evaluation: on the golden cases the faithful C oracle (which agrees with the reference to
-    1e-5 in max-norm) exceeds it up to 24-fold at pixels where contributions cancel, and the reference's own float64 run
-    differs from its float32 run by far more.  Against the pixel's mass a region of small gradients is held to 1e-4 of
-    ITS OWN scale — a small-magnitude region that is wrong by 100 % fails however right the peak is — and a pixel no
-    event touches must be exactly zero up to the floor."""
+def elementwise_error(a, b, rtol=1e-4, floor=1e-6):
+    """Element-wise parity of two flow-gradient arrays in its plain form: max over the elements of
+    |a - b| / (rtol * |b| + floor * max|b|) and where it is attained -> (error, index, a[index], b[index]); parity holds
+    when error <= 1: every pixel within 1e-4 of ITS OWN reference value, with a floor of 1e-6 of the largest gradient for
+    pixels that are (nearly) zero.  (Rounds 1-3 held pixels to 1e-4 x a builder-defined "gradient mass" instead, because
+    neither the oracle nor the HIP path could meet this form: their bilinear lookups differed from ATen's by an ulp in a
+    third of the cases and the backward used the closed form 2 A (tau - A) / (C + eps) where autograd forms dC + dT * tau.
+    With both fixed in round 4 the oracle meets it 40-fold and the HIP path on every recorded case.)"""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
-    bound = rtol * np.asarray(mass, np.float64) + floor * np.abs(b).max()
-    r = np.abs(a - b) / bound
+    r = np.abs(a - b) / (rtol * np.abs(b) + floor * np.abs(b).max() + 1e-300)
     i = np.unravel_index(int(r.argmax()), r.shape)
     return float(r[i]), tuple(int(v) for v in i), float(a[i]), float(b[i])
 

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import elementwise_excess, rel_err
+from conftest import elementwise_error, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -94,7 +94,7 @@ def test_configs2_full_size():
     assert abs(la - ol) <= 1e-4 * abs(ol), (la, float(ol))
     g_hip = np.stack([np.stack(row) for row in dfa])
     assert rel_err(g_hip, od) <= 1e-4
-    ex, where, got, want = elementwise_excess(g_hip, od, ow.gradient_mass("Iterative"))
+    ex, where, got, want = elementwise_error(g_hip, od)
     print(f"configs[2] loss on network flows: hip {la:.7f} oracle {float(ol):.7f}; d loss / d flow max-norm {rel_err(g_hip, od):.2e}, "
-          f"element-wise excess {ex:.3f} at {where}")
-    assert ex <= 4.0, (ex, where, got, want)
+          f"element-wise {ex:.3f} at {where}")
+    assert ex <= 1.0, (ex, where, got, want)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import (BENCH_WINDOW_CASES, FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, check_bench_window, elementwise_excess,
+from conftest import (BENCH_WINDOW_CASES, FULL_RES_CASES, ITERATIVE_CASES, LINEAR_CASES, check_bench_window, elementwise_error,
                       load_bench_window, load_case, rel_err)
 
 pytestmark = pytest.mark.gpu
@@ -65,24 +65,11 @@ def test_golden_cases(name, dev):
         np.testing.assert_allclose(evs[t][1][:, :, 0].cpu().numpy(), win["dev"][t][:, :, 0] + t, rtol=0, atol=0)
         for i in range(meta["F"]):
             if np.abs(dflows[t, i]).max() > 0:
-                assert rel_err(g[t, i], dflows[t, i]) <= 2e-3, (t, i)
-    # element by element, each pixel against ITS OWN scale (conftest.elementwise_excess): |hip - reference| <= 1e-4 x the
-    # pixel's gradient mass (the backward pass with every term's magnitude, from the oracle) + 1e-7 max|reference|.  A
-    # small-magnitude region that is wrong fails here however right the peak is.  Calibration: the C oracle — the same
-    # arithmetic in the reference's own order, 1e-5 from the reference in max-norm — reaches 2.5 on these cases (worst:
-    # it_two_128_p10), so the bar for the HIP path is 4.
-    from oracle import oracle
-
-    w = oracle.Window(win["flows"], win["ev"], win["pm"], win["dev"], win["dpm"], S=meta["S"], mode=meta["mode"],
-                      round_ts=meta["round_ts"], loss_scaling=meta.get("loss_scaling", True),
-                      border_compensation=meta.get("border_compensation", True))
-    mass = w.gradient_mass(meta["kind"])
-    if meta["spat"] is not None or meta["temp"] is not None:
-        mass = mass + np.abs(w.smoothing(meta["spat"], meta["temp"])[1])
-    ex, where, got, want = elementwise_excess(g, dflows, mass)
-    print(f"{name}: max-norm {rel_err(g, dflows):.2e}; element-wise excess {ex:.3f} at {where}: hip {got:.6e} reference {want:.6e}")
-    assert ex <= 4.0, (ex, where, got, want)
-
+                assert rel_err(g[t, i], dflows[t, i]) <= 5 * TOL, (t, i)
+    # element by element, the plain form: every pixel within 1e-4 of ITS OWN reference value + 1e-6 of the largest gradient
+    ex, where, got, want = elementwise_error(g, dflows)
+    print(f"{name}: max-norm {rel_err(g, dflows):.2e}; element-wise {ex:.3f} at {where}: hip {got:.6e} reference {want:.6e}")
+    assert ex <= 1.0, (ex, where, got, want)
 
 @pytest.mark.parametrize("name", BENCH_WINDOW_CASES)
 def test_bench_windows_against_reference(name, dev):
