@@ -106,6 +106,22 @@ def make_window(rng, B, H, W, P, F, n_grad, n_det=0, sigma=2.0, kind="smooth", r
     return out
 
 
+def make_eval_window(seed, H, W, passes, N, sigma=2.0):
+    """Inputs of one evaluation window for the validation metrics (loss/flow_val.py; batch 1 as eval_flow.py:30 hard-wires):
+    per pass the events + polarity mask, the flow map that counts, a low-resolution decoy (flow_list[-1] is the one the
+    reference uses) and the event mask image -> list of dicts."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(passes):
+        ev, pm = make_event_pass(rng, 1, N, H, W)
+        flow = make_flow(rng, 1, H, W, sigma=sigma, grid=12)
+        low = make_flow(rng, 1, H, W, sigma=sigma, grid=12)
+        mask = np.zeros((1, 1, H, W), np.float32)
+        mask[0, 0, ev[0, :, 1].astype(int), ev[0, :, 2].astype(int)] = 1.0
+        out.append(dict(ev=ev, pm=pm, flow=flow, low=low, mask=mask))
+    return out
+
+
 def make_model_weights(shapes, seed):
     """Deterministic (numpy PCG64) parameter values for a list of (name, shape): weights ~ N(0, 1/fan_in),
     biases ~ N(0, 0.05^2).  Used instead of storing 31 M parameters in the golden fixtures."""

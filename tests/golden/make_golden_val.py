@@ -70,7 +70,59 @@ def run(kind, H, W, passes, N, seed, round_ts=False, sigma=1.5):
           f"{os.path.getsize(path)/1e3:.0f} kB")
 
 
+def inputs_digest(inp):
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in inp:
+        for k in ("ev", "pm", "flow", "low", "mask"):
+            h.update(np.ascontiguousarray(d[k]).tobytes())
+    return h.hexdigest()
+
+
+def summarise(a, stride):
+    """What is stored of a full-resolution output image: a stride-`stride` lattice plus float64 sums over every pixel
+    (NaN / inf of the unmasked flow images counted separately)."""
+    a = np.asarray(a)
+    fin = np.isfinite(a)
+    z = np.where(fin, a, 0).astype(np.float64)
+    return dict(lattice=np.ascontiguousarray(a[..., ::stride, ::stride]), sum=z.sum(axis=(-1, -2)),
+                abs_sum=np.abs(z).sum(axis=(-1, -2)), sq_sum=(z * z).sum(axis=(-1, -2)),
+                nonfinite=np.int64((~fin).sum()))
+
+
+def run_big(seed=64, H=480, W=640, passes=10, N=100000, stride=4):
+    """flow_val.Iterative at the DSEC evaluation shape (BASELINE configs[4]: 480x640, 10 passes x 100 000 events, batch 1
+    as eval_flow.py hard-wires): per-pass FWL / RSAT and every window image as lattice + float64 sums."""
+    torch.set_num_threads(8)
+    inp = synth.make_eval_window(seed, H, W, passes, N)
+    cfg = {"loader": {"resolution": [H, W]}, "loss": {"round_ts": False}, "vis": {"mask_output": True}, "metrics": {}}
+    V = ref.Iterative(cfg, torch.device("cpu"))
+    out = dict(kind="Iterative", H=H, W=W, passes=passes, N=N, seed=seed, stride=stride, digest=inputs_digest(inp))
+    for t, d in enumerate(inp):
+        evt = torch.tensor(d["ev"]).clone()
+        V.update([torch.tensor(d["low"]), torch.tensor(d["flow"])], evt, torch.tensor(d["pm"]), torch.tensor(d["mask"]))
+        out[f"rsat{t}"] = np.float64(V.rsat().item())
+        out[f"fwl{t}"] = np.float64(V.fwl().item())
+    images = {"events_round": V.window_events(round_idx=True), "events_bilinear": V.window_events(round_idx=False),
+              "flow_none": V.window_flow(mode=None, mask=True)}
+    for mode in ("forward", "backward"):
+        images[f"iwe_{mode}_round"] = V.window_iwe(mode=mode, round_idx=True)
+        images[f"iwe_{mode}"] = V.window_iwe(mode=mode, round_idx=False)
+        images[f"flow_{mode}"] = V.window_flow(mode=mode, mask=True)
+    for name, img in images.items():
+        for k, v in summarise(img.numpy(), stride).items():
+            out[f"{name}.{k}"] = v
+    path = os.path.join(HERE, f"val_iterative_{H}x{W}.npz")
+    np.savez_compressed(path, **out)
+    print("Iterative", H, W, "rsat", [round(float(out[f"rsat{t}"]), 5) for t in range(passes)], "fwl",
+          [round(float(out[f"fwl{t}"]), 5) for t in range(passes)], f"{os.path.getsize(path)/1e3:.0f} kB")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--dsec-shape":
+        run_big()
+        sys.exit(0)
     run("Linear", 24, 30, 3, [250, 300, 200], seed=61)
     run("Iterative", 24, 30, 4, [250, 300, 200, 260], seed=62)
     run("Iterative", 20, 26, 3, [200, 220, 180], seed=63, round_ts=True)

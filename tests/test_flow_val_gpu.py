@@ -59,6 +59,60 @@ def test_validation_golden(name):
     assert V.num_passes == 0
 
 
+def test_validation_dsec_shape():
+    """BASELINE configs[4] at its real size against the reference: flow_val.Iterative at 480x640, 10 passes x 100 000
+    events (tests/golden/make_golden_val.py --dsec-shape; inputs regenerated from the seed and checked against the
+    recorded digest): FWL / RSAT after every pass, every window image on a stride-4 lattice and by float64 sums over all
+    pixels."""
+    import hashlib
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import synth
+    from taming_event_flow_amd.loss import flow_val
+
+    dev = torch.device("cuda:0")
+    z = np.load(os.path.join(GOLDEN, "val_iterative_480x640.npz"))
+    H, W, passes, N, stride = int(z["H"]), int(z["W"]), int(z["passes"]), int(z["N"]), int(z["stride"])
+    inp = synth.make_eval_window(int(z["seed"]), H, W, passes, N)
+    h = hashlib.sha256()
+    for d in inp:
+        for k in ("ev", "pm", "flow", "low", "mask"):
+            h.update(np.ascontiguousarray(d[k]).tobytes())
+    assert h.hexdigest() == str(z["digest"]), "regenerated inputs differ from the ones the reference was run on"
+    cfg = {"loader": {"resolution": [H, W]}, "loss": {"round_ts": False}, "vis": {"mask_output": True}, "metrics": {}}
+    V = flow_val.Iterative(cfg, dev)
+    t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    worst = 0.0
+    for p, d in enumerate(inp):
+        V.update([t(d["low"]), t(d["flow"])], t(d["ev"]), t(d["pm"]), t(d["mask"]))
+        for name, got in (("rsat", V.rsat()), ("fwl", V.fwl())):
+            e = abs(float(got.item()) - float(z[f"{name}{p}"])) / float(z[f"{name}{p}"])
+            worst = max(worst, e)
+            assert e <= TOL, (name, p, e)
+    images = {"events_round": V.window_events(round_idx=True), "events_bilinear": V.window_events(round_idx=False),
+              "flow_none": V.window_flow(mode=None, mask=True)}
+    for mode in ("forward", "backward"):
+        images[f"iwe_{mode}_round"] = V.window_iwe(mode=mode, round_idx=True)
+        images[f"iwe_{mode}"] = V.window_iwe(mode=mode, round_idx=False)
+        images[f"flow_{mode}"] = V.window_flow(mode=mode, mask=True)
+    for name, img in images.items():
+        a = img.cpu().numpy()
+        fin = np.isfinite(a)
+        assert int((~fin).sum()) == int(z[f"{name}.nonfinite"]), name
+        a0 = np.where(fin, a, 0)
+        e_lat = rel_err(a0[..., ::stride, ::stride], np.nan_to_num(z[f"{name}.lattice"], posinf=0, neginf=0))
+        a64 = a0.astype(np.float64)
+        den = np.maximum(z[f"{name}.abs_sum"], 1e-30)
+        e_sum = float((np.abs(a64.sum(axis=(-1, -2)) - z[f"{name}.sum"]) / den).max())
+        e_abs = float((np.abs(np.abs(a64).sum(axis=(-1, -2)) - z[f"{name}.abs_sum"]) / den).max())
+        e_sq = float((np.abs((a64 * a64).sum(axis=(-1, -2)) - z[f"{name}.sq_sum"]) / np.maximum(z[f"{name}.sq_sum"], 1e-30)).max())
+        print(f"{name}: lattice {e_lat:.2e} sum {e_sum:.2e} abs-sum {e_abs:.2e} sq-sum {e_sq:.2e}")
+        assert e_lat <= TOL and e_sum <= TOL and e_abs <= TOL and e_sq <= 2 * TOL, name
+    print(f"validation window 480x640: worst FWL / RSAT relative error {worst:.2e}")
+
+
 def test_compute_pol_iwe():
     """utils/iwe.py compute_pol_iwe / deblur_events (one-shot IWE for visualisation) vs the reference, all 4 modes."""
     import __graft_entry__ as g
