@@ -391,11 +391,13 @@ int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *
  * step (optional) is incremented by one: the counter of the Adam update that follows.
  * tef_adam_clip_step: clip_grad_norm_ (g *= min(1, max_norm / (norm + 1e-6)); max_norm <= 0: no clipping), torch.optim.Adam
  * with amsgrad=False / weight_decay=0 (exp_avg m, exp_avg_sq v, bias corrections from the device counter `step`, which
- * makes the call graph-capturable) and zero_grad (g <- 0), one launch over n elements. */
+ * makes the call graph-capturable) and zero_grad (g <- 0), one launch over n elements.  The hyper-parameters are doubles —
+ * Python floats in the reference — rounded to fp32 where torch rounds them (1 - beta, lr / bc1, sqrt(bc2)); a NaN norm
+ * propagates into every parameter, like torch's clamp. */
 size_t tef_l2_norm_scratch_bytes(void);
 int tef_l2_norm(const float *x, size_t n, void *scratch, float *out, float *step, void *stream);
-int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const float *norm, float max_norm, float lr,
-                       float beta1, float beta2, float eps, const float *step, void *stream);
+int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const float *norm, float max_norm, double lr,
+                       double beta1, double beta2, double eps, const float *step, void *stream);
 
 /* ---- validation metrics (loss/flow_val.py; evaluation only, batch 1, no gradients) ---------------------------------
  * Flow maps are planar [H][W] (fx, fy separately); event lists are loc [N][2] = (y, x), ts [N], mask [N][2]. */

@@ -54,19 +54,27 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double *__restric
 // cleared afterwards.  Op order of torch's _single_tensor_adam: lerp, mul + addcmul, sqrt / sqrt(bc2) + eps, addcdiv.
 __global__ __launch_bounds__(256) void adam_clip_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                         float *__restrict__ v, size_t n, const float *__restrict__ norm,
-                                                        float max_norm, float lr, float b1, float b2, float eps,
+                                                        float max_norm, double lr, double b1d, double b2d, double epsd,
                                                         const float *__restrict__ step)
 {
     const float t = step[0];
     float scale = 1.0f;
-    if (max_norm > 0.0f) scale = fminf(max_norm / (norm[0] + 1e-6f), 1.0f);      // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1)
-    const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
-    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+    if (max_norm > 0.0f) {
+        // clip_grad_norm_: clamp(max_norm / (norm + 1e-6), max=1).  torch's clamp PROPAGATES a NaN norm (every parameter is
+        // poisoned and the failure is loud); fminf would return 1 and update with the finite elements of a broken gradient
+        const float s = max_norm / (norm[0] + 1e-6f);
+        scale = (s < 1.0f || s != s) ? s : 1.0f;
+    }
+    // bias corrections as torch's _single_tensor_adam forms them for a host step count: Python floats (double) —
+    // 1 - beta ** step, lr / bc1, sqrt(bc2) — rounded to fp32 only where they enter the tensor arithmetic
+    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - b1d), b2 = (float)b2d, w2 = (float)(1.0 - b2d), eps = (float)epsd;
     const size_t n4 = n >> 2, stride = (size_t)gridDim.x * blockDim.x;
     auto one = [&](float &pp, float &gg, float &mm, float &vv) {
         const float gr = gg * scale;
-        mm = mm + (1.0f - b1) * (gr - mm);                       // exp_avg.lerp_(grad, 1 - beta1)
-        vv = vv * b2 + (1.0f - b2) * (gr * gr);                  // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+        mm = mm + w1 * (gr - mm);                                // exp_avg.lerp_(grad, 1 - beta1)
+        vv = vv * b2 + (w2 * gr) * gr;                           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2): (value * t1) * t2
         const float denom = sqrtf(vv) / bc2_sqrt + eps;
         pp = pp - step_size * (mm / denom);                      // param.addcdiv_(exp_avg, denom, value=-step_size)
         gg = 0.0f;                                               // zero_grad
@@ -100,8 +108,8 @@ int tef_l2_norm(const float *x, size_t n, void *scratch, float *out, float *step
     return tef::check_launch("norm kernels");
 }
 
-int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const float *norm, float max_norm, float lr,
-                       float beta1, float beta2, float eps, const float *step, void *stream)
+int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const float *norm, float max_norm, double lr,
+                       double beta1, double beta2, double eps, const float *step, void *stream)
 {
     if (!p || !g || !m || !v || !norm || !step) return tef::fail("tef_adam_clip_step: null pointer"), TEF_ERR_INVALID;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)

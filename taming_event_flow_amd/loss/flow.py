@@ -12,6 +12,7 @@ buffers, bookkeeping and the autograd boundary.  There is no PyTorch/CPU fallbac
 """
 
 import ctypes
+import weakref
 import sys
 
 import torch
@@ -105,7 +106,14 @@ class _Window:
         self.det = _SoA(B, device, res, hints[1])
         self.workspace = None
         self.scratch = None
+        self.leases = []          # weak references to the tokens of evaluations whose autograd graph still reads the buffers
         self.cfg = None
+
+
+class _Token:
+    """Lives exactly as long as the autograd context of one loss evaluation (weakly referenced by the window)."""
+
+    __slots__ = ("__weakref__",)
 
 
 class _CMLossFn(torch.autograd.Function):
@@ -125,8 +133,11 @@ class _CMLossFn(torch.autograd.Function):
             rc = lib.tef_smoothing_forward(ctypes.byref(cfg), win.flows.data_ptr(), ws, wt, win.scratch.data_ptr(),
                                            loss.data_ptr(), _lib.stream_ptr())
             _lib.check(rc, "tef_smoothing_forward")
-        # the context owns everything backward reads, so a later forward on the same window cannot clobber it
+        # the context owns everything backward reads, so a later forward on the same window cannot clobber it: while this
+        # evaluation's graph is alive its token is, and forward() takes fresh buffers instead of these (explicit ownership)
         ctx.win, ctx.cfg, ctx.workspace, ctx.scratch = win, cfg, win.workspace, win.scratch
+        ctx.token = _Token()
+        win.leases.append(weakref.ref(ctx.token))
         ctx.smooth = (ws, wt)
         return loss
 
@@ -341,12 +352,14 @@ class BaseEventWarping(torch.nn.Module):
             _lib.check(-1, "tef_loss_workspace_bytes")
         # the window keeps its workspace (0.7 GB at the BASELINE size) across evaluations; an autograd graph of an earlier
         # evaluation that is still alive holds a reference to the one it ran on, and then a fresh one is taken
-        if win.workspace is None or win.workspace.numel() != nbytes or sys.getrefcount(win.workspace) > 2:
+        win.leases = [r for r in win.leases if r() is not None]
+        leased = bool(win.leases)
+        if win.workspace is None or win.workspace.numel() != nbytes or leased:
             win.workspace = torch.empty((nbytes,), dtype=torch.uint8, device=win.flows.device)
         ws, wt = self._smooth_weights(P)
         if ws >= 0 or wt >= 0:
             nscr = lib.tef_smoothing_scratch_bytes(ctypes.byref(cfg))
-            if win.scratch is None or win.scratch.numel() != nscr or sys.getrefcount(win.scratch) > 2:
+            if win.scratch is None or win.scratch.numel() != nscr or leased:
                 win.scratch = torch.empty((nscr,), dtype=torch.uint8, device=win.flows.device)
         flat = [f for refs in win.flow_refs for f in refs]
         return _CMLossFn.apply(self, win, *flat)

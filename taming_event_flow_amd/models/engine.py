@@ -29,6 +29,7 @@ The flows then live on the side stream: whoever consumes them either works on th
 """
 
 import ctypes
+import weakref
 
 import torch
 
@@ -55,7 +56,9 @@ class _Tape:
 
 class PassEngine:
     def __init__(self, arch):
-        self.arch = arch
+        # weak: the architecture owns its engine; a strong back-reference would make every model a reference cycle that only
+        # the cycle collector — at whatever allocation it wakes up on, with streams and hipGraphs possibly in flight — frees
+        self._arch = weakref.ref(arch)
         self.plan = arch.plan
         self._ws = {}                 # one workspace per stream the engine launches on
         self.side_stream = None       # set: passes that record a graph run as two nodes on two streams (module docstring)
@@ -69,6 +72,29 @@ class PassEngine:
         self._zeros = {}
         self._layout = {}
         self._pending = []            # backward calls of the current window whose weight gradients are still deferred
+        self.last_pass_split = False  # whether the last run_pass left its flows on the side stream
+
+    @property
+    def arch(self):
+        a = self._arch()
+        if a is None:
+            raise RuntimeError("RecEVFlowNet pass engine used after its model was released")
+        return a
+
+    def close(self):
+        """Wait for the engine's streams and drop its device buffers (workspaces, cached zero states, unreduced weight
+        gradients).  Idempotent; the engine can be used again afterwards."""
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            for st in (self.side_stream, self.wgrad_stream):
+                if st is not None:
+                    st.synchronize()
+            torch.cuda.current_stream().synchronize()
+        for r in self._pending:
+            r.queued = False
+        self._pending = []
+        sm._DEFERRED_ENGINES.discard(self)
+        self._ws.clear()
+        self._zeros.clear()
 
     # ---- buffers -----------------------------------------------------------------------------------------------
     def workspace(self, nbytes, device):
@@ -428,6 +454,7 @@ class _DecFn(torch.autograd.Function):
 def run_pass(engine, x, states):
     """Differentiable pass when gradients are enabled, plain launches otherwise."""
     params = [p for p in engine.arch.parameters()]
+    engine.last_pass_split = False      # True: the flows of this pass live on the side stream (train.Trainer reads it)
     needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params) or
                                          any(s is not None and s.requires_grad for s in states))
     side = engine.side_stream
@@ -435,6 +462,7 @@ def run_pass(engine, x, states):
         if side is None or not engine.defer_join:       # (without gradients the split only pays when the caller overlaps)
             flows, new_states, _ = engine.forward(x, list(states), keep=False)
             return flows, new_states
+        engine.last_pass_split = True
         _, new_states, rec = engine.forward(x, list(states), keep=False, part=1)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -443,6 +471,7 @@ def run_pass(engine, x, states):
         return flows, new_states
     if side is not None and engine.arch.direct_grads and all(p.grad is not None and p.grad.is_contiguous()
                                                              for p in params if p.requires_grad):
+        engine.last_pass_split = True
         holder = []
         delay = engine.debug_delay or (0, 0)
         if delay[0]:

@@ -65,7 +65,9 @@ class FusedAdam:
         except ImportError:
             import _lib
         self._lib, self._ct = _lib, ctypes
-        self.bucket, self.lr, self.betas, self.eps = bucket, float(lr), betas, float(eps)
+        self.bucket = bucket
+        # one parameter group, like torch.optim.Adam over model.parameters(): schedulers write param_groups[0]["lr"]
+        self.param_groups = [{"params": list(bucket.params), "lr": float(lr), "betas": tuple(betas), "eps": float(eps)}]
         flat_g = bucket.flat
         self.flat_p = torch.empty_like(flat_g)
         o = 0
@@ -80,9 +82,51 @@ class FusedAdam:
         self.norm = torch.zeros((1,), dtype=torch.float32, device=flat_g.device)
         self.scratch = torch.empty((_lib.lib().tef_l2_norm_scratch_bytes(),), dtype=torch.uint8, device=flat_g.device)
 
-    def step(self, max_norm):
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        self.param_groups[0]["lr"] = float(value)
+
+    @property
+    def betas(self):
+        return self.param_groups[0]["betas"]
+
+    @property
+    def eps(self):
+        return self.param_groups[0]["eps"]
+
+    def zero_grad(self, set_to_none=False):
+        """Clear the flat gradient (the views stay: the kernels add into them).  set_to_none is refused: the pass engine
+        accumulates into the parameters' own .grad buffers."""
+        if set_to_none:
+            raise ValueError("FusedAdam keeps the flat gradient bucket: zero_grad(set_to_none=True) is not supported")
+        self.bucket.zero()
+
+    def state_dict(self):
+        """Adam's moments and step count (flat, in parameter order) + the group's hyper-parameters."""
+        return {"state": {"exp_avg": self.m.detach().clone(), "exp_avg_sq": self.v.detach().clone(),
+                          "step": self.step_count.detach().clone()},
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    def load_state_dict(self, sd):
+        st = sd["state"]
+        if st["exp_avg"].numel() != self.m.numel() or st["exp_avg_sq"].numel() != self.v.numel():
+            raise ValueError("FusedAdam.load_state_dict: moment buffers of a different parameter set")
+        self.m.copy_(st["exp_avg"].reshape(-1))
+        self.v.copy_(st["exp_avg_sq"].reshape(-1))
+        self.step_count.copy_(st["step"].reshape(-1))
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                self.param_groups[0][k] = tuple(v) if k == "betas" else v
+
+    def step(self, max_norm=None):
         """Clip the (already reduced) flat gradient to `max_norm` (None: no clipping), apply Adam, clear the gradient.
-        -> the gradient's global norm before clipping (a 1-element device tensor, overwritten by the next step)."""
+        -> the gradient's global norm before clipping (a 1-element device tensor, overwritten by the next step).  The
+        learning rate is read from param_groups[0]["lr"] at every call (a captured window holds the value it was captured
+        with: re-capture after changing it)."""
         lib, n = self._lib.lib(), self.bucket.flat.numel()
         st = self._lib.stream_ptr()
         self._lib.check(lib.tef_l2_norm(self.bucket.flat.data_ptr(), n, self.scratch.data_ptr(), self.norm.data_ptr(),

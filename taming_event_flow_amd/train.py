@@ -8,6 +8,7 @@ HDF5 loader (dataloader/h5.py needs h5py/cv2 and a dataset; out of scope, SURVEY
 
 import numpy as np
 import os
+import sys
 
 import torch
 
@@ -99,6 +100,24 @@ class CapturedWindow:
 
     __call__ = replay
 
+    def close(self):
+        """Wait for the last replay, then release the hipGraphs (and with them their private memory pool) in a fixed
+        order.  Idempotent.  Dropping the object without calling this does the same from __del__."""
+        if self.graph is None and self.graph_tail is None:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+        self.graph_tail = None
+        self.graph = None
+        self.inputs = self.states = None
+
+    def __del__(self):
+        if not sys.is_finalizing():
+            try:
+                self.close()
+            except Exception:      # noqa: BLE001  (a destructor must not raise)
+                pass
+
 
 class Trainer:
     """model + loss + optimiser wired like reference train_flow.py:60-70, plus the DP gradient bucket."""
@@ -126,7 +145,9 @@ class Trainer:
         if (config["optimizer"]["name"] == "Adam" and not extra and torch.device(device).type == "cuda"
                 and os.environ.get("TEF_TORCH_ADAM", "0") != "1"):
             self.fused_opt = parallel.FusedAdam(self.bucket, config["optimizer"]["lr"])
-            self.optimizer = None
+            # the optimiser-like surface callers reach for (param_groups[0]["lr"] for schedulers, state_dict /
+            # load_state_dict for checkpoints, zero_grad); TEF_TORCH_ADAM=1 puts torch.optim.Adam here instead
+            self.optimizer = self.fused_opt
         else:
             self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
@@ -147,6 +168,28 @@ class Trainer:
             if self.deferred_wgrad and group > 0:
                 self.wgrad_stream = torch.cuda.Stream(device=device)
                 eng.wgrad_stream, eng.wgrad_group = self.wgrad_stream, group
+
+    def close(self):
+        """Wait for every stream the trainer launched on and release the engine's device buffers in a fixed order.
+        Idempotent; also runs from __del__, so that a trainer dropped with work in flight (or collected late) never has
+        its streams' buffers released under a running kernel."""
+        eng = getattr(getattr(self.model, "arch", None), "_engine", None) if getattr(self, "model", None) is not None else None
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            for st in (self.dec_stream, self.wgrad_stream):
+                if st is not None:
+                    st.synchronize()
+            torch.cuda.current_stream().synchronize()
+        if eng is not None:
+            eng.close()
+            eng.side_stream = eng.wgrad_stream = None
+        self.dec_stream = self.wgrad_stream = None
+
+    def __del__(self):
+        if not sys.is_finalizing():
+            try:
+                self.close()
+            except Exception:      # noqa: BLE001
+                pass
 
     def reset(self):
         """train_flow.py:83-87"""
@@ -259,6 +302,10 @@ class Trainer:
         for k in ("event_list", "event_list_pol_mask", "d_event_list", "d_event_list_pol_mask"):
             if isinstance(inputs[k], torch.Tensor) and inputs[k].is_cuda:
                 inputs[k].record_stream(self.dec_stream)       # (the caller may drop them before the side stream read them)
+        if not arch.engine.last_pass_split:
+            # the pass fell back to one node on THIS stream (a parameter without a contiguous .grad, e.g. after an external
+            # zero_grad(set_to_none=True)): the flows and the loader's tensors are produced here, the side stream must see them
+            self.dec_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.dec_stream):
             self.loss_function.update(flows, inputs["event_list"], inputs["event_list_pol_mask"], inputs["d_event_list"],
                                       inputs["d_event_list_pol_mask"])

@@ -22,6 +22,8 @@ def _collect_between_tests():
     intermittent glibc abort ("corrupted size vs. prev_size", ~1 run in 10, in pytest's own session-finish code after every
     test had passed) went away with this; it never showed outside pytest, where the same objects are released in order."""
     yield
+    if os.environ.get("TEF_TEST_NO_COLLECT") == "1":      # tools/pytest_teardown_probe.sh: look for the abort, do not avoid it
+        return
     import gc
 
     gc.collect()

@@ -389,8 +389,9 @@ def test_multi_stream_window_matches_one_stream(warping, scales, smooth, graph):
         if graph:
             del win
         del tr, src
-        gc.collect()
-        torch.cuda.synchronize()
+        if os.environ.get("TEF_TEST_NO_COLLECT") != "1":      # (tools/pytest_teardown_probe.sh switches the tidy-up off)
+            gc.collect()
+            torch.cuda.synchronize()
         return np.array(out)
 
     one, multi = run(False), run(True)
@@ -430,8 +431,9 @@ def test_window_cut_short_by_new_seq():
             if stepped:
                 out += [float(tr.last_loss.item()), float(tr.last_grad_norm.item())]
         del tr, src
-        gc.collect()
-        torch.cuda.synchronize()
+        if os.environ.get("TEF_TEST_NO_COLLECT") != "1":
+            gc.collect()
+            torch.cuda.synchronize()
         return np.array(out)
 
     one, multi = run(False), run(True)
