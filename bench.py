@@ -280,6 +280,18 @@ def main():
 
     one = torch.ones((), dtype=torch.float32, device=dev)
 
+    # loss and gradient of window 0, once, untimed: the number `cpu_baseline.loss` (the same window through the CPU port) is
+    # comparable with, and — when the window is the one tests/golden/make_golden.py --bench-windows recorded from the
+    # reference (the default workload on rank 0) — its distance to the reference's own result
+    loss_w0, parity = None, None
+    if a.warping == "Iterative":
+        L0, fl0 = staged[0]
+        l0 = L0()
+        g0 = torch.autograd.grad(l0, [f for row in fl0 for f in row], grad_outputs=one)
+        loss_w0 = float(l0.item())
+        parity = parity_vs_golden(a, rank, loss_w0, g0, P, F)
+        del l0, g0
+
     def barrier():
         watchdog()           # a phase boundary: re-arm
         if dist:
@@ -549,7 +561,10 @@ def main():
                                    "hipGraph replay of the step") +
                                   ("; the last %d steps eager with per-kernel HIP events" % nprof
                                    if not a.no_kernel_events else "")) if graphs else "eager"},
-            "loss": round(loss_val, 6),
+            # window 0 (evaluated once before the timed region; `cpu_baseline.loss` is the same window through the CPU port)
+            "loss": round(loss_w0 if loss_w0 is not None else loss_val, 6),
+            "loss_last_timed_step": round(loss_val, 6),      # window (steps - 1) % windows
+            "parity_vs_golden": parity,
             "ms_per_step_hip_event_median": round(step_ms_median, 4),
             "ms_update_per_window": round(1e3 * t_update, 3),
             "ms_update_per_window_device": round(1e3 * t_update_dev, 3),      # HIP events around the P update() calls
@@ -1027,17 +1042,45 @@ def cpu_baseline(a, win, threads=None, seconds=None, batch=None):
            for k in win}
     w = oracle.Window(sub["flows"], sub["ev"], sub["pm"], sub["dev"], sub["dpm"], S=1, mode="two")
     w.iterative(backward=True)                      # untimed: thread pool start-up, page faults
-    reps, dt = 0, 0.0
-    while dt < (seconds or a.cpu_seconds) and reps < 1000:
+    times = []
+    while (sum(times) < (seconds or a.cpu_seconds) or len(times) < 5) and len(times) < 1000:      # at least 5 repetitions
         t0 = time.perf_counter()
         loss, _ = w.iterative(backward=True)
-        dt += time.perf_counter() - t0
-        reps += 1
-    ev = reps * bs * a.passes * (a.events + a.detached)
-    return {"value": round(ev / dt, 1), "unit": "events/s", "cores": nthr, "kind": "port",
-            "sample": f"{reps} x 1 window, B={bs}, same P/F/N/resolution as the GPU workload, fwd+bwd, {dt:.1f} s",
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    ev1 = bs * a.passes * (a.events + a.detached)
+    med = times[len(times) // 2]
+    return {"value": round(ev1 / med, 1), "unit": "events/s", "cores": nthr, "kind": "port",
+            "sample": f"{len(times)} x 1 window (window 0), B={bs}, same P/F/N/resolution as the GPU workload, fwd+bwd, "
+                      f"{sum(times):.1f} s; value = events / MEDIAN window time",
+            "window_ms": {"min": round(1e3 * times[0], 2), "median": round(1e3 * med, 2), "max": round(1e3 * times[-1], 2)},
+            "value_at_min": round(ev1 / times[0], 1),
             "loss": round(float(loss), 6)}
 
+
+def parity_vs_golden(a, rank, loss, grads, P, F):
+    """Distance of this run's window 0 to what the REFERENCE returned for it (tests/golden/bench_window_0.npz: loss, the
+    stride-4 lattice of d loss / d flow).  None when the workload is not the recorded one or the fixture is absent."""
+    import numpy as np
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "bench_window_0.npz")
+    if rank != 0 or not os.path.exists(path):
+        return None
+    z = np.load(path)
+    meta = json.loads(str(z["meta"]))
+    same = (meta["B"] == a.batch and [meta["H"], meta["W"]] == list(a.res) and meta["P"] == a.passes and meta["F"] == a.heads
+            and meta["n_grad"] == a.events and a.detached == 0 and a.flow == "smooth" and a.presort == "none" and meta["seed"] == 0)
+    if not same:
+        return None
+    import torch
+
+    s = meta["stride"]
+    lat = torch.stack([torch.stack([grads[t * F + i][..., ::s, ::s] for i in range(F)]) for t in range(P)]).cpu().numpy()
+    ref = z["dflows_lattice"]
+    return {"fixture": "tests/golden/bench_window_0.npz (reference loss/flow.py Iterative, CPU PyTorch fp32)",
+            "loss_reference": float(z["loss"]),
+            "loss_rel_err": float(abs(loss - float(z["loss"])) / abs(float(z["loss"]))),
+            "dflow_lattice_max_rel_err": float(np.abs(lat.astype(np.float64) - ref).max() / np.abs(ref).max())}
 
 if __name__ == "__main__":
     main()

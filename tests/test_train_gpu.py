@@ -437,6 +437,7 @@ def test_window_cut_short_by_new_seq():
         return np.array(out)
 
     one, multi = run(False), run(True)
+    print("cut-short window, one stream:", one, "multi-stream:", multi)
     assert len(one) == 4 and np.isfinite(multi).all()
     err = np.abs(multi - one) / np.abs(one)
     assert (err[0::2] <= 1e-6).all() and (err[1::2] <= 1e-5).all(), (one, multi)

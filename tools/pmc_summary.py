@@ -17,6 +17,7 @@ KERNELS = {                      # kernel symbol prefix -> bench.py name
     "iter_warp_kernel": "warp", "linear_warp_kernel": "warp", "splat_stats_kernel": "iwe_splat",
     "loss_reduce_kernel": "loss_reduce", "iter_chain_bwd_kernel": "chain_bwd",
     "linear_bwd_kernel": "chain_bwd", "dflow_splat_kernel": "dflow_splat", "pack_flow_kernel": "pack_flow",
+    "grad_planes_kernel": "grad_planes", "image_count_kernel": "image_count", "mag_reduce_kernel": "mag_reduce",
 }
 
 
