@@ -117,8 +117,6 @@ def algorithmic_bytes(a, delta):
         "chain_bwd": FB * N * (P * 24 + planes * 8 + vecs * 8) + nimg * FB * 2 * HW * 8 + maps,
         # per (grad event, head, reachable map): vector 8 + position 8; gradient maps written once
         "dflow_splat": FB * N * vecs * 16 + maps,
-        # (A, C + eps) in, (dC, dT) out per pixel and polarity of every image
-        "grad_planes": nimg * FB * 2 * HW * 16,
     }, splats
 
 

@@ -763,7 +763,7 @@ __device__ __forceinline__ void band_stats(const double *planes, size_t plane_sz
     const double *cp = planes, *tp = planes + plane_sz;
     auto pixel = [&](float c, float t, float2 &o) {
         float a = t / (c + kEps);                     // :727
-        o = make_float2(a, c + kEps);                 // (A, C + eps): what the division's backward needs (grad_planes_kernel)
+        o = make_float2(a, c + kEps);                 // (A, C + eps): what the division's backward needs (pixel_grads, K6)
         acc += a * a;                                 // :122-123
         return (uint8_t)(c != 0.0f);                  // :125 (masks are non-negative: C_pos + C_neg != 0 <=> either is)
     };
@@ -1156,60 +1156,55 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(Win w, const double *_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Backward, first launch: the gradient of every image's focus term w.r.t. its two images, PER PIXEL and in autograd's own
-// arithmetic.  The reference never forms the closed form 2 A (tau - A) / (C + eps): the backward of
-// iwe_ts / (iwe + 1e-9) (loss/flow.py:727) hands dT = gA / (C + eps) to the T image and dC = -gA * ((T / (C + eps)) /
-// (C + eps)) to the C image, with gA = g * (2 A) from the square (:122) and g the upstream gradient after the scalar
-// divisions of :740-741, :731-732 and :127 — ((((grad_out / F) / S) / D) / 2^s) / n, D = 2 delta + 1 (Iterative) or 2
-// (Linear), true fp32 divisions in that order — and an event's corner weight then collects dC + dT * tau through the four
-// scatters.  Where a pixel holds a single event, tau - A is ~1e-9 / C and dC, dT * tau cancel to a 1e-7 share of
-// themselves: the closed form (more accurate) and the reference then differ by the reference's own rounding, 1 / C times
-// larger than the result — 1.4e-5 of the largest gradient on the BASELINE window, 1e-3 on windows of a few events.  With
-// the same operations on the same bits the difference is the images' summation order only.
-//   ar [(q * 2 + c)][H*W] float2 = (A, C + eps) from K2;  gr = (dC, dT), same layout;  q = image * F*B + (head, sample)
+// The gradient of an image's focus term w.r.t. its two images, PER PIXEL and in autograd's own arithmetic.  The reference
+// never forms the closed form 2 A (tau - A) / (C + eps): the backward of iwe_ts / (iwe + 1e-9) (loss/flow.py:727) hands
+// dT = gA / (C + eps) to the T image and dC = -gA * ((T / (C + eps)) / (C + eps)) to the C image, with gA = g * (2 A)
+// from the square (:122) and g the upstream gradient after the scalar divisions of :740-741, :731-732 and :127 —
+// ((((grad_out / F) / S) / D) / 2^s) / n, D = 2 delta + 1 (Iterative) or 2 (Linear), true fp32 divisions in that order —
+// and an event's corner weight then collects dC + dT * tau through the four scatters.  Where a pixel holds a single event,
+// tau - A is ~1e-9 / C and dC, dT * tau cancel to a 1e-7 share of themselves: the closed form (more accurate) and the
+// reference then differ by the reference's own rounding, 1 / C times larger than the result — 1.4e-5 of the largest
+// gradient on the BASELINE window, 1e-3 on windows of a few events.  With the same operations on the same bits the
+// difference is the images' summation order only.
+// The divisions are the compiler's IEEE sequence (correctly rounded, like the CPU's): K6 is bound by its L1 gathers and
+// has the vector-ALU slots for them (as a separate pass over the (A, C + eps) planes, read + written once more, the same
+// arithmetic cost 31 us and 185 MB per step).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grad_planes_kernel(Win w, const float2 *__restrict__ ar,
-                                                          const float *__restrict__ stats,
-                                                          const float *__restrict__ grad_out, float2 *__restrict__ gr,
-                                                          int blocks_per_image)
+// upstream gradient of one image's per-sample focus term: the reference's division chain (n = active pixels + 1e-9, or 1)
+__device__ __forceinline__ float image_upstream(const Win &w, float gout, int s, float delta, float n)
 {
-    const int q = blockIdx.x / blocks_per_image, part = blockIdx.x - q * blocks_per_image;
-    const int FB = w.F * w.B;
-    const Img im = decode_image(w, q / FB);
-    float g = grad_out[0] / (float)w.F;               // loss /= num_flows            (:741 / :402)
+    float g = gout / (float)w.F;                      // loss /= num_flows            (:741 / :402)
     g = g / (float)w.S;                               // loss /= scales_loss          (:740 / :401)
-    g = g / (w.kind == TEF_KIND_ITERATIVE ? 2.0f * im.delta + 1.0f : 2.0f);      // deblurring points per window (:732 / :397)
-    g = g / (float)(1 << im.s);                       // windows of the scale         (:731 / :396)
-    g = g / stats[(size_t)q * 2 + 1];                 // active pixels + 1e-9 (or 1)  (:127)
-    const size_t n2 = (size_t)(w.H * w.W);            // pixel pairs of the image's two planes
-    const float4 *src = reinterpret_cast<const float4 *>(ar + (size_t)q * 2 * n2);
-    float4 *dst = reinterpret_cast<float4 *>(gr + (size_t)q * 2 * n2);
-    auto conv = [&](float a, float ce, float &dc, float &dt) {
-        const float ga = g * (2.0f * a);              // pow backward: grad * (2 * self)
-        dt = ga / ce;                                 // div backward, self:  grad / other
-        dc = -(ga * (a / ce));                        // div backward, other: -grad * ((self / other) / other), self / other = A
-    };
-    for (size_t k = (size_t)part * blockDim.x + threadIdx.x; k < n2; k += (size_t)blocks_per_image * blockDim.x) {
-        const float4 v = src[k];
-        float4 o;
-        conv(v.x, v.y, o.x, o.y);
-        conv(v.z, v.w, o.z, o.w);
-        dst[k] = o;
-    }
+    g = g / (w.kind == TEF_KIND_ITERATIVE ? 2.0f * delta + 1.0f : 2.0f);      // deblurring points per window (:732 / :397)
+    g = g / (float)(1 << s);                          // windows of the scale         (:731 / :396)
+    return g / n;                                     //                              (:127)
+}
+// (A, C + eps) of a pixel -> d/dw of one corner: dC + dT * tau.  A corner outside the image was loaded as (0, 0): 0.
+__device__ __forceinline__ void pixel_grads(float a, float ce, float g, float &dc, float &dt)
+{
+    const float ga = g * (2.0f * a);                  // pow backward: grad * (2 * self)
+    dt = ga / ce;                                     // div backward, self:  grad / other
+    dc = -(ga * (a / ce));                            // div backward, other: -grad * ((self / other) / other), self / other = A
+}
+__device__ __forceinline__ float2 pixel_grads_guarded(float2 p, float g)
+{
+    float dc, dt;
+    pixel_grads(p.x, p.y != 0.0f ? p.y : 1.0f, g, dc, dt);
+    return make_float2(dc, dt);
 }
 
 // ---------------------------------------------------------------------------------------------
 // d(coef * image loss)/d position of one event at one image:
-//   dl/dw_k = sum_c (dC_c m_c) + (sum_c dT_c m_c) * tau     (grad_planes_kernel's planes; autograd's order for one-hot masks)
+//   dl/dw_k = sum_c (dC_c m_c) + (sum_c dT_c m_c) * tau     (pixel_grads on K2's (A, C + eps) planes; autograd's order for one-hot masks)
 // followed by the derivative of the bilinear hat weights.
 // ---------------------------------------------------------------------------------------------
 // FAST (the backward of the single-scale Iterative loss): delta is kernel-invariant there, an integer number of passes,
 // so tau takes the cheaper exact form of the same division (div_by_const).
 // INTERIOR (decided per wavefront by the caller): all four corners inside the image, the right column adjacent to the
 // left one and a single polarity — the validity selects, the fp32 corner case and the second-polarity branch drop out.
-// pos: the image's positive-polarity (dC, dT) plane (the negative one follows it)
+// pos: the image's positive-polarity (A, C + eps) plane (the negative one follows it); g = image_upstream of the image
 template <bool FAST = false, bool INTERIOR = false>
-__device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__restrict__ pos, float tref,
+__device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__restrict__ pos, float g, float tref,
                                                 float delta, const Splat &sp, float ts, float mp, float mn)
 {
     const int HW = H * W;
@@ -1225,8 +1220,11 @@ __device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__re
         for (int k = 0; k < 2; ++k) r[k] = *reinterpret_cast<const f32x4_a8 *>(pl + sp.iy[k] * w.W + sp.ix[0]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const float dw0 = r[k].x * m1 + (r[k].y * m1) * tau;
-            const float dw1 = r[k].z * m1 + (r[k].w * m1) * tau;
+            float c0, t0, c1, t1;
+            pixel_grads(r[k].x, r[k].y, g, c0, t0);
+            pixel_grads(r[k].z, r[k].w, g, c1, t1);
+            const float dw0 = c0 * m1 + (t0 * m1) * tau;
+            const float dw1 = c1 * m1 + (t1 * m1) * tau;
             gy += dw0 * (sp.sy[k] * sp.wx[0]);
             gx += dw0 * (sp.wy[k] * sp.sx[0]);
             gy += dw1 * (sp.sy[k] * sp.wx[1]);
@@ -1240,7 +1238,7 @@ __device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__re
     const bool hp = mp != 0.0f, both = hp & (mn != 0.0f);
     const float2 *pl = hp ? pos : neg;
     const float m1 = hp ? mp : mn;
-    float2 a0[2], a1[2];          // (dC, dT) at [row][left / right]
+    float2 a0[2], a1[2];          // (A, C + eps) at [row][left / right]
     int i1s[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -1254,17 +1252,20 @@ __device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__re
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         if (i1s[r] >= 0) a1[r] = pl[i1s[r]];            // fp32 corner case: floor(x + 1) == floor(x) + 2
-        float c0 = a0[r].x * m1, t0 = a0[r].y * m1, c1 = a1[r].x * m1, t1 = a1[r].y * m1;
+        const float2 p0 = pixel_grads_guarded(a0[r], g), p1 = pixel_grads_guarded(a1[r], g);
+        float c0 = p0.x * m1, t0 = p0.y * m1, c1 = p1.x * m1, t1 = p1.y * m1;
         if (both) {
             int iy = sp.iy[r];
             bool vy = (iy >= 0) & (iy < w.H);
             float2 n0 = make_float2(0.f, 0.f), n1 = n0;
             if (vy && vx0) n0 = neg[iy * w.W + sp.ix[0]];
             if (vy && vx1) n1 = neg[iy * w.W + sp.ix[1]];
+            n0 = pixel_grads_guarded(n0, g);
+            n1 = pixel_grads_guarded(n1, g);
             c0 += n0.x * mn; t0 += n0.y * mn;
             c1 += n1.x * mn; t1 += n1.y * mn;
         }
-        // invalid corners read (dC, dT) = (0, 0): their dw is 0
+        // invalid corners read (A, C + eps) = (0, 0): their dw is 0
         const float dw0 = c0 + t0 * tau, dw1 = c1 + t1 * tau;
         gy += dw0 * (sp.sy[r] * sp.wx[0]);
         gx += dw0 * (sp.wy[r] * sp.sx[0]);
@@ -1274,32 +1275,41 @@ __device__ __forceinline__ float2 image_grad_at(int H, int W, const float2 *__re
     return make_float2(gy, gx);
 }
 
+// s: the image's temporal scale; gout: d (total loss) / d (this loss)
 template <bool FAST = false, bool INTERIOR = false>
-__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ gr, int ib, int j, float tref,
-                                             float delta, const Splat &sp, float ts, float mp, float mn)
+__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar, const float *__restrict__ stats,
+                                             float gout, int s, int ib, int j, float tref, float delta, const Splat &sp,
+                                             float ts, float mp, float mn)
 {
     const size_t q = (size_t)j * (w.F * w.B) + ib;
-    return image_grad_at<FAST, INTERIOR>(w.H, w.W, gr + q * 2 * (size_t)(w.H * w.W), tref, delta, sp, ts, mp, mn);
+    const float g = image_upstream(w, gout, s, w.kind == TEF_KIND_ITERATIVE ? delta : 0.0f, stats[q * 2 + 1]);
+    return image_grad_at<FAST, INTERIOR>(w.H, w.W, ar + q * 2 * (size_t)(w.H * w.W), g, tref, delta, sp, ts, mp, mn);
 }
 
 // The same gradient when the position is STRICTLY inside its pixel cell and the cell inside the frame (decided per
 // wavefront by the caller), one polarity with mask value 1, one temporal scale: the hat slopes are exactly -1 (near
 // corner) and +1 (far corner), so the sign / tie logic of hat() and the slope products drop out.  Same operations on the
-// same values in the same order as image_grad<true, true> (a product with +-1 is exact).  r0 / r1: the (dC, dT) pairs of
-// the cell's upper and lower pixel rows (loaded by the caller, one chain step ahead).
-__device__ __forceinline__ float2 cell_grad(const f32x4_a8 r0, const f32x4_a8 r1, float tau, float wy0, float wy1,
+// same values in the same order as image_grad<true, true> (a product with +-1 is exact).  r0 / r1: the (A, C + eps) pairs
+// of the cell's upper and lower pixel rows (loaded by the caller, one chain step ahead); g = image_upstream of the image.
+__device__ __forceinline__ float corner_dw(float a, float ce, float g, float tau)
+{
+    float dc, dt;
+    pixel_grads(a, ce, g, dc, dt);
+    return dc + dt * tau;
+}
+__device__ __forceinline__ float2 cell_grad(const f32x4_a8 r0, const f32x4_a8 r1, float g, float tau, float wy0, float wy1,
                                             float wx0, float wx1)
 {
     float gy = 0.0f, gx = 0.0f;
     {
-        const float dw0 = r0.x + r0.y * tau, dw1 = r0.z + r0.w * tau;
+        const float dw0 = corner_dw(r0.x, r0.y, g, tau), dw1 = corner_dw(r0.z, r0.w, g, tau);
         gy += dw0 * (-wx0);
         gx += dw0 * (-wy0);
         gy += dw1 * (-wx1);
         gx += dw1 * wy0;
     }
     {
-        const float dw0 = r1.x + r1.y * tau, dw1 = r1.z + r1.w * tau;
+        const float dw0 = corner_dw(r1.x, r1.y, g, tau), dw1 = corner_dw(r1.z, r1.w, g, tau);
         gy += dw0 * wx0;
         gx += dw0 * (-wy1);
         gy += dw1 * wx1;
@@ -1309,15 +1319,17 @@ __device__ __forceinline__ float2 cell_grad(const f32x4_a8 r0, const f32x4_a8 r1
 }
 
 template <bool FAST = false>
-__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ gr, int ib, int j, float tref,
-                                             float delta, float2 p, float ts, float mp, float mn)
+__device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restrict__ ar, const float *__restrict__ stats,
+                                             float gout, int s, int ib, int j, float tref, float delta, float2 p, float ts,
+                                             float mp, float mn)
 {
     Splat sp = make_splat(p.x, p.y);
-    return image_grad<FAST, false>(w, gr, ib, j, tref, delta, sp, ts, mp, mn);
+    return image_grad<FAST, false>(w, ar, stats, gout, s, ib, j, tref, delta, sp, ts, mp, mn);
 }
 
 // gradient w.r.t. the event position at tref = k, summed over the temporal scales that use it (Iterative)
-__device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 *__restrict__ gr, int ib, uint32_t bits,
+__device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 *__restrict__ ar,
+                                                     const float *__restrict__ stats, float gout, int ib, uint32_t bits,
                                                      int t, int k, float2 p, float ts, float mp, float mn)
 {
     float2 g = make_float2(0.0f, 0.0f);
@@ -1330,7 +1342,7 @@ __device__ __forceinline__ float2 iter_position_grad(const Win &w, const float2 
         int le = max(lo, k - delta), he = min(hi, k + delta);
         if (t < le || t >= he) continue;
         int j = w.img_base[s] + wi * (scale + 1) + (k - lo);
-        float2 a = image_grad(w, gr, ib, j, (float)k, (float)delta, p, ts, mp, mn);
+        float2 a = image_grad(w, ar, stats, gout, s, ib, j, (float)k, (float)delta, p, ts, mp, mn);
         g.x += a.x;
         g.y += a.y;
     }
@@ -1391,7 +1403,9 @@ template <bool ONE>
 __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
                                                              const float2 *__restrict__ traj,
                                                              const uint2 *__restrict__ meta,
-                                                             const float2 *__restrict__ gr,
+                                                             const float2 *__restrict__ ar,
+                                                             const float *__restrict__ stats,
+                                                             const float *__restrict__ grad_out,
                                                              float2 *__restrict__ cyx,
                                                              uint32_t *__restrict__ cmax, int chunks)
 {
@@ -1426,6 +1440,7 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     int kb = (int)((mv >> 8) & 0xffu) - 1, kf = (int)((mv >> 16) & 0xffu);
     size_t o = (size_t)b * g.cap + sl;
     float ts = __uint_as_float(mv_ts.y), mp = g.mp[o], mn = g.mn[o];
+    const float gout = grad_out[0];
     const float2 *tr = traj + (size_t)ib * (w.nplanes + 1) * w.Mt + sl;
     float c0y = 0.0f, c0x = 0.0f;
 
@@ -1443,10 +1458,12 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     const int ks_f = bits ? min(min(P, kf - 1), k_top) : t, ks_b = bits ? max(max(0, kb + 1), k_bot) : t + 1;
     // gradient w.r.t. the position at tref = k
     const float one_delta = (float)reach;
+    // ONE: the upstream gradient of every image up to its pixel count (the reference's division chain, scale 0)
+    const float one_g4 = ((gout / (float)w.F) / (float)w.S) / (2.0f * one_delta + 1.0f);
     auto pos_grad = [&](int k, float2 p) -> float2 {
-        if (!ONE) return iter_position_grad(w, gr, ib, bits, t, k, p, ts, mp, mn);
+        if (!ONE) return iter_position_grad(w, ar, stats, gout, ib, bits, t, k, p, ts, mp, mn);
         if (t < k - reach || t >= k + reach) return make_float2(0.0f, 0.0f);      // window [0, P], delta = reach
-        return image_grad<true>(w, gr, ib, w.img_base[0] + k, (float)k, one_delta, p, ts, mp, mn);
+        return image_grad<true>(w, ar, stats, gout, 0, ib, w.img_base[0] + k, (float)k, one_delta, p, ts, mp, mn);
     };
     // (the fast form of a step also wants the event's mask value to be exactly 1: a product the reference makes, exact then)
     const bool one_pol = !((mp != 0.0f) & (mn != 0.0f)) & (((mp != 0.0f) ? mp : mn) == 1.0f);
@@ -1518,12 +1535,13 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                 const f32x4_a8 q1 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(fm, (fo + (uint32_t)W) * 8u));
                 if (in_reach(k)) {
                     const size_t q = (size_t)(w.img_base[0] + k) * FB + ib;
-                    const float2 *pl = gr + uniform_off(q * 2 * (size_t)(H * W));
+                    const float gimg = one_g4 / stats[q * 2 + 1];
+                    const float2 *pl = ar + uniform_off(q * 2 * (size_t)(H * W));
                     const uint32_t po = ((mp != 0.0f) ? 0u : (uint32_t)(H * W)) + (act ? (uint32_t)(__mul24(iy0, W) + ix0) : 0u);
                     const f32x4_a8 r0 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(pl, po * 8u));
                     const f32x4_a8 r1 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(pl, (po + (uint32_t)W) * 8u));
                     const float tau = 1.0f - div_by_const(fabsf((float)k - ts), rdelta);
-                    gk = cell_grad(r0, r1, tau, 1.0f - dy, wy1, 1.0f - dx, wx1);
+                    gk = cell_grad(r0, r1, gimg, tau, 1.0f - dy, wy1, 1.0f - dx, wx1);
                 }
                 Quad2 q;
                 q.v00 = make_float2(q0.x, q0.y); q.v01 = make_float2(q0.z, q0.w);
@@ -1629,7 +1647,9 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
 __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const float2 *__restrict__ traj,
                                                          const uint2 *__restrict__ meta,
-                                                         const float2 *__restrict__ gr, float2 *__restrict__ cyx,
+                                                         const float2 *__restrict__ ar,
+                                                         const float *__restrict__ stats,
+                                                         const float *__restrict__ grad_out, float2 *__restrict__ cyx,
                                                          uint32_t *__restrict__ cmax, int chunks)
 {
     int ib, chunk;
@@ -1644,6 +1664,7 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
         size_t o = (size_t)b * g.cap + sl;
         float ts = g.ts[o], mp = g.mp[o], mn = g.mn[o];
         int t = g.bin[sl];
+        const float gout = grad_out[0];
         const float2 *tr = traj + (size_t)ib * (w.nplanes + 1) * w.Mt + sl;
         for (int s = 0; s < w.S; ++s) {
             if (!((bits >> s) & 1u)) continue;
@@ -1653,7 +1674,7 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(Win w, Events g, const 
                 float tref = (float)(e ? lo : hi);
                 int j = w.img_base[s] + wi * 2 + e;
                 float2 p = tr[(size_t)(2 * s + e) * w.Mt];
-                float2 gp = image_grad(w, gr, ib, j, tref, (float)scale, p, ts, mp, mn);
+                float2 gp = image_grad(w, ar, stats, gout, s, ib, j, tref, (float)scale, p, ts, mp, mn);
                 gy += (tref - ts) * gp.x;
                 gx += (tref - ts) * gp.y;
             }
@@ -2138,7 +2159,7 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, yr, ar, gr, nz, counts, stats, parts, queue, cmax, wmax, cyx, bad, total;
+    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cyx, bad, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2233,7 +2254,6 @@ Layout make_layout(const Win &w)
     L.meta = o;   o += align_up(FB * (size_t)w.Mt * sizeof(uint2));
     L.yr = o;     o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.nrow * sizeof(float2));
     L.ar = o;     o += align_up(img * sizeof(float2));
-    L.gr = o;     o += align_up(img * sizeof(float2));      // (dC, dT) planes of the backward (a second backward finds `ar` intact)
     L.stats = o;  o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
     L.nz = o;     o += align_up(img * sizeof(uint8_t));
     L.counts = o; o += align_up((size_t)w.nimg * FB * sizeof(double));
@@ -2471,7 +2491,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     char *ws = (char *)workspace;
     float2 *traj = (float2 *)(ws + L.traj);
     uint2 *meta = (uint2 *)(ws + L.meta);
-    float2 *ar = (float2 *)(ws + L.ar), *gr = (float2 *)(ws + L.gr);
+    float2 *ar = (float2 *)(ws + L.ar);
     float *stats = (float *)(ws + L.stats);
     float2 *cyx = (float2 *)(ws + L.cyx);
     uint32_t *cmax = (uint32_t *)(ws + L.cmax), *wmax = (uint32_t *)(ws + L.wmax);
@@ -2479,22 +2499,17 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     Events g = to_events(grad);
     const int FB = w.F * w.B;
     if (w.M > 0) {
-        // (A, C + eps) -> (dC, dT) per pixel, in autograd's arithmetic; 2 pixels per thread, ~8 such sweeps per block
-        const int per_image = std::max(1, (int)(((size_t)w.H * w.W + 2047) / 2048));
-        TEF_LAUNCH_TIMED(tef::PROF_GRAD_PLANES, grad_planes_kernel, dim3((unsigned)(w.nimg * FB * per_image)), dim3(256), 0, st, w,
-                         ar, stats, grad_out, gr, per_image);
-        if (int rc = tef::check_launch("grad_planes_kernel")) return rc;
         int chunks = (w.M + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
         if (w.kind == TEF_KIND_ITERATIVE && w.S == 1)
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, gr,
-                             cyx, wmax, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+                             stats, grad_out, cyx, wmax, chunks);
         else if (w.kind == TEF_KIND_ITERATIVE)
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, gr,
-                             cyx, wmax, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+                             stats, grad_out, cyx, wmax, chunks);
         else
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, gr, cyx, wmax,
-                             chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
+                             grad_out, cyx, wmax, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
     TEF_LAUNCH_TIMED(tef::PROF_STATS, mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax,
