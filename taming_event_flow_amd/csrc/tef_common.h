@@ -18,7 +18,8 @@ int check_launch(const char *kernel);
 // around each kernel while enabled; zero cost when disabled.
 enum ProfSlot {
     PROF_PACK = 0, PROF_WARP, PROF_SPLAT, PROF_STATS, PROF_REDUCE, PROF_CHAIN_BWD, PROF_DFLOW,
-    PROF_SMOOTH_FWD, PROF_SMOOTH_BWD, PROF_ENCODE, PROF_CONV_FWD, PROF_CONV_DGRAD, PROF_CONV_WGRAD, PROF_COUNT, PROF_NSLOTS
+    PROF_SMOOTH_FWD, PROF_SMOOTH_BWD, PROF_ENCODE, PROF_CONV_FWD, PROF_CONV_DGRAD, PROF_CONV_WGRAD, PROF_COUNT, PROF_CHAIN_BWD_REST,
+    PROF_NSLOTS
 };
 // A (start, stop) event pair to hand to hipExtLaunchKernelGGL: the timestamps then come from the kernel's own dispatch
 // signal and no marker packets enter the stream.  Both are null while profiling is off (= a plain launch).

@@ -12,6 +12,7 @@ thread_local char g_err[512] = "";
 const char *kSlotNames[tef::PROF_NSLOTS] = {
     "pack_events", "warp", "iwe_splat", "mag_reduce", "loss_reduce", "chain_bwd", "dflow_splat",
     "smoothing_fwd", "smoothing_bwd", "encode", "conv_fwd_gemm", "conv_dgrad_gemm", "conv_wgrad_gemm", "image_count",
+    "chain_bwd_rest",
 };
 struct Pending { int slot; hipEvent_t a, b; };
 bool g_prof_on = false;

@@ -48,7 +48,8 @@ constexpr size_t kSplatLdsBudget = 141 * 1024;   // K7's two planes of 64 + 2 ha
 constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the few-row
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
-constexpr int kQueueInts = 16;                // work queues of the persistent scatter kernels: [0, 8) images, [8, 16) flow gradients
+constexpr int kQueueInts = 24;                // work queues of the persistent scatter kernels: [0, 8) images, [8, 16) flow gradients; [16] = K6's deferred wavefronts
+constexpr int kDeferWord = 16;
 
 // meta word written by K1 per (head, sample, slot): .x = flags below | border bits per scale | kb + 1 | kf, .y = the
 // event's timestamp (bit pattern), so that the scatter reads everything but the position of an event in ONE 8-byte load
@@ -1286,34 +1287,36 @@ __device__ __forceinline__ float2 image_grad(const Win &w, const float2 *__restr
     return image_grad_at<FAST, INTERIOR>(w.H, w.W, ar + q * 2 * (size_t)(w.H * w.W), g, tref, delta, sp, ts, mp, mn);
 }
 
-// The same gradient when the position is STRICTLY inside its pixel cell and the cell inside the frame (decided per
-// wavefront by the caller), one polarity with mask value 1, one temporal scale: the hat slopes are exactly -1 (near
-// corner) and +1 (far corner), so the sign / tie logic of hat() and the slope products drop out.  Same operations on the
-// same values in the same order as image_grad<true, true> (a product with +-1 is exact).  r0 / r1: the (A, C + eps) pairs
-// of the cell's upper and lower pixel rows (loaded by the caller, one chain step ahead); g = image_upstream of the image.
+// The same gradient when the cell is inside the frame, one polarity with mask value 1, one temporal scale (decided per
+// wavefront by the caller): the validity selects, the fp32 corner case's extra load and the second-polarity branch drop
+// out.  The hat weights and their slopes come from the caller — near corner: 1 - d with slope -1 (0 at d == 0: abs'(0));
+// far corner: max(0, v), v = 1 - |p - floor(p + 1)|, with slope +1, +0.5 at the tie v == 0 (torch.max splits it) and 0
+// where fp32 rounded p + 1 up (v < 0) — so exact ties stay on this path.  Same operations on the same values in the same
+// order as image_grad<true, true>.  r0 / r1: the (A, C + eps) pairs of the cell's upper and lower pixel rows (loaded by the
+// caller, one chain step ahead); g = image_upstream of the image.
 __device__ __forceinline__ float corner_dw(float a, float ce, float g, float tau)
 {
     float dc, dt;
     pixel_grads(a, ce, g, dc, dt);
     return dc + dt * tau;
 }
-__device__ __forceinline__ float2 cell_grad(const f32x4_a8 r0, const f32x4_a8 r1, float g, float tau, float wy0, float wy1,
-                                            float wx0, float wx1)
+__device__ __forceinline__ float2 cell_grad(const f32x4_a8 r0, const f32x4_a8 r1, float g, float tau, float wy0, float sy0,
+                                            float wy1, float sy1, float wx0, float sx0, float wx1, float sx1)
 {
     float gy = 0.0f, gx = 0.0f;
     {
         const float dw0 = corner_dw(r0.x, r0.y, g, tau), dw1 = corner_dw(r0.z, r0.w, g, tau);
-        gy += dw0 * (-wx0);
-        gx += dw0 * (-wy0);
-        gy += dw1 * (-wx1);
-        gx += dw1 * wy0;
+        gy += dw0 * (sy0 * wx0);
+        gx += dw0 * (wy0 * sx0);
+        gy += dw1 * (sy0 * wx1);
+        gx += dw1 * (wy0 * sx1);
     }
     {
         const float dw0 = corner_dw(r1.x, r1.y, g, tau), dw1 = corner_dw(r1.z, r1.w, g, tau);
-        gy += dw0 * wx0;
-        gx += dw0 * (-wy1);
-        gy += dw1 * wx1;
-        gx += dw1 * wy1;
+        gy += dw0 * (sy1 * wx0);
+        gx += dw0 * (wy1 * sx0);
+        gy += dw1 * (sy1 * wx1);
+        gx += dw1 * (wy1 * sx1);
     }
     return make_float2(gy, gx);
 }
@@ -1375,7 +1378,7 @@ __global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restr
                                                          int *__restrict__ queue7)
 {
     __shared__ uint32_t red[4];
-    if (blockIdx.x == 0 && threadIdx.x < 8) queue7[threadIdx.x] = 0;      // K7's work queues, once per backward call
+    if (blockIdx.x == 0 && threadIdx.x < 9) queue7[threadIdx.x] = 0;      // K7's work queues (+ K6's deferred-wavefront count), once per backward call
     uint32_t m = 0u;
     for (int k = threadIdx.x; k < nwaves; k += blockDim.x) m = max(m, wmax[(size_t)blockIdx.x * nwaves + k]);
     for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft, 64));
@@ -1399,22 +1402,23 @@ __device__ __forceinline__ void NT_ST2(float2 *p, float a, float b)
 // ONE: a single temporal scale (scales_loss = 1, the headline configuration).  The kernel is VALU-bound (~450 vector
 // instructions per chain step, 2.9e7 steps per BASELINE window): the per-step scale loop with its integer division
 // (t / scale) and the normalisation constant are hoisted, and 1 / n is a reciprocal (image_grad<true>).
-template <bool ONE>
-__global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
-                                                             const float2 *__restrict__ traj,
-                                                             const uint2 *__restrict__ meta,
-                                                             const float2 *__restrict__ ar,
-                                                             const float *__restrict__ stats,
-                                                             const float *__restrict__ grad_out,
-                                                             float2 *__restrict__ cyx,
-                                                             uint32_t *__restrict__ cmax, int chunks)
+// PART (single-scale kernel only; 0 = everything in one launch): 1 = the fast form of every step, unconditionally — a
+// wavefront in which some active lane needed the general form somewhere (a corner or tap outside the frame, two polarities,
+// a mask value other than 1) computes that lane from clamped addresses, appends itself to `defer` and is recomputed by
+// PART 2, a few workgroups that walk the list with both forms.  In one launch the general form's code (sixteen guarded
+// divisions since round 4) sat in the sweeps' loop bodies and cost every wavefront its schedule: 0.228 ms where the fast form
+// alone takes 0.206 (a second loop, an out-of-line call or an early exit in the same kernel: 0.235 / 0.232 / 0.215 — the
+// register allocation and the loop shape are the kernel's).
+template <bool ONE, int PART>
+__device__ __forceinline__ void chain_bwd_wave(const Win &w, const float2 *__restrict__ flows, const Events &g,
+                                               const float2 *__restrict__ traj, const uint2 *__restrict__ meta,
+                                               const float2 *__restrict__ ar, const float *__restrict__ stats,
+                                               const float *__restrict__ grad_out, float2 *__restrict__ cyx,
+                                               uint32_t *__restrict__ cmax, int ib, int sl, int *__restrict__ defer_count,
+                                               int *__restrict__ defer)
 {
-    int ib, chunk;
-    xcd_split(blockIdx.x, chunks, ib, chunk);
-    if (ib >= w.F * w.B) return;
-    int sl = chunk * blockDim.x + threadIdx.x;
-    if (sl >= w.M) return;                              // (M is a multiple of 64: whole wavefronts)
     uint32_t mag = 0u;
+    unsigned long long strayed = 0ull;                  // PART 1: lanes that needed the general form at some step
     int i = ib / w.B, b = ib - i * w.B;
     const int H = w.H, W = w.W, P = w.P, M = w.M;
     float2 *co = cyx + (size_t)ib * P * M + sl;
@@ -1475,9 +1479,10 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     // gathers take the scalar-base form with a 32-bit lane offset, and lanes whose chain has not started yet or has left
     // the frame are handled by selects instead of divergent branches.
     // The fast form of a step needs EVERY active lane of the wavefront to have its four flow taps and its four image
-    // corners inside the frame, adjacent, strictly inside the pixel cell, one polarity (~25 % fewer vector instructions;
-    // border events and exact ties send their wavefront through the general code).  Same arithmetic in the same order
-    // either way.
+    // corners inside the frame and one polarity with mask value 1 (~25 % fewer vector instructions; events on the frame's
+    // last row / column send their wavefront through the general code; exact ties are handled here since round 4 — they
+    // were all of the 0.26 % of wavefront-steps that left the fast form on the BASELINE window).  Same arithmetic in the
+    // same order either way.
     const AxisConst ach = axis_const(H), acw = axis_const(W);
     const double rdelta = uniform_f64(1.0 / (double)one_delta);
     // D = -1: forward chain, newest tref first (k = min(P, t + reach) .. t + 1, map k - 1, p_k = p_{k-1} + dt f_{k-1});
@@ -1513,21 +1518,28 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
             }
         };
         auto step = [&](int k, float2 cur, float2 nxt) {
-            const bool act = active(k);
+            const bool act0 = active(k);
             const int km = D < 0 ? k - 1 : k;
             float jyy = 0.f, jyx = 0.f, jxy = 0.f, jxx = 0.f;
             float2 gk = make_float2(0.0f, 0.0f);
             int y0, x0;
             Taps tp = taps_core(nxt.x, nxt.y, ach, acw, y0, x0);
             // bilinear cell of `cur` (utils/iwe.py:85-107): near weights 1 - d with d = p - floor(p) in [0, 1), far weights
-            // 1 - |p - floor(p + 1)|; "strictly inside" = no weight is 0 or 1 (ties take the general path: hat() splits them)
+            // max(0, v), v = 1 - |p - floor(p + 1)|; slopes as hat() gives them, exact ties included (cell_grad)
             const float fy = floorf(cur.x), fx = floorf(cur.y);
             const float dy = cur.x - fy, dx = cur.y - fx;
-            const float wy1 = 1.0f - fabsf(cur.x - floorf(cur.x + 1.0f)), wx1 = 1.0f - fabsf(cur.y - floorf(cur.y + 1.0f));
+            const float vy1 = 1.0f - fabsf(cur.x - floorf(cur.x + 1.0f)), vx1 = 1.0f - fabsf(cur.y - floorf(cur.y + 1.0f));
+            const float wy1 = fmaxf(vy1, 0.0f), wx1 = fmaxf(vx1, 0.0f);
+            const float sy0 = dy > 0.0f ? -1.0f : -0.0f, sx0 = dx > 0.0f ? -1.0f : -0.0f;
+            const float sy1 = vy1 > 0.0f ? 1.0f : (vy1 == 0.0f ? 0.5f : 0.0f), sx1 = vx1 > 0.0f ? 1.0f : (vx1 == 0.0f ? 0.5f : 0.0f);
             const int iy0 = (int)fy, ix0 = (int)fx;
             const bool inside = one_pol & (y0 >= 0) & (y0 < H - 1) & (x0 >= 0) & (x0 < W - 1) & (iy0 >= 0) & (iy0 < H - 1) &
-                                (ix0 >= 0) & (ix0 < W - 1) & (dy > 0.0f) & (dx > 0.0f) & (wy1 > 0.0f) & (wx1 > 0.0f);
-            if (__builtin_amdgcn_ballot_w64(act & !inside) == 0) {
+                                (ix0 >= 0) & (ix0 < W - 1);
+            const unsigned long long stray = __builtin_amdgcn_ballot_w64(act0 & !inside);
+            if (PART == 1) strayed |= stray;
+            // (PART 1: a straying lane is computed like an inactive one — clamped addresses, zero adjoint; its wavefront is redone)
+            const bool act = PART == 1 ? (act0 & inside) : act0;
+            if (PART == 1 || stray == 0) {
                 const int kmc = min(max(km, 0), P - 1);               // (the jacobian of the last step is not used)
                 const float2 *fm = flows + uniform_off((((size_t)kmc * w.F + i) * w.B + b) * (size_t)(H * W));
                 const uint32_t fo = act ? (uint32_t)(__mul24(y0, W) + x0) : 0u;
@@ -1541,16 +1553,18 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                     const f32x4_a8 r0 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(pl, po * 8u));
                     const f32x4_a8 r1 = *reinterpret_cast<const f32x4_a8 *>(at_bytes(pl, (po + (uint32_t)W) * 8u));
                     const float tau = 1.0f - div_by_const(fabsf((float)k - ts), rdelta);
-                    gk = cell_grad(r0, r1, gimg, tau, 1.0f - dy, wy1, 1.0f - dx, wx1);
+                    gk = cell_grad(r0, r1, gimg, tau, 1.0f - dy, sy0, wy1, sy1, 1.0f - dx, sx0, wx1, sx1);
                 }
                 Quad2 q;
                 q.v00 = make_float2(q0.x, q0.y); q.v01 = make_float2(q0.z, q0.w);
                 q.v10 = make_float2(q1.x, q1.y); q.v11 = make_float2(q1.z, q1.w);
                 quad_jacobian(q, tp, jyy, jyx, jxy, jxx);
             } else if (act) {
-                Taps tg = make_taps(nxt.x, nxt.y, H, W);
-                quad_jacobian(load_quad(flow_map(w, flows, max(km, 0), i, b), tg, H * W), tg, jyy, jyx, jxy, jxx);
-                gk = pos_grad(k, cur);
+                if constexpr (PART != 1) {
+                    Taps tg = make_taps(nxt.x, nxt.y, H, W);
+                    quad_jacobian(load_quad(flow_map(w, flows, max(km, 0), i, b), tg, H * W), tg, jyy, jyx, jxy, jxx);
+                    gk = pos_grad(k, cur);
+                }
             }
             advance(k, act, gk, jyy, jyx, jxy, jxx);
         };
@@ -1573,6 +1587,8 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
         ay = 0.0f;
         ax = 0.0f;
         sweep(std::integral_constant<int, 1>());
+        if (PART == 1 && strayed != 0ull && (threadIdx.x & 63) == 0)      // (the second launch redoes the whole wavefront)
+            defer[atomicAdd(defer_count, 1)] = ib * (M >> 6) + (sl >> 6);
     } else {
         {   // forward chain, newest first: p_k = p_{k-1} + dt * f_{k-1}(p_{k-1}), k = min(P, t + reach) .. t+1
             const int k0 = min(P, t + reach);
@@ -1642,6 +1658,34 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
     NT_ST2(&co[(size_t)t * M], c0y, c0x);
     track_mag(mag, c0y, c0x);
     commit_mag(mag, cmax + (size_t)ib * (M >> 6) + (sl >> 6));       // (here: the per-wavefront slots)
+}
+
+template <bool ONE, int PART = 0>
+__global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2 *__restrict__ flows, Events g,
+                                                             const float2 *__restrict__ traj,
+                                                             const uint2 *__restrict__ meta,
+                                                             const float2 *__restrict__ ar,
+                                                             const float *__restrict__ stats,
+                                                             const float *__restrict__ grad_out,
+                                                             float2 *__restrict__ cyx,
+                                                             uint32_t *__restrict__ cmax, int chunks,
+                                                             int *__restrict__ defer_count, int *__restrict__ defer)
+{
+    if (PART == 2) {                                    // the listed wavefronts, one per wavefront of this grid at a time
+        const int n = defer_count[0], per = w.M >> 6;
+        for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) {
+            const int id = defer[e], ib = id / per;
+            chain_bwd_wave<ONE, PART>(w, flows, g, traj, meta, ar, stats, grad_out, cyx, cmax, ib,
+                                      (id - ib * per) * 64 + (int)(threadIdx.x & 63), defer_count, defer);
+        }
+        return;
+    }
+    int ib, chunk;
+    xcd_split(blockIdx.x, chunks, ib, chunk);
+    if (ib >= w.F * w.B) return;
+    const int sl = chunk * blockDim.x + threadIdx.x;
+    if (sl >= w.M) return;                              // (M is a multiple of 64: whole wavefronts)
+    chain_bwd_wave<ONE, PART>(w, flows, g, traj, meta, ar, stats, grad_out, cyx, cmax, ib, sl, defer_count, defer);
 }
 
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
@@ -2159,7 +2203,7 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, cyx, bad, total;
+    size_t traj, meta, yr, ar, nz, counts, stats, parts, queue, cmax, wmax, defer, cyx, bad, total;
 };
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -2266,6 +2310,7 @@ Layout make_layout(const Win &w)
     L.queue = o;  o += align_up((kQueueInts + FB) * sizeof(int));      // + one magnitude word per (head, sample) for K6 -> K7
     L.cmax = L.queue + kQueueInts * sizeof(int);
     L.wmax = o;   o += align_up(FB * (size_t)(w.M / 64 + 1) * sizeof(uint32_t));
+    L.defer = o;  o += align_up(FB * (size_t)(w.M / 64 + 1) * sizeof(int));      // K6: wavefronts left to its second launch
     L.cyx = o;    o += align_up(nc * sizeof(float2));
     L.bad = o;    o += align_up((FB * (size_t)((w.Mt + 255) / 256 + 1) + (size_t)w.nimg * FB) * sizeof(int));   // one word per K1 workgroup, then one per image
     L.total = o;
@@ -2501,12 +2546,19 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     if (w.M > 0) {
         int chunks = (w.M + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
-        if (w.kind == TEF_KIND_ITERATIVE && w.S == 1)
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<true>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cyx, wmax, chunks);
-        else if (w.kind == TEF_KIND_ITERATIVE)
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, iter_chain_bwd_kernel<false>, grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cyx, wmax, chunks);
+        int *defer_count = (int *)(ws + L.queue) + kDeferWord, *defer = (int *)(ws + L.defer);
+        if (w.kind == TEF_KIND_ITERATIVE && w.S == 1) {
+            // the fast form of every step; then the few wavefronts that needed the general form somewhere (the count is on the
+            // device: one workgroup per CU walks the list)
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, (iter_chain_bwd_kernel<true, 1>), grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+                             stats, grad_out, cyx, wmax, chunks, defer_count, defer);
+            if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
+            const unsigned rest = (unsigned)std::min<size_t>(((size_t)FB * (w.M >> 6) + 3) / 4, (size_t)num_cus());
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD_REST, (iter_chain_bwd_kernel<true, 2>), dim3(rest), dim3(256), 0, st, w, fl, g, traj,
+                             meta, ar, stats, grad_out, cyx, wmax, chunks, defer_count, defer);
+        } else if (w.kind == TEF_KIND_ITERATIVE)
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, (iter_chain_bwd_kernel<false, 0>), grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
+                             stats, grad_out, cyx, wmax, chunks, defer_count, defer);
         else
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
                              grad_out, cyx, wmax, chunks);
