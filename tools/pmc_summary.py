@@ -13,7 +13,8 @@ import csv
 import json
 from collections import defaultdict
 
-KERNELS = {                      # kernel symbol prefix -> bench.py name
+KERNELS = {                      # kernel symbol prefix -> bench.py name (first match wins)
+    "iter_chain_bwd_kernel<true, 2>": "chain_bwd_rest",
     "iter_warp_kernel": "warp", "linear_warp_kernel": "warp", "splat_stats_kernel": "iwe_splat",
     "loss_reduce_kernel": "loss_reduce", "iter_chain_bwd_kernel": "chain_bwd",
     "linear_bwd_kernel": "chain_bwd", "dflow_splat_kernel": "dflow_splat", "pack_flow_kernel": "pack_flow",
@@ -29,7 +30,7 @@ def per_kernel(path, counter, skip):
                 continue
             sym = row["Kernel_Name"]
             for pre, name in KERNELS.items():
-                if "::" + pre + "(" in sym or "::" + pre + "<" in sym or sym.startswith(pre):     # plain or templated
+                if "::" + pre + "(" in sym or "::" + pre + "<" in sym or sym.startswith(pre) or ("<" in pre and pre in sym):     # plain or templated
                     vals[name].append(float(row["Counter_Value"]) * 1024.0)
                     break
     return {k: (sum(v[skip:]) / max(1, len(v[skip:])), len(v[skip:])) for k, v in vals.items()}
