@@ -385,6 +385,12 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
 int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran,
                           void *stream);
+/* the same for one half of the layers: part = TEF_NET_ENCODERS (heads + ConvGRU gates), TEF_NET_DECODERS (residual blocks,
+ * decoders, prediction heads) or both.  A data-parallel caller reduces the decoder half first and all-reduces its slice
+ * of the gradient bucket while the encoder half is still being reduced (train.Trainer). */
+int tef_net_window_wgrads_part(const tef_net_plan *p, int part, int npass, const float *const *x,
+                               const float *const *const *states_in, const float *const *tape, const float *const *gtape,
+                               const unsigned long long *ran, void *stream);
 
 /* ---- optimiser step of the training window on flat buffers (train_flow.py:127-131) ----------------------------------
  * tef_l2_norm: out[0] = ||x||_2 (double partial sums in `scratch`, tef_l2_norm_scratch_bytes, fixed summation order);

@@ -164,6 +164,9 @@ SIGNATURES = {
     "tef_net_window_wgrads": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.POINTER(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ulonglong), _fp]),
+    "tef_net_window_wgrads_part": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                                  ctypes.POINTER(ctypes.POINTER(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p),
+                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ulonglong), _fp]),
     "tef_l2_norm_scratch_bytes": (ctypes.c_size_t, []),
     "tef_l2_norm": (ctypes.c_int, [_fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_adam_clip_step": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, ctypes.c_float, ctypes.c_double,

@@ -456,6 +456,14 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
 int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran, void *stream)
 {
+    return tef_net_window_wgrads_part(p, TEF_NET_ENCODERS | TEF_NET_DECODERS, npass, x, states_in, tape, gtape, ran, stream);
+}
+
+int tef_net_window_wgrads_part(const tef_net_plan *p, int part, int npass, const float *const *x,
+                               const float *const *const *states_in, const float *const *tape, const float *const *gtape,
+                               const unsigned long long *ran, void *stream)
+{
+    if (part < 1 || part > 3) return tef::fail("tef_net_window_wgrads_part: part must be 1, 2 or 3"), TEF_ERR_INVALID;
     Geo g;
     if (!make_geo(p, &g)) return TEF_ERR_INVALID;
     if (npass < 0 || (npass && (!x || !states_in || !tape || !gtape || !ran))) return tef::fail("tef_net_window_wgrads: null pointer"), TEF_ERR_INVALID;
@@ -479,7 +487,7 @@ int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *
         }
         return 0;
     };
-    for (int i = 0; i < g.lv; ++i) {
+    for (int i = 0; i < g.lv && (part & TEF_NET_ENCODERS); ++i) {
         TEF_TRY(layer(D.head[i], p->head[i], bit_head(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.g_e[i]; a = i ? tape[s] + t.hn[i - 1] : x[s]; b = nullptr; c_ = nullptr; }));
         TEF_TRY(layer(D.ur[i], p->gate_ur[i], bit_ur(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
@@ -487,6 +495,7 @@ int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *
         TEF_TRY(layer(D.og[i], p->gate_o[i], bit_og(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.g_o[i]; a = tape[s] + t.e[i]; b = states_in[s][i]; c_ = tape[s] + t.r[i]; }));
     }
+    if (!(part & TEF_NET_DECODERS)) return 0;
     for (int j = 0; j < g.nres; ++j) {
         TEF_TRY(layer(D.res, p->res1[j], bit_res1(j), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.gmid[j]; a = j ? tape[s] + t.y[j - 1] : tape[s] + t.hn[g.top]; b = nullptr; c_ = nullptr; }));

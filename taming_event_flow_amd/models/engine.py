@@ -352,15 +352,23 @@ class PassEngine:
         grads = [None] * len(params) if direct else [fresh.get(id(p)) for p in params]
         return dh, dx, grads
 
-    def flush_window(self, stream=None):
+    def flush_window(self, stream=None, parts=(3,), between=None, keep=False):
         """The deferred weight gradients of every backward call since the last flush: one reduction per layer over all
         passes (tef_net_window_wgrads) — on the current stream, or on `stream` once it has caught up with the current
-        one (the caller makes its stream wait for `stream` before the gradients are read)."""
-        pend, self._pending = self._pending, []
-        sm._DEFERRED_ENGINES.discard(self)
-        for r in pend:
-            r.queued = False
+        one (the caller makes its stream wait for `stream` before the gradients are read).  `parts`: the layer halves in
+        the order to reduce them (2 = residual blocks / decoders / heads, 1 = encoders, 3 = all); `between()` runs after
+        every half but the last — a data-parallel caller starts the all-reduce of the finished half's gradients there.
+        keep: leave the backward calls queued (the caller reduces the other half with a second call)."""
+        pend = self._pending
+        if not keep:
+            self._pending = []
+            sm._DEFERRED_ENGINES.discard(self)
+            for r in pend:
+                r.queued = False
         if not pend:
+            if between is not None:
+                for _ in parts[:-1]:
+                    between()
             return
         if stream is not None:
             stream.wait_stream(torch.cuda.current_stream())
@@ -370,19 +378,23 @@ class PassEngine:
                 for r in pend:          # the arenas are released right after this call: not before `stream` has read them
                     for t in [r.tape, r.gtape, r.xp] + list(r.states_in):
                         t.record_stream(stream)
-                self._launch_wgrads(pend)
+                self._launch_wgrads(pend, parts, between)
             return
-        self._launch_wgrads(pend)
+        self._launch_wgrads(pend, parts, between)
 
-    def _launch_wgrads(self, pend):
+    def _launch_wgrads(self, pend, parts=(3,), between=None):
         npass = len(pend)
         xs = (ctypes.c_void_p * npass)(*[r.xp.data_ptr() for r in pend])
         sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p)) for r in pend])
         tapes = (ctypes.c_void_p * npass)(*[r.tape.data_ptr() for r in pend])
         gtapes = (ctypes.c_void_p * npass)(*[r.gtape.data_ptr() for r in pend])
         rans = (ctypes.c_ulonglong * npass)(*[r.ran for r in pend])
-        rc = _lib.lib().tef_net_window_wgrads(ctypes.byref(pend[-1].plan), npass, xs, sts, tapes, gtapes, rans, _lib.stream_ptr())
-        _lib.check(rc, "tef_net_window_wgrads")
+        for k, part in enumerate(parts):
+            rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(pend[-1].plan), int(part), npass, xs, sts, tapes, gtapes, rans,
+                                                       _lib.stream_ptr())
+            _lib.check(rc, "tef_net_window_wgrads")
+            if between is not None and k + 1 < len(parts):
+                between()
 
 
 class _PassFn(torch.autograd.Function):

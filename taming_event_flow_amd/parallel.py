@@ -41,6 +41,23 @@ class FlatGradBucket:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         return self.flat
 
+    def all_reduce_range(self, lo, hi):
+        """The same for the elements [lo, hi) of the flat buffer (a contiguous view: one collective).  Two ranges that cover
+        the buffer give bit for bit what all_reduce_sum gives on two ranks (a sum of two numbers has one rounding); on more
+        ranks the reduction order of an element may depend on where the collective cuts its chunks."""
+        if is_distributed() and hi > lo:
+            dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+        return self.flat
+
+    def offset_of(self, param):
+        """First element of `param`'s gradient in the flat buffer (parameters are laid out in iteration order)."""
+        o = 0
+        for p in self.params:
+            if p is param:
+                return o
+            o += p.numel()
+        raise KeyError("parameter is not in the bucket")
+
     def clip_(self, max_norm):
         """Global-norm clipping on the (already reduced) flat buffer = clip_grad_norm_ (train_flow.py:127-128)."""
         norm = torch.linalg.vector_norm(self.flat)

@@ -77,24 +77,38 @@ class CapturedWindow:
     window's first pass (train_flow.py:83-87); a captured window is P passes long by construction, so sequences must
     change at window boundaries (DSEC: 200 passes per sequence, P = 10)."""
 
-    def __init__(self, trainer, graph, graph_tail, inputs, states):
+    def __init__(self, trainer, graph, graph_tail, inputs, states, graph_mid=None):
         self.trainer, self.graph, self.graph_tail, self.inputs, self.states = trainer, graph, graph_tail, inputs, states
-        self.allreduce_events = None      # a list: replay() appends a (start, stop) event pair around each DP all-reduce
+        self.graph_mid = graph_mid        # DP with overlap: the encoder half of the last weight-gradient reduction
+        # a list: replay() appends (start, local work done, stop) events around each DP reduction — start -> stop is the
+        # reduction as the main stream sees it, local work done -> stop the part of it nothing was left to hide
+        self.allreduce_events = None
 
     def replay(self, new_seq=False):
         if parallel.any_rank(new_seq):       # host-side exchange, outside the graph; all ranks reset together
             for s in self.states:            # loss containers and gradients are already clear at a window boundary
                 s.zero_()
         self.graph.replay()
-        if self.graph_tail is not None:      # DP: the collective runs between the two graphs, on the same stream
+        if self.graph_tail is not None:      # DP: the collectives run between the graphs, never captured
+            ev = None
             if self.allreduce_events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                self.trainer.bucket.all_reduce_sum()
-                e1.record()
-                self.allreduce_events.append((e0, e1))
+                ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(3))
+                ev[0].record()
+            if self.graph_mid is not None:
+                # the decoder half's gradients are complete: their all-reduce runs on the communication stream beside the
+                # encoder half's last weight-gradient reduction
+                self.trainer._allreduce_tail_begin()
+                self.graph_mid.replay()
+                if ev:
+                    ev[1].record()
+                self.trainer._allreduce_head_and_join()
             else:
+                if ev:
+                    ev[1].record()
                 self.trainer.bucket.all_reduce_sum()
+            if ev:
+                ev[2].record()
+                self.allreduce_events.append(ev)
             self.graph_tail.replay()
         return self.trainer.last_loss
 
@@ -108,6 +122,7 @@ class CapturedWindow:
         if torch.cuda.is_available() and torch.cuda.is_initialized():
             torch.cuda.synchronize()
         self.graph_tail = None
+        self.graph_mid = None
         self.graph = None
         self.inputs = self.states = None
 
@@ -152,6 +167,18 @@ class Trainer:
             self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
         self.last_grad_norm = None
+        # DP: the gradient bucket is reduced in two pieces — [encoders | residual blocks, decoders, heads], the order of
+        # model.parameters() — so that the second piece's all-reduce overlaps the encoders' last weight-gradient reduction
+        # (TEF_DP_OVERLAP=0: one all-reduce of the whole bucket after everything)
+        self.comm_stream = None
+        self._dp_split = None
+        self._dp_tail_started = False
+        arch_ = getattr(self.model, "arch", None)
+        if arch_ is not None and hasattr(arch_, "resblocks") and os.environ.get("TEF_DP_OVERLAP", "1") != "0":
+            try:
+                self._dp_split = self.bucket.offset_of(next(iter(arch_.resblocks.parameters())))
+            except (KeyError, StopIteration):
+                self._dp_split = None
         # Two streams per window (models/engine.py): the decoder half of pass t, and the loss container's update() behind
         # it, run on a side stream beside the encoders of pass t + 1; BPTT mirrors it through autograd's own stream
         # handling.  TEF_TWO_STREAMS=0 keeps every launch on one stream.
@@ -175,7 +202,7 @@ class Trainer:
         its streams' buffers released under a running kernel."""
         eng = getattr(getattr(self.model, "arch", None), "_engine", None) if getattr(self, "model", None) is not None else None
         if torch.cuda.is_available() and torch.cuda.is_initialized():
-            for st in (self.dec_stream, self.wgrad_stream):
+            for st in (self.dec_stream, self.wgrad_stream, self.comm_stream):
                 if st is not None:
                     st.synchronize()
             torch.cuda.current_stream().synchronize()
@@ -218,17 +245,22 @@ class Trainer:
 
         split = parallel.is_distributed()
 
-        def run_head():          # everything up to the local gradient
+        overlap = split and self._dp_overlap() is not None
+
+        def run_head(stage=0):   # everything up to the local gradient (stage 1: without the encoder half's last reduction)
             for src, dst in zip(inputs, work):
                 for k in src:
                     dst[k].copy_(src[k])
                 complete = self._forward_update(dst)
             assert complete
-            self._backward_window()
+            loss = self.loss_function()
+            loss.backward()
+            self._flush_wgrads(stage=stage)
+            self.last_loss = loss.detach()
 
         def run():
             run_head()
-            self.bucket.all_reduce_sum()
+            self.all_reduce_gradients()
             self._apply_update()
 
         side = torch.cuda.Stream()
@@ -250,17 +282,21 @@ class Trainer:
             for dst, src in zip(static_states, self.model.arch.states):
                 dst.copy_(src.detach())
 
-        graph, graph_tail = torch.cuda.CUDAGraph(), None
+        graph, graph_tail, graph_mid = torch.cuda.CUDAGraph(), None, None
         with torch.cuda.graph(graph):
-            run_head()
+            run_head(1 if overlap else 0)
             if not split:
                 tail()
+        if overlap:
+            graph_mid = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_mid, pool=graph.pool()):
+                self._flush_wgrads(stage=2)
         if split:
             graph_tail = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph_tail, pool=graph.pool()):
                 tail()
         self.model.arch.states = static_states
-        return CapturedWindow(self, graph, graph_tail, inputs, static_states)
+        return CapturedWindow(self, graph, graph_tail, inputs, static_states, graph_mid)
 
     def step(self, inputs, new_seq=False):
         """One pass (train_flow.py:83-137).  Returns True when an optimiser step happened."""
@@ -272,7 +308,7 @@ class Trainer:
         if not self._forward_update(inputs):
             return False
         self._backward_window()
-        self.bucket.all_reduce_sum()                    # DP: gradient of the global batch (sum of shards)
+        self.all_reduce_gradients()                     # DP: gradient of the global batch (sum of shards)
         self._apply_update()
         return True
 
@@ -318,11 +354,68 @@ class Trainer:
         """train_flow.py:120-125: loss over the window, BPTT backward (local shard of the batch)."""
         loss = self.loss_function()
         loss.backward()
-        if self.deferred_wgrad:
-            submodules.flush_deferred_wgrads()
-            if self.wgrad_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+        self._flush_wgrads(stage=0)
         self.last_loss = loss.detach()
+
+    def _dp_overlap(self):
+        eng = getattr(getattr(self.model, "arch", None), "_engine", None)
+        return (eng if (self._dp_split and self.deferred_wgrad and parallel.is_distributed()
+                        and torch.device(self.device).type == "cuda") else None)
+
+    def _flush_wgrads(self, stage=0):
+        """The window's deferred weight gradients.  Outside DP (or with TEF_DP_OVERLAP=0): all layers, then wait for the
+        reductions that ran beside BPTT.  Under DP the last reduction is split: the decoder half first, then `between`
+        (eager: start that half's all-reduce on the communication stream), then the encoder half.  A captured window
+        records the two halves in two graphs (stage 1, stage 2) with the collective between them."""
+        if not self.deferred_wgrad:
+            return
+        cur = torch.cuda.current_stream() if torch.device(self.device).type == "cuda" else None
+        eng = self._dp_overlap()
+        if eng is None:
+            if stage in (0, 1):
+                submodules.flush_deferred_wgrads()
+                if self.wgrad_stream is not None:
+                    cur.wait_stream(self.wgrad_stream)
+            return
+
+        def tail_done():       # every reduction that touched the decoder half has been issued: wait for the side stream's
+            if self.wgrad_stream is not None:
+                cur.wait_stream(self.wgrad_stream)
+
+        if stage == 0:         # eager
+            def between():
+                tail_done()
+                self._allreduce_tail_begin()
+            eng.flush_window(parts=(2, 1), between=between)
+            submodules.flush_deferred_wgrads()      # (layer-by-layer modules, other engines: normally nothing)
+        elif stage == 1:       # captured: decoder half, the backward calls stay queued
+            eng.flush_window(parts=(2,), keep=True)
+            tail_done()
+        else:                  # captured: encoder half
+            eng.flush_window(parts=(1,))
+            submodules.flush_deferred_wgrads()
+
+    def _allreduce_tail_begin(self):
+        """all-reduce(SUM) of the decoder half's slice of the bucket on the communication stream, behind the current one."""
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            self.bucket.all_reduce_range(self._dp_split, self.bucket.flat.numel())
+        self._dp_tail_started = True
+
+    def _allreduce_head_and_join(self):
+        """The encoder half's slice on the current stream, then wait for the other half."""
+        self.bucket.all_reduce_range(0, self._dp_split)
+        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._dp_tail_started = False
+
+    def all_reduce_gradients(self):
+        """DP: SUM of the shards' gradients (= the gradient of the global batch), before clipping."""
+        if self._dp_tail_started:
+            self._allreduce_head_and_join()
+        else:
+            self.bucket.all_reduce_sum()
 
     def _apply_update(self):
         """train_flow.py:127-137 on the (already reduced) flat gradient: clip, step, clear, cut the graph."""

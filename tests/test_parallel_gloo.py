@@ -39,8 +39,17 @@ def _worker(rank, world, port, q):
     bucket = parallel.FlatGradBucket(model.parameters())
     _loss(model, xg[lo:hi]).backward()
     local = bucket.flat.clone()
+    # the two-piece reduction train.Trainer overlaps with the last weight-gradient reduction: [second layer | first layer]
+    # slices of the flat buffer, the later one first — bit for bit what one all-reduce of the whole buffer gives
+    split = bucket.offset_of(list(model.parameters())[2])
+    assert 0 < split < bucket.flat.numel()
+    bucket.all_reduce_range(split, bucket.flat.numel())
+    bucket.all_reduce_range(0, split)
+    pieces = bucket.flat.clone()
+    bucket.flat.copy_(local)
     bucket.all_reduce_sum()
     reduced = bucket.flat.clone()
+    assert torch.equal(pieces, reduced), "bucketed all-reduce differs from the single one"
     norm = bucket.clip_(0.5)
     flag = parallel.any_rank(rank == 1, torch.device("cpu"))
     noflag = parallel.any_rank(False, torch.device("cpu"))
