@@ -39,6 +39,10 @@ def test_loss_mode_two_ranks():
     assert x["rccl_world_size"] == 2 and x["rank_checksum"] == x["rank_checksum_expected"] == 3.0
     assert x["dp_train_window_ms"] > 0 and x["allreduce_ms"] > 0 and x["allreduce_GBps"] > 0
     assert x["allreduce_bytes"] == 4 * 31_365_352 and x["replicas_bit_identical"]
+    # the reduction is overlapped (two pieces around the encoder half's last weight-gradient reduction): what is left
+    # exposed is reported beside the whole
+    assert x["allreduce_overlap"] is True and 0 <= x["allreduce_exposed_ms"] <= x["allreduce_ms"]
+    print("DP window on two ranks sharing one GPU (gloo):", {k: x[k] for k in ("dp_train_window_ms", "allreduce_ms", "allreduce_exposed_ms")})
     assert 0 < x["new_seq_exchange_ms_per_pass"] < 50
 
 
