@@ -17,7 +17,7 @@ def load(tag):
     acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
     for f in glob.glob("$O/%s_*/**/*counter_collection.csv" % tag, recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
+            k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0][:72]
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
             if r["Counter_Name"] == "GRBM_GUI_ACTIVE": n[k] += 1
     return acc, n
