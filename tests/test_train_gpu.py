@@ -441,3 +441,127 @@ def test_window_cut_short_by_new_seq():
     assert len(one) == 4 and np.isfinite(multi).all()
     err = np.abs(multi - one) / np.abs(one)
     assert (err[0::2] <= 1e-6).all() and (err[1::2] <= 1e-5).all(), (one, multi)
+
+
+def test_fused_adam_optimizer_surface_and_nan_norm():
+    """parallel.FusedAdam as `Trainer.optimizer`: param_groups[0]["lr"] is what the step uses, state_dict /
+    load_state_dict carry the moments and the step count, zero_grad clears the flat bucket, and a NaN gradient norm poisons
+    every parameter like torch's clip_grad_norm_ (clamp propagates NaN) instead of applying the finite elements unclipped."""
+    import copy
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import train
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"].update(batch_size=1, resolution=[32, 32], max_num_grad_events=200)
+    cfg["data"]["passes_loss"] = 2
+    cfg["optimizer"]["lr"] = 1e-3
+    torch.manual_seed(3)
+    tr = train.Trainer(cfg, dev)
+    opt = tr.optimizer
+    assert opt is tr.fused_opt and opt.param_groups[0]["lr"] == 1e-3 and len(opt.param_groups[0]["params"]) == len(tr.bucket.params)
+    p0 = tr.bucket.params[0]
+    tr.bucket.flat.fill_(0.5)
+    before = p0.detach().clone()
+    opt.param_groups[0]["lr"] = 2e-3                       # what a scheduler does
+    norm = opt.step(None)
+    torch.cuda.synchronize()
+    # first Adam step: every weight moves by lr * sign(g) (bias-corrected m / sqrt(v) = 1)
+    assert torch.allclose(before - p0.detach(), torch.full_like(before, 2e-3), rtol=1e-4, atol=1e-8)
+    assert float(tr.bucket.flat.abs().max()) == 0.0 and float(norm) > 0        # the step cleared the gradient
+    sd = opt.state_dict()
+    assert float(sd["state"]["step"]) == 1.0 and sd["param_groups"][0]["lr"] == 2e-3
+    tr2 = train.Trainer(cfg, dev)
+    tr2.optimizer.load_state_dict(sd)
+    assert torch.equal(tr2.optimizer.m, opt.m) and torch.equal(tr2.optimizer.v, opt.v) and tr2.optimizer.lr == 2e-3
+    tr.bucket.flat.fill_(1.0)
+    opt.zero_grad()
+    assert float(tr.bucket.flat.abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        opt.zero_grad(set_to_none=True)
+    # NaN norm with clipping on: torch's clamp(max_norm / (norm + 1e-6), max=1) is NaN -> every gradient, then every weight
+    tr.bucket.flat.fill_(0.1)
+    tr.bucket.flat[7] = float("nan")
+    opt.step(5.0)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(tr.fused_opt.flat_p).all())
+    tr.close()
+    tr2.close()
+
+
+def test_side_stream_update_after_one_node_fallback():
+    """with the side stream on, a pass that falls back to ONE autograd node on the caller's stream (here: a
+    parameter's .grad set to None by an external zero_grad(set_to_none=True)) leaves its flows on the caller's stream;
+    update() on the side stream must wait for them.  The window's loss equals the one-stream trainer's."""
+    import copy
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import train
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"].update(batch_size=2, resolution=[64, 64], max_num_grad_events=1500)
+    cfg["data"]["passes_loss"] = 4
+    cfg["optimizer"]["lr"] = 0.0
+
+    def run(streams):
+        torch.manual_seed(7)
+        tr = train.Trainer(cfg, dev, streams=streams)
+        src = train.SyntheticSequences(cfg, dev, 2000, seq_len=10 ** 9, seed=3, jitter=100)
+        tr.reset()
+        next(iter(tr.model.parameters())).grad = None          # the engine now takes the one-node path
+        if streams:
+            tr.model.arch.engine.debug_delay = (20_000_000, 0, 0)
+        for _ in range(4):
+            complete = tr._forward_update(src.next())
+            if streams:
+                assert tr.model.arch.engine.last_pass_split is False
+        assert complete
+        loss = float(tr.loss_function().item())
+        tr.close()
+        return loss
+
+    one, multi = run(False), run(True)
+    assert abs(one - multi) <= 1e-6 * abs(one), (one, multi)
+
+
+def test_loss_workspace_lease():
+    """A second evaluation of the same loss window while the first one's autograd graph is alive must not clobber the
+    workspace the first backward reads (explicit lease, not sys.getrefcount)."""
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import synth
+    from taming_event_flow_amd.loss.flow import Iterative
+
+    dev = torch.device("cuda:0")
+    B, H, W, P, F = 2, 32, 32, 4, 2
+    rng = np.random.default_rng(0)
+    win = synth.make_window(rng, B, H, W, P, F, 400, 100, sigma=1.5)
+    cfg = {"loader": {"resolution": [H, W], "batch_size": B},
+           "loss": {"flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "round_ts": False, "iterative_mode": "two"},
+           "data": {"passes_loss": P, "scales_loss": 1}}
+    L = Iterative(cfg, dev)
+    flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
+    for t in range(P):
+        L.update(flows[t], torch.tensor(win["ev"][t], device=dev), torch.tensor(win["pm"][t], device=dev),
+                 torch.tensor(win["dev"][t], device=dev), torch.tensor(win["dpm"][t], device=dev))
+    flat = [f for row in flows for f in row]
+    l1 = L()
+    ws1 = L._win.workspace
+    l2 = L()                                               # first graph still alive: a fresh workspace
+    assert L._win.workspace is not ws1
+    g1 = torch.autograd.grad(l1, flat, retain_graph=False)
+    g2 = torch.autograd.grad(l2, flat)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+    del l1, l2, g1, g2
+    ws3 = L._win.workspace
+    l3 = L()                                               # both graphs are gone: the buffer is reused
+    assert L._win.workspace is ws3
+    del l3
