@@ -62,7 +62,8 @@ def sweep(cases, seed, verbose=True, big_frac=0.05, ragged_windows=False):
                                 integer_coords=rng.random() < 0.7)
         spat = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
         temp = float(rng.choice([0.001, 0.1])) if rng.random() < 0.25 else None
-        rts = rng.random() < 0.15 and min(ng) > 0          # round_ts on an empty list raises, as in the reference (:461)
+        # round_ts on an empty list raises in the reference (:461 for the gradient list, :463 for the detached one)
+        rts = rng.random() < 0.15 and min(ng) > 0 and min(nd) > 0
         comp = rng.random() >= 0.2                                   # border_compensation=False in a fifth of the cases
         meta = dict(H=H, W=W, B=B, P=P, S=S, mode=mode, spat=spat, temp=temp, round_ts=bool(rts), border_compensation=comp)
         try:
