@@ -115,16 +115,28 @@ class CapturedWindow:
     __call__ = replay
 
     def close(self):
-        """Wait for the last replay, then release the hipGraphs (and with them their private memory pool) in a fixed
-        order.  Idempotent.  Dropping the object without calling this does the same from __del__."""
+        """Wait for the last replay, release the hipGraphs (and with them their private memory pool), then WAIT AGAIN.
+        Idempotent.  Dropping the object without calling this does the same from __del__.
+
+        The second wait is the fix for round 3's "hidden heap corruption" (DESIGN section 9d): destroying a captured
+        multi-stream hipGraph on this stack (ROCm 7.0 runtime of torch 2.10) leaves device-side work behind — after the
+        destructor has returned, and although the device was idle before it, one 32-bit word inside memory the graph owned
+        is decremented by one and another, 736 bytes on, is zeroed (the signature of a completion signal).  If that memory
+        has been handed to a new allocation by then, the writes land there: observed in the first 4.6 KB of the NEXT
+        trainer's parameter buffer (two weights of its first convolution changed, one by an ulp, one to 0.0: 6 % of the
+        iterations of tools/interference_trace.py; 0 of 100 with this wait, 0 of 90 when graphs are never destroyed) and,
+        in round 3, as glibc heap-corruption aborts when the recycled memory was the host's."""
         if self.graph is None and self.graph_tail is None:
             return
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
+        live = torch.cuda.is_available() and torch.cuda.is_initialized()
+        if live:
             torch.cuda.synchronize()
         self.graph_tail = None
         self.graph_mid = None
         self.graph = None
         self.inputs = self.states = None
+        if live:
+            torch.cuda.synchronize()
 
     def __del__(self):
         if not sys.is_finalizing():
