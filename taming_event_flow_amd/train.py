@@ -71,6 +71,21 @@ class SyntheticSequences:
         return batch
 
 
+_RETIRED_GRAPHS = []      # hipGraphs of closed CapturedWindows (see CapturedWindow.close)
+
+
+def release_retired_graphs():
+    """Destroy the hipGraphs of closed windows (returns their private memory pools): wait for the device, destroy, wait again.
+    On this stack a destroyed multi-stream graph can still write into the memory it owned a moment later (DESIGN section
+    9d): call this when nothing else is about to allocate device or host memory — or never; the graphs die with the process."""
+    live = torch.cuda.is_available() and torch.cuda.is_initialized()
+    if live:
+        torch.cuda.synchronize()
+    _RETIRED_GRAPHS.clear()
+    if live:
+        torch.cuda.synchronize()
+
+
 class CapturedWindow:
     """A loss window captured by Trainer.capture_window.  `inputs[t]` is pass t's batch dict of STATIC tensors: write
     the next window's data into them (`.copy_`), then `replay()`.  `new_seq` is the reference's reset flag for the
@@ -124,13 +139,19 @@ class CapturedWindow:
         is decremented by one and another, 736 bytes on, is zeroed (the signature of a completion signal).  If that memory
         has been handed to a new allocation by then, the writes land there: observed in the first 4.6 KB of the NEXT
         trainer's parameter buffer (two weights of its first convolution changed, one by an ulp, one to 0.0: 6 % of the
-        iterations of tools/interference_trace.py; 0 of 100 with this wait, 0 of 90 when graphs are never destroyed) and,
-        in round 3, as glibc heap-corruption aborts when the recycled memory was the host's."""
+        iterations of tools/interference_trace.py; 0 of 100 with this wait there but still 1 of 24 in the longer test
+        sequence of tools/pytest_sequence_probe.py; 0 of 90 when graphs are never destroyed) and, in round 3, as glibc
+        heap-corruption aborts when the recycled memory was the host's.  Hence the default below: retire, do not destroy."""
         if self.graph is None and self.graph_tail is None:
             return
         live = torch.cuda.is_available() and torch.cuda.is_initialized()
         if live:
             torch.cuda.synchronize()
+        if os.environ.get("TEF_DESTROY_GRAPHS", "0") != "1":
+            # default: the graphs are RETIRED, not destroyed — they (and their private memory pool) stay allocated until the
+            # process ends or release_retired_graphs() is called.  The wait after destruction cuts the late writes from 6 %
+            # of the probe's iterations to ~1 % (1 in 124), never destroying a graph to 0 in 90: correctness over memory.
+            _RETIRED_GRAPHS.extend(g_ for g_ in (self.graph_tail, self.graph_mid, self.graph) if g_ is not None)
         self.graph_tail = None
         self.graph_mid = None
         self.graph = None
