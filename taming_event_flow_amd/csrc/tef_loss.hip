@@ -1368,10 +1368,11 @@ __device__ __forceinline__ void track_mag(uint32_t &m, float a, float b)
 }
 // One plain store per wavefront into wmax[(head, sample)][wavefront]; mag_reduce_kernel folds them.  (4e5 wavefronts on
 // 32 words: an atomicMax each doubled K6's time, 0.23 -> 0.50 ms; guarded by a coherent read of the word still 0.28.)
-__device__ __forceinline__ void commit_mag(uint32_t m, uint32_t *__restrict__ wave_slot)
+__device__ __forceinline__ uint32_t commit_mag(uint32_t m, uint32_t *__restrict__ wave_slot)
 {
     for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft, 64));
     if ((threadIdx.x & 63) == 0) *wave_slot = m;
+    return m;
 }
 
 __global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restrict__ wmax, int nwaves, uint32_t *__restrict__ cmax,
@@ -1415,7 +1416,7 @@ __device__ __forceinline__ void chain_bwd_wave(const Win &w, const float2 *__res
                                                const float2 *__restrict__ ar, const float *__restrict__ stats,
                                                const float *__restrict__ grad_out, float2 *__restrict__ cyx,
                                                uint32_t *__restrict__ cmax, int ib, int sl, int *__restrict__ defer_count,
-                                               int *__restrict__ defer)
+                                               int *__restrict__ defer, uint32_t *__restrict__ cmax_ib)
 {
     uint32_t mag = 0u;
     unsigned long long strayed = 0ull;                  // PART 1: lanes that needed the general form at some step
@@ -1657,7 +1658,10 @@ __device__ __forceinline__ void chain_bwd_wave(const Win &w, const float2 *__res
     }
     NT_ST2(&co[(size_t)t * M], c0y, c0x);
     track_mag(mag, c0y, c0x);
-    commit_mag(mag, cmax + (size_t)ib * (M >> 6) + (sl >> 6));       // (here: the per-wavefront slots)
+    // (here `cmax`: the per-wavefront slots.  PART 1: a wavefront that strayed leaves 0 — its vectors are recomputed by the
+    // finishing launch, which publishes their magnitude with an atomic of its own: chain_bwd_finish_kernel)
+    const uint32_t wm = commit_mag((PART == 1 && strayed != 0ull) ? 0u : mag, cmax + (size_t)ib * (M >> 6) + (sl >> 6));
+    if (PART == 2 && (threadIdx.x & 63) == 0) atomicMax(cmax_ib + ib, wm);
 }
 
 template <bool ONE, int PART = 0>
@@ -1669,23 +1673,50 @@ __global__ __launch_bounds__(256) void iter_chain_bwd_kernel(Win w, const float2
                                                              const float *__restrict__ grad_out,
                                                              float2 *__restrict__ cyx,
                                                              uint32_t *__restrict__ cmax, int chunks,
-                                                             int *__restrict__ defer_count, int *__restrict__ defer)
+                                                             int *__restrict__ defer_count, int *__restrict__ defer,
+                                                             uint32_t *__restrict__ cmax_ib)
 {
-    if (PART == 2) {                                    // the listed wavefronts, one per wavefront of this grid at a time
-        const int n = defer_count[0], per = w.M >> 6;
-        for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) {
-            const int id = defer[e], ib = id / per;
-            chain_bwd_wave<ONE, PART>(w, flows, g, traj, meta, ar, stats, grad_out, cyx, cmax, ib,
-                                      (id - ib * per) * 64 + (int)(threadIdx.x & 63), defer_count, defer);
-        }
-        return;
-    }
     int ib, chunk;
     xcd_split(blockIdx.x, chunks, ib, chunk);
     if (ib >= w.F * w.B) return;
+    if (PART == 1 && chunk == 0 && threadIdx.x == 0) cmax_ib[ib] = 0u;      // the finishing launch folds into it with atomicMax
     const int sl = chunk * blockDim.x + threadIdx.x;
     if (sl >= w.M) return;                              // (M is a multiple of 64: whole wavefronts)
-    chain_bwd_wave<ONE, PART>(w, flows, g, traj, meta, ar, stats, grad_out, cyx, cmax, ib, sl, defer_count, defer);
+    chain_bwd_wave<ONE, PART>(w, flows, g, traj, meta, ar, stats, grad_out, cyx, cmax, ib, sl, defer_count, defer, cmax_ib);
+}
+
+// K6's finishing launch (single-scale Iterative): R workgroups per (head, sample).  First every workgroup takes its share of
+// the wavefronts the fast launch listed and recomputes them with both forms (normally none: the launch then costs what the
+// magnitude reduce alone cost, and the separate 10 us launch round 4 first had is gone); then workgroup (ib, r) folds its
+// slice of ib's per-wavefront magnitudes into cmax[ib].  No workgroup waits for another: a recomputed wavefront's slot was
+// left at 0 by the fast launch and its magnitude goes into cmax[ib] by the recomputing wavefront's own atomicMax.
+// The list's counter is cleared by K7 (and by K1): a workgroup of THIS launch may not have read it yet when another is done.
+__global__ __launch_bounds__(256) void chain_bwd_finish_kernel(Win w, const float2 *__restrict__ flows, Events g,
+                                                               const float2 *__restrict__ traj,
+                                                               const uint2 *__restrict__ meta,
+                                                               const float2 *__restrict__ ar,
+                                                               const float *__restrict__ stats,
+                                                               const float *__restrict__ grad_out,
+                                                               float2 *__restrict__ cyx, uint32_t *__restrict__ wmax,
+                                                               int *__restrict__ defer_count, int *__restrict__ defer,
+                                                               uint32_t *__restrict__ cmax_ib, int R, int *__restrict__ queue7)
+{
+    __shared__ uint32_t red[4];
+    if (blockIdx.x == 0 && threadIdx.x < 8) queue7[threadIdx.x] = 0;      // K7's work queues, once per backward call
+    const int n = defer_count[0], per = w.M >> 6;
+    for (int e = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6); e < n; e += (int)gridDim.x * 4) {
+        const int id = defer[e], ib = id / per;
+        chain_bwd_wave<true, 2>(w, flows, g, traj, meta, ar, stats, grad_out, cyx, wmax, ib,
+                                (id - ib * per) * 64 + (int)(threadIdx.x & 63), defer_count, defer, cmax_ib);
+    }
+    const int ib = (int)blockIdx.x / R, r = (int)blockIdx.x - ib * R;
+    const int lo = (int)(((long)per * r) / R), hi = (int)(((long)per * (r + 1)) / R);
+    uint32_t m = 0u;
+    for (int k = lo + (int)threadIdx.x; k < hi; k += blockDim.x) m = max(m, wmax[(size_t)ib * per + k]);
+    for (int sft = 32; sft > 0; sft >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, sft, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(cmax_ib + ib, max(max(red[0], red[1]), max(red[2], red[3])));
 }
 
 // K6 (Linear): d/d(sampled flow) = sum over scales and both window ends of (tref - ts) * d/d position.
@@ -1852,6 +1883,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
     const int reach = w.P / max(1, w.mode_div);     // Iterative: pass t feeds map k only if |k - t| < delta_passes[0]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     for (int k = threadIdx.x; k < (kSplatThreads / 64) * kRing; k += blockDim.x) hit_ring[k] = 0;      // (stale entries are read)
+    if (blockIdx.x == 0 && threadIdx.x == 0) queue[kDeferWord - 8] = 0;      // K6's list of deferred wavefronts: consumed
     if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
     __syncthreads();
     for (;;) {
@@ -2543,6 +2575,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     const float2 *fl = (const float2 *)flows_yx;
     Events g = to_events(grad);
     const int FB = w.F * w.B;
+    bool finished = false;
     if (w.M > 0) {
         int chunks = (w.M + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
@@ -2551,21 +2584,23 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
             // the fast form of every step; then the few wavefronts that needed the general form somewhere (the count is on the
             // device: one workgroup per CU walks the list)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, (iter_chain_bwd_kernel<true, 1>), grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cyx, wmax, chunks, defer_count, defer);
+                             stats, grad_out, cyx, wmax, chunks, defer_count, defer, cmax);
             if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
-            const unsigned rest = (unsigned)std::min<size_t>(((size_t)FB * (w.M >> 6) + 3) / 4, (size_t)num_cus());
-            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD_REST, (iter_chain_bwd_kernel<true, 2>), dim3(rest), dim3(256), 0, st, w, fl, g, traj,
-                             meta, ar, stats, grad_out, cyx, wmax, chunks, defer_count, defer);
+            const int R = std::max(1, std::min(8, num_cus() / std::max(1, FB)));
+            TEF_LAUNCH_TIMED(tef::PROF_STATS, chain_bwd_finish_kernel, dim3((unsigned)(FB * R)), dim3(256), 0, st, w, fl, g, traj,
+                             meta, ar, stats, grad_out, cyx, wmax, defer_count, defer, cmax, R, (int *)(ws + L.queue) + 8);
+            finished = true;
         } else if (w.kind == TEF_KIND_ITERATIVE)
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, (iter_chain_bwd_kernel<false, 0>), grid, dim3(256), 0, st, w, fl, g, traj, meta, ar,
-                             stats, grad_out, cyx, wmax, chunks, defer_count, defer);
+                             stats, grad_out, cyx, wmax, chunks, defer_count, defer, cmax);
         else
             TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD, linear_bwd_kernel, grid, dim3(256), 0, st, w, g, traj, meta, ar, stats,
                              grad_out, cyx, wmax, chunks);
     }
     if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
-    TEF_LAUNCH_TIMED(tef::PROF_STATS, mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax,
-                     (int *)(ws + L.queue) + 8);      // (M = 0: writes zeros)
+    if (!finished)       // (the single-scale Iterative path folds the magnitudes in its finishing launch)
+        TEF_LAUNCH_TIMED(tef::PROF_STATS, mag_reduce_kernel, dim3((unsigned)FB), dim3(256), 0, st, wmax, w.M / 64, cmax,
+                         (int *)(ws + L.queue) + 8);      // (M = 0: writes zeros)
     if (int rc = tef::check_launch("mag_reduce_kernel")) return rc;
     int rows, nbands;
     size_t lds;

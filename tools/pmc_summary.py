@@ -14,7 +14,7 @@ import json
 from collections import defaultdict
 
 KERNELS = {                      # kernel symbol prefix -> bench.py name (first match wins)
-    "iter_chain_bwd_kernel<true, 2>": "chain_bwd_rest",
+    "chain_bwd_finish_kernel": "mag_reduce",
     "iter_warp_kernel": "warp", "linear_warp_kernel": "warp", "splat_stats_kernel": "iwe_splat",
     "loss_reduce_kernel": "loss_reduce", "iter_chain_bwd_kernel": "chain_bwd",
     "linear_bwd_kernel": "chain_bwd", "dflow_splat_kernel": "dflow_splat", "pack_flow_kernel": "pack_flow",
