@@ -53,8 +53,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = ctypes.CDLL(_LIB)
+        override = os.environ.get("TEF_ORACLE_LIB")      # a sanitizer build of the same source (tools/oracle_asan.sh)
+        if not override:
+            build()
+        _lib = ctypes.CDLL(override or _LIB)
         _lib.tef_oracle_iterative.restype = ctypes.c_float
         _lib.tef_oracle_iterative.argtypes = [ctypes.POINTER(_Window), _f, ctypes.c_float]
         _lib.tef_oracle_linear.restype = ctypes.c_float
