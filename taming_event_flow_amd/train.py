@@ -402,18 +402,16 @@ class Trainer:
         records the two halves in two graphs (stage 1, stage 2) with the collective between them."""
         if not self.deferred_wgrad:
             return
-        cur = torch.cuda.current_stream() if torch.device(self.device).type == "cuda" else None
+        def tail_done():       # every reduction has been issued: wait for the ones that ran beside BPTT on the side stream
+            if self.wgrad_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.wgrad_stream)
+
         eng = self._dp_overlap()
         if eng is None:
             if stage in (0, 1):
                 submodules.flush_deferred_wgrads()
-                if self.wgrad_stream is not None:
-                    cur.wait_stream(self.wgrad_stream)
+                tail_done()
             return
-
-        def tail_done():       # every reduction that touched the decoder half has been issued: wait for the side stream's
-            if self.wgrad_stream is not None:
-                cur.wait_stream(self.wgrad_stream)
 
         if stage == 0:         # eager
             def between():
