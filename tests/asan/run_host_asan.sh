@@ -2,9 +2,13 @@
 # Host-side ASan + UBSan run of libtef_hip.so without a GPU: see tests/asan/dry_run_driver.py.   tests/asan/run_host_asan.sh
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
-LIB=$ROOT/taming_event_flow_amd/build/asan/libtef_hip_asan.so
+# (outside the tree, keyed by the sources' hash: a stale instrumented build is never tested)
+H=$(cat $ROOT/taming_event_flow_amd/csrc/* $ROOT/include/*.h $ROOT/tools/build_asan_host.sh | sha256sum | cut -c1-16)
+export TEF_ASAN_DIR=${TEF_ASAN_DIR:-/tmp/tef_asan_$H}
+DIR=$TEF_ASAN_DIR
+LIB=$DIR/libtef_hip_asan.so
 [ -f $LIB ] || $ROOT/tools/build_asan_host.sh
-STUB=$ROOT/taming_event_flow_amd/build/asan/libhipstub.so
+STUB=$DIR/libhipstub.so
 gcc -O1 -g -fPIC -shared -o $STUB $ROOT/tests/asan/hip_stub.c
 RT=$($ROOT/tools/build_asan_host.sh --runtime)
 UB=$(dirname $RT)/libclang_rt.ubsan_standalone-x86_64.so
