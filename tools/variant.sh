@@ -1,6 +1,7 @@
 #!/bin/bash
 # Experiment helper: build libtef_<name>.so from a PATCHED COPY of one translation unit (the shipped sources carry no
-# experiment hooks).  A/B runs pick the library through TEF_HIP_LIB (tools/ab.sh).
+# experiment hooks).  A/B runs pick the library through TEF_HIP_LIB (tools/ab.sh).  The variants must travel to the GPU box with
+# the snapshot, so they live in the tree: delete taming_event_flow_amd/build/variants when the experiment is over.
 #   SRC=tef_loss tools/variant.sh NAME 'sed -E expression' [-DFLAG ...]
 set -e
 PKG=/root/repo/taming_event_flow_amd
