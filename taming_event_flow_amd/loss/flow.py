@@ -13,7 +13,6 @@ buffers, bookkeeping and the autograd boundary.  There is no PyTorch/CPU fallbac
 
 import ctypes
 import weakref
-import sys
 
 import torch
 

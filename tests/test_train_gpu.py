@@ -1,6 +1,5 @@
 """GPU parity of the training-window semantics (reference train_flow.py:80-156) on the full HIP path:
 HIP encoder -> RecEVFlowNet (MFMA convs) -> Iterative loss (HIP) -> backward -> clip -> Adam, two windows."""
-import gc
 import os
 
 import numpy as np
