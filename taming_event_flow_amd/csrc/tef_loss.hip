@@ -64,8 +64,6 @@ struct Win {
     int kind, B, H, W, P, F, S, mode_div, M, Md, Mt, nplanes, nimg, scaling;
     int comp;                        // border compensation (loss/flow.py:671-681): shared mask over the window's reference times
     int nrow;                        // rows of 16 slots: ceil(Mt / 16)
-    int nchunk;                      // K1 workgroups per (head, sample): ceil(Mt / 256), 16 rows each
-    int rpb2, nb2;                   // the IWE scatter's row bands: rows per band, number of bands (band_geometry)
     int img_base[TEF_MAX_SCALES + 1];
     int off[TEF_MAX_PASSES + 1];
     int doff[TEF_MAX_PASSES + 1];
@@ -372,25 +370,6 @@ __device__ __forceinline__ bool in_image(const Win &w, uint32_t mv, int s, int t
     return (mv & (kMetaPos | kMetaNeg)) != 0u && tref >= kb1 && tref < kf;
 }
 
-// What the integer scatter (K2) reads of an event besides its position: ONE 4-byte word per temporal scale and polarity,
-//   sts[((ib * S + s) * 2 + c) * Mt + u] = the timestamp of an event of exactly polarity c (masks (1, 0) / (0, 1)) that has
-//   border bit s, NaN for everything else — the other polarity, padding, events outside the shared border mask of scale
-//   s, and events with any other mask pair: runs that hold such events take the fp64 path, which reads `meta`.
-// 12 bytes per event visit instead of 16, no flag tests in the sweep; a polarity's plane of one (head, sample) is 4 Mt
-// bytes that all images of the (head, sample) share (K2 works through them back to back on one XCD: they stay in its L2).
-__device__ __forceinline__ void store_pol_ts(const Win &w, float *__restrict__ sts, int ib, int u, bool valid, uint32_t bits,
-                                             float mp, float mn, float ts)
-{
-    const bool pos = mp == 1.0f && mn == 0.0f, neg = mp == 0.0f && mn == 1.0f;
-    const float nan = __uint_as_float(0x7fc00000u);
-    for (int s = 0; s < w.S; ++s) {
-        const bool in = valid && ((bits >> s) & 1u);
-        float *o = sts + ((size_t)ib * w.S + s) * 2 * w.Mt + u;
-        o[0] = in && pos ? ts : nan;
-        o[w.Mt] = in && neg ? ts : nan;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Row ranges.  Slots are handled in ROWS of 16 consecutive slots (= one DPP row of a wavefront; pass boundaries are
 // multiples of 64 slots, so a wavefront, and with it a row, belongs to one pass).  For every trajectory plane K1 also records, per row, the
@@ -477,55 +456,13 @@ __device__ __forceinline__ void init_row_ranges(float2 (*rng)[16], int nplanes1)
     __syncthreads();
 }
 
-// Hit masks: what the IWE scatter (K2) reads instead of the intervals.  A K1 workgroup owns 16 rows; for every plane and
-// every row band of the scatter it leaves ONE 16-bit word per polarity — bit r set when row r holds events of that polarity
-// and its interval at the plane can touch the band (an event with floor(y) = f touches image rows f and f + 1):
-//   hm[(((ib * (nplanes + 1) + plane) * nchunk + chunk) * nb2 + band) * 2 + polarity]
-// and one word per workgroup for the rows that hold events with general masks (neither exactly (1, 0) nor (0, 1)):
-//   gm[ib * nchunk + chunk]
-// A band workgroup of K2 then reads 2 bytes per 256 event slots and knows its rows: no interval tests, no lists of runs,
-// and — the point — no load whose arrival it has to wait for in the middle of its stream of event loads.
-// Every plane's words are written by every workgroup (a plane no row keeps holds empty intervals: zeros), nothing to clear.
-//   rowflags[r]: bit 0 / 1 / 2 = row r holds an event with a positive / negative / general mask
-__device__ __forceinline__ uint32_t row_flags(bool valid, float mp, float mn)
-{
-    const bool general = !((mp == 1.0f && mn == 0.0f) || (mp == 0.0f && mn == 1.0f));
-    const unsigned long long bp = __builtin_amdgcn_ballot_w64(valid && mp != 0.0f), bn = __builtin_amdgcn_ballot_w64(valid && mn != 0.0f),
-                             bg = __builtin_amdgcn_ballot_w64(valid && general);
-    const int sh = (int)(threadIdx.x & 48);
-    return (((bp >> sh) & 0xffffull) ? 1u : 0u) | (((bn >> sh) & 0xffffull) ? 2u : 0u) | (((bg >> sh) & 0xffffull) ? 4u : 0u);
-}
-
-__device__ __forceinline__ void flush_row_ranges(const Win &w, float2 (*rng)[16], const uint32_t *rowflags,
-                                                 float2 *__restrict__ yr, uint16_t *__restrict__ hm, uint16_t *__restrict__ gm,
-                                                 int ib, int chunk)
+__device__ __forceinline__ void flush_row_ranges(const Win &w, float2 (*rng)[16], float2 *__restrict__ yr, int ib, int chunk)
 {
     __syncthreads();
     const int row0 = chunk * ((int)blockDim.x >> 4);
-    const int nk = (w.nplanes + 1) * 16, iters = (nk + (int)blockDim.x - 1) / (int)blockDim.x;
-    for (int it = 0; it < iters; ++it) {          // (uniform trip count: the ballots below see whole wavefronts)
-        const int k = it * blockDim.x + threadIdx.x;
-        const bool on = k < nk;
-        const int plane = on ? k >> 4 : 0, r = k & 15;
-        const float2 iv = rng[plane][r];
-        if (on && row0 + r < w.nrow) yr[((size_t)ib * (w.nplanes + 1) + plane) * w.nrow + row0 + r] = iv;
-        const uint32_t fl = rowflags[r];
-        const bool some = on && __float_as_uint(iv.x) != 0xffffffffu;      // (an empty row: [NaN, 0])
-        const int flo = some ? (int)fminf(iv.x, 16777216.0f) : 0, fhi1 = some ? (int)fminf(iv.y, 16777216.0f) + 1 : -1;      // image rows floor(lo) .. floor(hi) + 1
-        const int sh = (int)(threadIdx.x & 48);
-        uint16_t *o = hm + (((size_t)ib * (w.nplanes + 1) + plane) * w.nchunk + chunk) * (size_t)(w.nb2 * 2);
-        for (int band = 0; band < w.nb2; ++band) {
-            const bool hit = some && fhi1 >= band * w.rpb2 && flo < (band + 1) * w.rpb2;
-            const unsigned long long mpos = __builtin_amdgcn_ballot_w64(hit && (fl & 1u)), mneg = __builtin_amdgcn_ballot_w64(hit && (fl & 2u));
-            if (on && r == 0) {
-                o[band * 2] = (uint16_t)(mpos >> sh);
-                o[band * 2 + 1] = (uint16_t)(mneg >> sh);
-            }
-        }
-    }
-    if (threadIdx.x < 64) {
-        const unsigned long long g = __builtin_amdgcn_ballot_w64(threadIdx.x < 16 && (rowflags[threadIdx.x & 15] & 4u));
-        if (threadIdx.x == 0) gm[(size_t)ib * w.nchunk + chunk] = (uint16_t)g;
+    for (int k = threadIdx.x; k < (w.nplanes + 1) * 16; k += blockDim.x) {
+        const int plane = k >> 4, r = k & 15;
+        if (row0 + r < w.nrow) yr[((size_t)ib * (w.nplanes + 1) + plane) * w.nrow + row0 + r] = rng[plane][r];
     }
 }
 
@@ -554,16 +491,14 @@ __device__ __forceinline__ void flag_bad_events(int *__restrict__ bad, int slot,
 // =============================================================================================
 __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
                                                         float2 *__restrict__ traj, uint2 *__restrict__ meta,
-                                                        float *__restrict__ sts, float2 *__restrict__ yr,
-                                                        uint16_t *__restrict__ hm, uint16_t *__restrict__ gm,
-                                                        int *__restrict__ queue, int *__restrict__ bad, int chunks)
+                                                        float2 *__restrict__ yr, int *__restrict__ queue,
+                                                        int *__restrict__ bad, int chunks)
 {
     if (blockIdx.x == 0 && threadIdx.x < kQueueInts) queue[threadIdx.x] = 0;      // work queues of the later kernels
     int ib, chunk;
     xcd_split(blockIdx.x, chunks, ib, chunk);
     if (ib >= w.F * w.B) return;
     __shared__ float2 rng[kRangePlanes][16];
-    __shared__ uint32_t rowflags[16];
     init_row_ranges(rng, w.nplanes + 1);
     const int u_raw = chunk * blockDim.x + threadIdx.x;
     const bool in_list = u_raw < w.Mt;
@@ -595,10 +530,6 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         return quad_value(load_quad(map, q, H * W), q);
     };
     store_row_range(rng, w.nplanes, valid, y0, in_list);
-    {
-        const uint32_t fl = row_flags(valid, mp, mn);
-        if ((threadIdx.x & 15) == 0) rowflags[threadIdx.x >> 4] = fl;
-    }
     if (in_list) tr[(size_t)w.nplanes * w.Mt] = make_float2(y0, x0);      // plane nplanes: where pass t sampled its own map (K7)
     // flow at the original location, shared by the first forward and the first backward step
     float2 f0 = make_float2(0.0f, 0.0f);
@@ -652,7 +583,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
             store_row_range(rng, max(k, 0), alive, y, kept && in_list);
         }
     }
-    flush_row_ranges(w, rng, rowflags, yr, hm, gm, ib, chunk);
+    flush_row_ranges(w, rng, yr, ib, chunk);
     if (!in_list) return;
     uint32_t bits = 0;
     for (int s = 0; s < w.S; ++s) {
@@ -662,7 +593,6 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         if (kb < lo && kf > hi) bits |= 1u << s;
     }
     meta[(size_t)ib * w.Mt + u] = make_uint2(valid ? pack_meta(bits, kb, kf, mp, mn) : 0u, __float_as_uint(ts));
-    store_pol_ts(w, sts, ib, u, valid, bits, mp, mn, ts);
 }
 
 // =============================================================================================
@@ -672,16 +602,14 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
 // =============================================================================================
 __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *__restrict__ flows, Events g, Events d,
                                                           float2 *__restrict__ traj, uint2 *__restrict__ meta,
-                                                          float *__restrict__ sts, float2 *__restrict__ yr,
-                                                          uint16_t *__restrict__ hm, uint16_t *__restrict__ gm,
-                                                          int *__restrict__ queue, int *__restrict__ bad, int chunks)
+                                                          float2 *__restrict__ yr, int *__restrict__ queue,
+                                                          int *__restrict__ bad, int chunks)
 {
     if (blockIdx.x == 0 && threadIdx.x < kQueueInts) queue[threadIdx.x] = 0;
     int ib, chunk;
     xcd_split(blockIdx.x, chunks, ib, chunk);
     if (ib >= w.F * w.B) return;
     __shared__ float2 rng[kRangePlanes][16];
-    __shared__ uint32_t rowflags[16];
     init_row_ranges(rng, w.nplanes + 1);
     const int u_raw = chunk * blockDim.x + threadIdx.x;
     const bool in_list = u_raw < w.Mt;
@@ -698,10 +626,6 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
     const int t = E.bin[sl];
     flag_bad_events(bad, ib * chunks + chunk, valid && !event_is_sane(ts, y0, x0, t));
     store_row_range(rng, w.nplanes, valid, y0, in_list);
-    {
-        const uint32_t fl = row_flags(valid, mp, mn);
-        if ((threadIdx.x & 15) == 0) rowflags[threadIdx.x >> 4] = fl;
-    }
     float2 f = make_float2(0.0f, 0.0f);
     if (valid) {
         Taps tp = make_taps(y0, x0, H, W);
@@ -730,11 +654,8 @@ __global__ __launch_bounds__(256) void linear_warp_kernel(Win w, const float2 *_
         store_row_range(rng, 2 * s, in, fmaxf(yf, 0.0f), has && in_list);
         store_row_range(rng, 2 * s + 1, in, fmaxf(yb, 0.0f), has && in_list);
     }
-    flush_row_ranges(w, rng, rowflags, yr, hm, gm, ib, chunk);
-    if (in_list) {
-        meta[(size_t)ib * w.Mt + u] = make_uint2(valid ? pack_meta(bits, -1, 0, mp, mn) : 0u, __float_as_uint(ts));
-        store_pol_ts(w, sts, ib, u, valid, bits, mp, mn, ts);
-    }
+    flush_row_ranges(w, rng, yr, ib, chunk);
+    if (in_list) meta[(size_t)ib * w.Mt + u] = make_uint2(valid ? pack_meta(bits, -1, 0, mp, mn) : 0u, __float_as_uint(ts));
 }
 
 // LDS image plane helpers of the two scatter kernels: [rows][W + kRowPad] 8-byte accumulators.
@@ -766,18 +687,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float v)
 template <bool FX>
 __device__ __forceinline__ float acc_value(double a)
 {
-#ifdef TEF_X_C4
-    if (FX) {
-        // (double)(int64) without the compiler's six double-rate instructions: hi * 2^32 + lo in ONE rounding (fma) is the
-        // correctly rounded double of the integer, as the conversion's; the power of two goes on the float (exact)
-        const long long b = __double_as_longlong(a);
-        const double dd = __builtin_fma((double)(int)(b >> 32), 4294967296.0, (double)(unsigned)b);
-        return (float)dd * 0x1p-46f;
-    }
-    return (float)a;
-#else
     return FX ? (float)((double)__double_as_longlong(a) * 0x1p-46) : (float)a;
-#endif
 }
 
 // =============================================================================================
@@ -911,78 +821,48 @@ __host__ __device__ inline int nz_words(int nrows, int W, int WP, int threads)
 
 // band pixels of one polarity -> (A, C + eps), the polarity's share of the focus-loss sum, and one bit per pixel "C != 0"
 // (the count of active pixels needs both polarities: image_count_kernel).  planes: first band row of C; T is plane_sz further.
-// The thread that has read a pixel's accumulators clears them, and the halo rows are cleared as well: the planes are all
-// zero again for the workgroup's next item (all-zero bits: 0.0 and integer 0 alike) without a pass of their own.
-template <bool FX>
+// CLEAR: the thread that has read a pixel's accumulators clears them, and the halo rows are cleared as well: the planes are
+// all zero again for the workgroup's next item (all-zero bits: 0.0 and integer 0 alike) without a pass of their own.
+template <bool FX, bool CLEAR = true>
 __device__ __forceinline__ void band_stats(double *planes, size_t plane_sz, int nrows, int W, int WP,
-                                           float2 *__restrict__ ar, unsigned long long *__restrict__ nzw, float &acc
-#ifdef TEF_K2_PROBE
-                                           , long long *k2p_acc
-#endif
-                                           )
+                                           float2 *__restrict__ ar, unsigned long long *__restrict__ nzw, float &acc)
 {
-#ifdef TEF_K2_PROBE
-    const long long k2p_s0 = (long long)clock64();
-#endif
     double *cp = planes, *tp = planes + plane_sz;
     auto pixel = [&](float c, float t, float2 &o) {
-#ifdef TEF_X_S2
-        float a = t * (c + kEps);
-#else
         float a = t / (c + kEps);                     // :727
-#endif
         o = make_float2(a, c + kEps);                 // (A, C + eps): what the division's backward needs (pixel_grads, K6)
         acc += a * a;                                 // :122-123
         return c != 0.0f;                             // :125 (masks are non-negative: C_pos + C_neg != 0 <=> either is)
     };
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int p = threadIdx.x; p < 2 * WP; p += blockDim.x) {      // halo rows: above the band, below it
-        const int i = p < WP ? p - WP : nrows * WP + (p - WP);
-        cp[i] = 0.0;
-        tp[i] = 0.0;
+    if (CLEAR) {
+        for (int p = threadIdx.x; p < 2 * WP; p += blockDim.x) {      // halo rows: above the band, below it
+            const int i = p < WP ? p - WP : nrows * WP + (p - WP);
+            cp[i] = 0.0;
+            tp[i] = 0.0;
+        }
     }
-#ifdef TEF_K2_PROBE
-    const long long k2p_s1 = (long long)clock64();
-    k2p_acc[8] += k2p_s1 - k2p_s0;
-#endif
     if (stats_by_column_pairs(W, WP, (int)blockDim.x)) {
         const int half = W >> 1, rstep = blockDim.x / half;
         const int rt = threadIdx.x / half, c = (threadIdx.x - rt * half) * 2;
         const int iters = (nrows + rstep - 1) / rstep;
-        // groups of four rows per thread: the eight 16-byte reads go out together, then the clears, then the arithmetic (one
-        // row at a time the loop was a chain of LDS round trips: 1.2 us per row with a neighbour workgroup's atomics queued
-        // in front of every access)
-        for (int k0 = 0; k0 < iters; k0 += 4) {       // (wave-uniform trip count: the ballots see every lane)
-            double2 dc[4], dt[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = min(rt + (k0 + u) * rstep, nrows - 1), i = r * WP + c;      // (a row past the band: re-read the last one, not used)
-                dc[u] = *reinterpret_cast<const double2 *>(cp + i);
-                dt[u] = *reinterpret_cast<const double2 *>(tp + i);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = rt + (k0 + u) * rstep, i = r * WP + c;
-                if (k0 + u < iters && r < nrows) {
+        for (int k = 0; k < iters; ++k) {             // (wave-uniform trip count: the ballots see every lane)
+            const int r = rt + k * rstep;
+            bool z0 = false, z1 = false;
+            if (r < nrows) {
+                const int i = r * WP + c;
+                double2 dc = *reinterpret_cast<const double2 *>(cp + i), dt = *reinterpret_cast<const double2 *>(tp + i);
+                if (CLEAR) {
                     *reinterpret_cast<double2 *>(cp + i) = make_double2(0.0, 0.0);
                     *reinterpret_cast<double2 *>(tp + i) = make_double2(0.0, 0.0);
                 }
+                float2 p0, p1;
+                z0 = pixel(acc_value<FX>(dc.x), acc_value<FX>(dt.x), p0);
+                z1 = pixel(acc_value<FX>(dc.y), acc_value<FX>(dt.y), p1);
+                *reinterpret_cast<float4 *>(ar + (size_t)r * W + c) = make_float4(p0.x, p0.y, p1.x, p1.y);
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u, r = rt + k * rstep;
-                if (k < iters) {                      // (uniform)
-                    bool z0 = false, z1 = false;
-                    if (r < nrows) {
-                        float2 p0, p1;
-                        z0 = pixel(acc_value<FX>(dc[u].x), acc_value<FX>(dt[u].x), p0);
-                        z1 = pixel(acc_value<FX>(dc[u].y), acc_value<FX>(dt[u].y), p1);
-                        *reinterpret_cast<float4 *>(ar + (size_t)r * W + c) = make_float4(p0.x, p0.y, p1.x, p1.y);
-                    }
-                    const unsigned long long b0 = __builtin_amdgcn_ballot_w64(z0), b1 = __builtin_amdgcn_ballot_w64(z1);
-                    if (lane == 0) *reinterpret_cast<ulonglong2 *>(nzw + 2 * (k * nwaves + wid)) = make_ulonglong2(b0, b1);
-                }
-            }
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(z0), b1 = __builtin_amdgcn_ballot_w64(z1);
+            if (lane == 0) *reinterpret_cast<ulonglong2 *>(nzw + 2 * (k * nwaves + wid)) = make_ulonglong2(b0, b1);
         }
     } else {
         const int n = nrows * W, iters = (n + (int)blockDim.x - 1) / (int)blockDim.x;
@@ -993,17 +873,16 @@ __device__ __forceinline__ void band_stats(double *planes, size_t plane_sz, int 
                 const int r = q / W, i = r * WP + (q - r * W);
                 float2 p0;
                 z = pixel(acc_value<FX>(cp[i]), acc_value<FX>(tp[i]), p0);
-                cp[i] = 0.0;
-                tp[i] = 0.0;
+                if (CLEAR) {
+                    cp[i] = 0.0;
+                    tp[i] = 0.0;
+                }
                 ar[q] = p0;
             }
             const unsigned long long b0 = __builtin_amdgcn_ballot_w64(z);
             if (lane == 0) nzw[k * nwaves + wid] = b0;
         }
     }
-#ifdef TEF_K2_PROBE
-    k2p_acc[9] += (long long)clock64() - k2p_s1;
-#endif
 }
 
 // Per image (j, head, sample): the number of pixels that hold events of either polarity (loss/flow.py:125-127) from K2's
@@ -1073,26 +952,17 @@ __device__ __forceinline__ void splat_fixed(float y, float x, float tau, int rr,
     farw.y = fmaxf(farw.y, 0.0f);
     const f32x2_e wx = {nearw.y, farw.y};
     const f32x2_e w0 = nearw.x * wx, w1 = farw.x * wx;   // (w00, w01), (w10, w11)
-    // utils/iwe.py:94-95 weights * tau, then the polarity mask (1).  Four plain multiplies: as a packed multiply by a
-    // broadcast scalar the instruction NAMES the register pair (tau, its neighbour) — where the neighbour is the destination
-    // of an event load still in flight, the compiler waits for that load (it was the next batch's).
-    const f32x2_e t0 = {w0.x * tau, w0.y * tau}, t1 = {w1.x * tau, w1.y * tau};
+    const f32x2_e t0 = w0 * tau, t1 = w1 * tau;          // utils/iwe.py:94-95 weights * tau, then the polarity mask (1)
     const int cell = __mul24(rr, WP) + (int)f0.y;        // (24-bit multiply: full rate)
     unsigned long long *c0 = cpl + cell, *q0 = tpl + cell;
-#ifdef TEF_X_NOATOM
-#define TEF_ATOM(p, v) asm volatile("" :: "v"(p), "v"(v))
-#else
-#define TEF_ATOM(p, v) atomicAdd(p, v)
-#endif
-    TEF_ATOM(c0, to_fixed(w0.x));
-    TEF_ATOM(c0 + 1, to_fixed(w0.y));
-    TEF_ATOM(c0 + WP, to_fixed(w1.x));
-    TEF_ATOM(c0 + WP + 1, to_fixed(w1.y));
-    TEF_ATOM(q0, to_fixed(t0.x));
-    TEF_ATOM(q0 + 1, to_fixed(t0.y));
-    TEF_ATOM(q0 + WP, to_fixed(t1.x));
-    TEF_ATOM(q0 + WP + 1, to_fixed(t1.y));
-#undef TEF_ATOM
+    atomicAdd(c0, to_fixed(w0.x));
+    atomicAdd(c0 + 1, to_fixed(w0.y));
+    atomicAdd(c0 + WP, to_fixed(w1.x));
+    atomicAdd(c0 + WP + 1, to_fixed(w1.y));
+    atomicAdd(q0, to_fixed(t0.x));
+    atomicAdd(q0 + 1, to_fixed(t0.y));
+    atomicAdd(q0 + WP, to_fixed(t1.x));
+    atomicAdd(q0 + WP + 1, to_fixed(t1.y));
 }
 
 // =============================================================================================
@@ -1100,278 +970,171 @@ __device__ __forceinline__ void splat_fixed(float y, float x, float tau, int rr,
 //   loss/flow.py:81-110 iwe_formatting = utils/iwe.py:63-136 get_interpolation + 4x interpolate (scatter_add_), then
 //   :725-727 A = T / (C + 1e-9) and :112-129 focus_loss.
 // A workgroup owns a ROW BAND of one polarity of one image with its two planes — event count C and weighted timestamp
-// sum T — in LDS (32 rows + 2 halo rows at 128x128 = 72 KiB; two workgroups per CU).  It reads K1's hit masks (2 bytes per
-// 256 event slots: which 16-slot rows hold events of the polarity that can touch the band), lists those rows, and streams
-// their events; an event is split into corner weights once for its eight accumulations.  When all events are in, the
-// band's pixels are turned into (A, C + eps) for the backward and into the partial sums of the focus loss: the images
-// themselves never go to memory.  Accumulators: Q17.46 integers (ds_add_u64) or fp64 (general masks / very long runs).
-// Workgroups are persistent: they pull (head, sample, image, polarity, band) items from one queue per XCD.
+// sum T — in LDS (32 rows + 2 halo rows at 128x128 = 72 KiB; two workgroups per CU).  Per 16-slot row of events it reads
+// K1's [min y, max y] interval (8 bytes) and loads the row's events only if the interval can touch the band; an event is
+// split into corner weights once for its eight accumulations.  When all events are in, the band's pixels are turned into
+// (A, R = 1/(C + eps)) for the backward and into the partial sums of the focus loss: the images themselves never go to
+// memory.  Accumulators: Q17.46 integers (ds_add_u64) or fp64 (general masks / very long runs).
+// Workgroups are persistent: they pull (image, head, sample, polarity, band) items from one queue per XCD — largest images
+// first, the bands of an image on one XCD so that its trajectory plane is fetched from HBM once.
 //   ar   [(j*FB + ib)*2 + c][H*W] float2 = (A, C + eps)
 //   part [(((j*FB + ib)*2 + c)*nbands + band)*8 + wavefront] = the wavefront's share of sum_px A_c^2 of the band
-//
-// Round 5.  Until round 4 every wavefront tested row intervals, kept a list of hit rows, loaded their events and
-// accumulated, all in one loop — and the hardware's single in-order counter of outstanding vector loads tied these
-// together: consuming a group of intervals meant waiting for every event batch issued before it (the compiler emitted
-// s_waitcnt vmcnt(0) in that loop: one full drain of the load pipeline per 64 candidate rows, ~6 per wavefront and item),
-// so streaming, weight math and LDS atomics added up instead of overlapping.  Now the rows of an item are known BEFORE its
-// sweep starts (K1's hit masks -> a block-wide scan -> one list in LDS), and the sweep is a loop whose only loads are the
-// events of THREE batches in flight per wavefront: the waits are exact (vmcnt(16 + ...)), a wavefront stalls only for
-// data it is about to use.  (A producer wavefront feeding seven consumers through an LDS ring — the same decoupling with
-// the intervals still read in the kernel — starved the consumers: its own chain of loads and LDS round trips behind the
-// other wavefronts' atomics took 15 us per item.)
-// Further:
-//   * an XCD works through the images of ONE (head, sample) after the other (its share of the (head, sample, image) units
-//     is a contiguous range in that order): the per-event words all those images share (`sts`, 4 bytes per event and
-//     polarity) stay in the XCD's L2, only the positions (8 bytes per event visit) stream from HBM;
-//   * an event visit is an 8-byte position and a 4-byte timestamp that is NaN for everything this image does not take
-//     (K1: store_pol_ts) — no flag words, no polarity / border tests;
-//   * the wavefronts' partial sums go to memory as they are (K4 adds them in a fixed order).
 // Instruction diet of round 3 (the sweep was VALU-bound at ~155 vector instructions per 64 event slots, a third of them
 // address arithmetic and lane-range bookkeeping of the event loads):
 //   * the item index goes through readfirstlane: everything derived from it (image, planes, base pointers) is scalar;
-//   * event loads at one 32-bit offset from scalar bases;
-//   * whole rows are loaded (a list entry is just the row); halo rows instead of per-corner band tests; near weights
-//     without abs / max; (y, x) as packed pairs.
+//   * an event visit is TWO 8-byte loads at one 32-bit offset from scalar bases: the position, and K1's (flags, timestamp)
+//     word pair;
+//   * whole rows are loaded; which slots of a row belong to this polarity is decided by the event's own flag bits (the
+//     integer path runs only when the passes hold no general-mask events, so a slot is pos-only, neg-only or padding):
+//     a list entry is just the row;
+//   * halo rows instead of per-corner band tests; near weights without abs / max; (y, x) as packed pairs.
 // =============================================================================================
-// MODE 0: border compensation (the reference's reachable setting): K1's per-polarity timestamp planes.  MODE 1: Iterative
-// without: alive at this reference time (kb < tref < kf), from the meta word pair.  Two instantiations (the test as a
-// run-time branch cost the default path 4 %).  Linear without compensation splats positions outside the frame and takes
-// the general path.
+// MODE 0: border compensation (the reference's reachable setting): the border bit of the image's temporal scale in the meta
+// word.  MODE 1: Iterative without: alive at this reference time (kb < tref < kf).  Two instantiations (the test as a
+// run-time branch cost the default path 4 %).  Linear without compensation splats positions
+// outside the frame and takes the general path.
 // (second argument: at least 4 wavefronts per SIMD, i.e. at most 128 VGPRs — two of these workgroups per CU)
-constexpr int kWaveCap = 128;                   // rows in a wavefront's LDS list (a wavefront with more hit rows works through them in windows)
-
-#ifdef TEF_K2_PROBE
-__device__ unsigned long long tef_k2_probe_acc[1024 * 8 * 16];      // [workgroup][wavefront][slot], accumulated over launches
-#define K2P_NOW() ((long long)clock64())
-#define K2P_ADD(slot, v) do { k2p_acc[slot] += (long long)(v); } while (0)
-#else
-#define K2P_NOW() 0ll
-#define K2P_ADD(slot, v) do { } while (0)
-#endif
-
 template <int MODE>
 __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, Events g, Events d,
                                                                      const float2 *__restrict__ traj,
                                                                      const uint2 *__restrict__ meta,
-                                                                     const float *__restrict__ sts,
-                                                                     const uint16_t *__restrict__ hm,
-                                                                     const uint16_t *__restrict__ gm,
+                                                                     const float2 *__restrict__ yr,
                                                                      float2 *__restrict__ ar,
                                                                      unsigned long long *__restrict__ nzw, int nz_cap,
                                                                      double *__restrict__ part, int rows_per_band,
                                                                      int nbands, int *__restrict__ queue)
 {
-    extern __shared__ __align__(16) double lds_img[];      // (the planes are cleared and read with 16-byte accesses)
-    __shared__ __align__(16) int hit_list[kSplat2Waves][kWaveCap];      // per wavefront: rows (16 slots) of the item that can touch the band
-    __shared__ int s_wsum[2][kSplat2Waves], s_wgen[2][kSplat2Waves], s_more[kSplat2Waves], s_item, s_next;
+    extern __shared__ double lds_img[];
+    constexpr int kRuns = 2 * TEF_MAX_PASSES;      // (grad, detached) per pass, one polarity
+    __shared__ int run_u0[kRuns], run_len[kRuns], run_cum[kRuns + 1], s_item, s_flags[2];
+    __shared__ int hit_ring[(kSplat2Threads / 64) * kRing];      // rows that can touch the band: one FIFO per wavefront
     const int FB = w.F * w.B, H = w.H, W = w.W, WP = W + kRowPad, HW = H * W;
     const int xcd = blockIdx.x & 7;
-    const int nsub = 2 * nbands;
-    // units = (head, sample, image) in that order; XCD x owns the contiguous range [x T / 8, (x + 1) T / 8)
-    const int T = w.nimg * FB;
-    const int unit_lo = (int)(((long)xcd * T) >> 3), unit_hi = (int)(((long)(xcd + 1) * T) >> 3);
-    // (the wavefront's number as a scalar: list addresses and loop exits derived from it are then scalar — with lane-wise
-    // exits the compiler merges the exit paths' outstanding loads into the loop header and waits for them there)
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int *list = hit_list[wid];
-    for (int k = lane; k < kWaveCap; k += 64) list[k] = 0;      // (stale entries are read, as rows)
-    lds_plane_zero(lds_img, 2 * (min(H, rows_per_band) + 2) * WP);      // (afterwards band_stats leaves the planes clear)
-    // the queue is read TWO items ahead: the next item is known from the start of the current one (its hit masks are
-    // fetched during the current sweep, its list is built and its first loads are issued before the current item's
-    // statistics), and nobody ever waits for the atomic's round trip
-    int queued = 0;                                  // (thread 0) the item after the next
-    if (threadIdx.x == 0) {
-        s_item = atomicAdd(&queue[xcd], 1);
-        s_next = atomicAdd(&queue[xcd], 1);
-    }
+    const int nitems = w.nimg * FB, nsub = 2 * nbands;
+    for (int k = threadIdx.x; k < (kSplat2Threads / 64) * kRing; k += blockDim.x) hit_ring[k] = 0;      // (stale entries are read, as rows)
+    if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
     __syncthreads();
-    // an item: (head, sample) ib, image j, polarity c, row band
-    struct Item {
-        bool valid;
-        int c, band, ib, j, r0, nrows;
-        Img im;
-        int ga0, ga1, gb0, gb1, ca0, na, cb0, nmask;      // the image's grad / detached slots; as K1 workgroups (one mask word each)
-    };
-    auto decode = [&](int q) -> Item {
-        Item it;
-        const int unit = unit_lo + q / nsub, sub = q - (q / nsub) * nsub;
-        it.valid = unit < unit_hi;
-        const int u = it.valid ? unit : unit_lo;
-        it.c = sub & 1;
-        it.band = sub >> 1;
-        it.ib = u / w.nimg;
-        it.j = w.order[u - it.ib * w.nimg];
-        it.r0 = it.band * rows_per_band;
-        it.nrows = min(H, it.r0 + rows_per_band) - it.r0;
-        it.im = decode_image(w, it.j);
-        // grad slots [off[le], off[he]) and detached slots M + [doff[le], doff[he]); pass boundaries are multiples of 64 slots
-        it.ga0 = w.off[it.im.le]; it.ga1 = w.off[it.im.he];
-        it.gb0 = w.M + w.doff[it.im.le]; it.gb1 = w.M + w.doff[it.im.he];
-        it.ca0 = it.ga0 >> 8;
-        it.na = it.ga1 > it.ga0 ? ((it.ga1 + 255) >> 8) - it.ca0 : 0;
-        it.cb0 = it.gb0 >> 8;
-        it.nmask = it.na + (it.gb1 > it.gb0 ? ((it.gb1 + 255) >> 8) - it.cb0 : 0);
-        return it;
-    };
-    // K1's hit-mask word of the item for its idx-th workgroup of 256 slots, cut to the rows of the image's events
-    // (.x: rows of this polarity that can touch the band, .y: rows with general masks, .z: the workgroup's first row).
-    // Mask words are dealt to the wavefronts round robin (word i to wavefront i % 8): the rows that touch a band cluster (the
-    // passes are sorted by tile), every wavefront gets its share of every cluster.
-    auto load_mask = [&](const Item &it, int pass) -> uint3 {
-        const int idx = (pass * 64 + lane) * kSplat2Waves + wid;
-        uint3 r = make_uint3(0u, 0u, 0u);
-        if (it.valid && idx < it.nmask) {
-            const bool isd = idx >= it.na;
-            const int chunk = isd ? it.cb0 + (idx - it.na) : it.ca0 + idx;
-            const int rlo = (isd ? it.gb0 : it.ga0) >> 4, rhi = (isd ? it.gb1 : it.ga1) >> 4;
-            const int lo_bit = min(max(rlo - chunk * 16, 0), 16), hi_bit = min(max(rhi - chunk * 16, 0), 16);
-            const uint32_t rmask = ((1u << hi_bit) - 1u) & ~((1u << lo_bit) - 1u);
-            const size_t o = ((((size_t)it.ib * (w.nplanes + 1) + it.im.plane) * w.nchunk + chunk) * (size_t)w.nb2 + it.band) * 2 + it.c;
-            r.x = (uint32_t)hm[o] & rmask;
-            r.y = (uint32_t)gm[(size_t)it.ib * w.nchunk + chunk] & rmask;
-            r.z = (uint32_t)chunk * 16u;
-        }
-        return r;
-    };
-    // this wavefront's hit rows with index [win_lo, win_lo + kWaveCap) among those of mask pass `mk` -> its list; returns
-    // their number (wave-local: no barrier; LDS is in order per wavefront)
-    auto list_rows = [&](const uint3 &mk, int win_lo) -> int {
-        uint32_t m = mk.x;
-        const int cnt = __builtin_popcount(m);
-        const int incl = wave_prefix_sum(cnt);
-        int pos = incl - cnt - win_lo;                   // list position of this lane's first hit row
-        while (m) {
-            const int bit = __builtin_ctz(m);
-            m &= m - 1;
-            if ((unsigned)pos < (unsigned)kWaveCap) list[pos] = (int)mk.z + bit;
-            ++pos;
-        }
-        return __builtin_amdgcn_readlane(incl, 63);
-    };
-    // A batch = four quads of (4 rows x 16 slots) from the wavefront's list.  An event visit is an 8-byte and a 4-byte load at
-    // 32-bit offsets from scalar bases.  A batch past the end of the list loads ONE line (its loads are never looked at).
-    constexpr int kQ = 4;
-    struct Quad { float y, x, ts; uint32_t mv; };
-    const uint32_t lane_off = (uint32_t)(lane & 15) * 8u;
-    const int lane_grp = lane >> 4;
-    struct Bases { const float2 *pl; const uint2 *mt; const float *st; };
-    auto bases_of = [&](const Item &it) -> Bases {
-        Bases bs;
-        bs.pl = traj + uniform_off(((size_t)it.ib * (w.nplanes + 1) + it.im.plane) * w.Mt);
-        bs.mt = meta + uniform_off((size_t)it.ib * w.Mt);
-        bs.st = sts + uniform_off((((size_t)it.ib * w.S + it.im.s) * 2 + it.c) * w.Mt);
-        return bs;
-    };
-    // e0: list entry of the batch's first row; n: entries of the list
-    auto load_batch = [&](Quad (&qd)[kQ], const Bases &bs, int e0, int n) {
-        const uint32_t row_bytes = e0 < n ? 128u : 0u;   // (scalar; no branch: the four list reads go out together)
-#pragma unroll
-        for (int k = 0; k < kQ; ++k) {
-            const uint32_t row = (uint32_t)list[(e0 + 4 * k + lane_grp) & (kWaveCap - 1)];
-            const uint32_t off = row * row_bytes + lane_off;      // slot (16 row + lane) x 8 bytes
-            const float2 pp = *at_bytes(bs.pl, off);
-            // (nothing here may LOOK at the loaded registers: a select on them makes the compiler wait for the load right
-            // where it was issued)
-            if (MODE == 0) {
-                qd[k].ts = *at_bytes(bs.st, off >> 1);
-            } else {
-                const uint2 m2 = *at_bytes(bs.mt, off);
-                qd[k].mv = m2.x;
-                qd[k].ts = __uint_as_float(m2.y);
-            }
-            qd[k].y = pp.x;                    // traj stores (y, x) in (.x, .y)
-            qd[k].x = pp.y;
-        }
-    };
-    Item cur = decode(__builtin_amdgcn_readfirstlane(s_item));
-    uint3 mk = load_mask(cur, 0);                    // the first 512 mask words of an item travel in registers
-    Quad qa[kQ], qb[kQ];                             // the two batches in flight (across the statistics of the previous item)
-    int nlist = list_rows(mk, 0);                    // entries of this wavefront's list (of the mask pass being worked on)
-    {
-        const Bases bs = bases_of(cur);
-        load_batch(qa, bs, 0, min(nlist, kWaveCap));
-        load_batch(qb, bs, 16, min(nlist, kWaveCap));
-    }
-    int par = 0;
-    if (lane == 0) {
-        s_wsum[par][wid] = nlist;
-        s_wgen[par][wid] = __builtin_amdgcn_ballot_w64(mk.y != 0u) != 0ull;
-    } else {
-        (void)__builtin_amdgcn_ballot_w64(mk.y != 0u);
-    }
-    lds_barrier();
-    const long long k2p_start = K2P_NOW();
-#ifdef TEF_K2_PROBE
-    long long k2p_acc[16] = {0};
-#endif
-    while (cur.valid) {
-        // here: this wavefront's list of the item (first mask pass, first window) is built, its first two batches are in
-        // flight, the wavefronts' row counts are published
-        const long long k2p_t0 = K2P_NOW();
-        if (wid == 1) K2P_ADD(0, 1);
-        const int c = cur.c, band = cur.band, ib = cur.ib, j = cur.j, r0 = cur.r0, nrows = cur.nrows, b = ib % w.B;
-        const Img im = cur.im;
+    for (;;) {
+        const int q = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: everything derived from it is scalar
+        const int it = xcd + 8 * (q / nsub), sub = q - (q / nsub) * nsub;
+        if (it >= nitems) break;
+        const int c = sub & 1, band = sub >> 1;          // polarity, row band
+        const int j = w.order[it / FB], ib = it % FB, b = ib % w.B;
+        const int r0 = band * rows_per_band, nrows = min(H, r0 + rows_per_band) - r0;
+        const Img im = decode_image(w, j);
         const double rdelta = 1.0 / (double)im.delta;
+        const float band_lo = (float)(r0 - 1), band_hi = (float)(r0 + nrows);     // rows floor(y), floor(y) + 1 of an event
         // planes: [C | T], each nrows + 2 rows (halo row, the band, halo row) of WP accumulators
         const size_t plane_sz = (size_t)(nrows + 2) * WP;
         double *img_c = lds_img, *img_t = lds_img + plane_sz;
-        const Bases bs = bases_of(cur);
-        const Item nxt = decode(__builtin_amdgcn_readfirstlane(s_next));
-        uint3 mkn = load_mask(nxt, 0);                   // the next item's masks (issued here, looked at below)
-        int total = 0;
-        bool any_general = false;
-#pragma unroll
-        for (int k = 0; k < kSplat2Waves; ++k) {
-            total += s_wsum[par][k];
-            any_general = any_general || s_wgen[par][k] != 0;
+        lds_plane_zero(lds_img, 2 * (nrows + 2) * WP);         // all-zero bits: 0.0 and integer 0 alike
+        // run list of the integer path (the [pos-only] or [neg-only] slots of every pass / list) + accumulator choice
+        const int nb = im.he - im.le, nlists = w.Md > 0 ? 2 : 1, nruns = nb * nlists;
+        if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
+        __syncthreads();                                  // (also: everybody has read s_item)
+        int next_item = 0;
+        if (threadIdx.x == 0) next_item = atomicAdd(&queue[xcd], 1);      // in flight while this item is worked on
+        if ((int)threadIdx.x < nruns) {
+            const int r = threadIdx.x;
+            const bool isd = r >= nb;
+            const int t = im.le + (isd ? r - nb : r);
+            const int *cl = (isd ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
+            run_u0[r] = (isd ? w.M + w.doff[t] : w.off[t]) + (c ? cl[0] : 0);
+            run_len[r] = c ? cl[1] - cl[0] : cl[0];
+            if (cl[2] != cl[1]) atomicOr(&s_flags[0], 1);                  // general masks present
+            atomicAdd(&s_flags[1], run_len[r]);
         }
-        const int mpasses = (cur.nmask + kSplat2Threads - 1) / kSplat2Threads;      // (1 unless the image holds > 131072 slots)
-        if (mpasses > 1) {      // (workgroup-uniform) the rows of the further mask passes count as well
-            int more = 0;
-            bool gen = false;
-            for (int ps = 1; ps < mpasses; ++ps) {
-                const uint3 m2 = load_mask(cur, ps);
-                more += __builtin_popcount(m2.x);
-                gen = gen || m2.y != 0u;
+        __syncthreads();
+        if (threadIdx.x < 64) {       // rows (16 slots) spanned by every run, as a running total: one wavefront scans
+            int carry = 0;
+            for (int base_r = 0; base_r < nruns; base_r += 64) {
+                const int r = base_r + (int)threadIdx.x;
+                int cnt = 0;
+                if (r < nruns && run_len[r] > 0) cnt = ((run_u0[r] + run_len[r] - 1) >> 4) - (run_u0[r] >> 4) + 1;
+                int incl = cnt;
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    int up = __shfl_up(incl, sft, 64);
+                    if ((int)threadIdx.x >= sft) incl += up;
+                }
+                if (r < nruns) run_cum[r] = carry + incl - cnt;
+                carry += __shfl(incl, 63, 64);
             }
-            more = __builtin_amdgcn_readlane(wave_prefix_sum(more), 63);
-            const bool wgen = __builtin_amdgcn_ballot_w64(gen) != 0ull;
-            if (lane == 0) s_more[wid] = more | (wgen ? (int)0x80000000 : 0);
-            lds_barrier();
-#pragma unroll
-            for (int k = 0; k < kSplat2Waves; ++k) {
-                total += s_more[k] & 0x7fffffff;
-                any_general = any_general || s_more[k] < 0;
-            }
-            lds_barrier();
+            if (threadIdx.x == 0) run_cum[nruns] = carry;
         }
-        // (Linear without border compensation: positions outside the frame; Q17.46 holds < 2^17 events per pixel)
-        const bool fixed = !any_general && total * 16 < kFxMaxEvents && (w.comp || w.kind == TEF_KIND_ITERATIVE);
-        // The masks are taken in HERE: loads retire in order, so this waits for the two batches issued before them — which are
-        // needed now anyway.  Left to the compiler, the wait lands in the middle of the sweep (where a register is reused)
-        // as a full drain of the event loads.
-        asm volatile("" : "+v"(mkn.x), "+v"(mkn.y), "+v"(mkn.z));
-        K2P_ADD(1, K2P_NOW() - k2p_t0);
-        const long long k2p_tb1 = K2P_NOW();
+        __syncthreads();
+        const bool fixed = s_flags[0] == 0 && s_flags[1] < kFxMaxEvents && (w.comp || w.kind == TEF_KIND_ITERATIVE);
+        const float2 *pl = traj + uniform_off(((size_t)ib * (w.nplanes + 1) + im.plane) * w.Mt);
+        const uint2 *mt = meta + uniform_off((size_t)ib * w.Mt);
         if (fixed) {
+            // Wave-centric sweep.  The rows (16 slots) of all runs form one flattened sequence; a wavefront takes 128 rows at
+            // a time (eight chunks of 16, see load_range): every lane reads two row intervals, the rows that can touch
+            // the band are compacted into the wavefront's list, and the wavefront then works through the list in batches of
+            // 16 rows (four quads of 4 x 16 lanes) with the next batch's events already in flight.  Iterations are dense in
+            // work whatever the fraction of rows that hit (a workgroup-wide chunk loop spent a memory round trip per mostly
+            // skipped chunk: 0.30 ms instead of 0.21).
+            const float2 *rows = yr + uniform_off(((size_t)ib * (w.nplanes + 1) + im.plane) * w.nrow);
+            const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+            const int total_rows = run_cum[nruns];
+            int *ring = hit_ring + wid * kRing;      // this wavefront's FIFO of hit rows (entry i lives at i & (kRing - 1))
+            int run_hint = 0;                        // run of the first row of the group being located (wave-uniform, monotone)
+            // Rows are dealt to the wavefronts in chunks of 16 (one 128-byte line of intervals), chunk c to wavefront
+            // c % nwaves: hits cluster over hundreds of rows (the passes are sorted by tile), so with 128 consecutive rows
+            // per wavefront and ~3 such groups per item the wavefronts waited 30 % of an item for the slowest of them.
+            // m-th load of a wavefront: its chunks 4m .. 4m + 3, 16 lanes each.
+            auto load_range = [&](int m, int &row_out) -> float2 {
+                const int first = (m * 4 * nwaves + wid) * 16;                      // (wave-uniform)
+                const int fr = first + (lane >> 4) * (nwaves * 16) + (lane & 15);
+                float2 rg = make_float2(__uint_as_float(0xffffffffu), 0.0f);
+                row_out = 0;
+                if (first < total_rows) {
+                    while (__builtin_amdgcn_readfirstlane(run_cum[run_hint + 1]) <= first) ++run_hint;
+                }
+                if (fr < total_rows) {
+                    int r = run_hint;                // the lanes' rows follow the group's first: a step or two at most
+                    while (run_cum[r + 1] <= fr) ++r;
+                    row_out = (run_u0[r] >> 4) + (fr - run_cum[r]);
+                    rg = rows[row_out];
+                }
+                return rg;
+            };
+            // A batch = 16 ring entries = four quads of (4 rows x 16 slots).  An event visit is two 8-byte loads at the same
+            // 32-bit offset from scalar bases.  Entries past the tail hold rows seen earlier (or row 0): their loads are
+            // harmless and they are discarded when the batch is processed (`rem`).
+            constexpr int kQ = 4;
+            struct Quad { uint32_t mv; float y, x, ts; };
+            const uint32_t lane_off = (uint32_t)(lane & 15) * 8u;
+            const int lane_grp = lane >> 4;
+            auto load_batch = [&](Quad (&qd)[kQ], int pos) {
+#pragma unroll
+                for (int k = 0; k < kQ; ++k) {
+                    const uint32_t off = (uint32_t)ring[(pos + 4 * k + lane_grp) & (kRing - 1)] * 128u + lane_off;   // slot (16 row + lane) x 8 bytes
+                    const uint2 m2 = *at_bytes(mt, off);
+                    const float2 pp = *at_bytes(pl, off);
+                    // (nothing here may LOOK at the loaded registers: a select on them makes the compiler wait for the
+                    // load right where it was issued — that is how round 3's first version of this loop lost its
+                    // prefetch)
+                    qd[k].mv = m2.x;
+                    qd[k].ts = __uint_as_float(m2.y);
+                    qd[k].y = pp.x;                    // traj stores (y, x) in (.x, .y)
+                    qd[k].x = pp.y;
+                }
+            };
             unsigned long long *cpl = reinterpret_cast<unsigned long long *>(img_c), *tpl = reinterpret_cast<unsigned long long *>(img_t);
             const uint32_t polbit = c ? kMetaNeg : kMetaPos;
             const int r0m1 = r0 - 1;
-            // rem: list entries from the batch's first on (quad k's lane group g holds entry 4 k + g of those)
+            const uint32_t need = polbit | (1u << im.s);
+            // rem: list entries left at the batch's first one (a quad's lane group g holds entry 4 k + g)
             auto process = [&](const Quad (&qd)[kQ], int rem) {
 #pragma unroll
                 for (int k = 0; k < kQ; ++k) {
-                    bool take = qd[k].ts == qd[k].ts;                      // this polarity + border mask (:671-681): K1's NaN otherwise
+                    const uint32_t mv = qd[k].mv;
+                    bool take = (mv & need) == need;                       // this polarity + border mask (:671-681)
                     if (MODE == 1) {
-                        const uint32_t mv = qd[k].mv;
                         const int kb1 = (int)((mv >> 8) & 0xffu), kf = (int)((mv >> 16) & 0xffu);
                         take = (mv & polbit) != 0u && im.plane >= kb1 && im.plane < kf;
                     }
                     const int rr = (int)floorf(qd[k].y) - r0m1;          // halo row 0 = image row r0 - 1
                     take = take && (unsigned)rr <= (unsigned)nrows && lane_grp < rem - 4 * k;
-#ifdef TEF_X_NOPROC
-                    take = take && im.tref < -1.0f;
-#endif
                     if (take) {
                         // tau = 1 - |tref - ts| / delta (:94-95); delta is an integer number of passes: exact division by a constant
                         const float tau = 1.0f - div_by_const(fabsf(im.tref - qd[k].ts), rdelta);
@@ -1379,33 +1142,55 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
                     }
                 }
             };
-            // Two register sets in turn; the loop's only loads are the events, its waits are exact.  ONE exit, at the end of
-            // the body (with an exit after every process() the compiler funnels them through one latch block and has to
-            // assume, at the top of the loop, the outstanding loads of ALL of them).
-            for (int ps = 0, win_lo = 0;;) {
-                const int n = min(nlist - win_lo, kWaveCap);
-                int e0 = 0;
-                do {
-                    process(qa, n - e0);
-                    load_batch(qa, bs, e0 + 32, n);
-                    process(qb, n - e0 - 16);
-                    load_batch(qb, bs, e0 + 48, n);
-                    e0 += 32;
-                } while (e0 < n);
-                // a wavefront with more hit rows than its list holds: the next kWaveCap of them; an image of more than 512
-                // mask words: the next pass (both wave-local)
-                win_lo += kWaveCap;
-                if (win_lo >= nlist) {
-                    if (++ps >= mpasses) break;
-                    mk = load_mask(cur, ps);
-                    win_lo = 0;
+            // The hit rows of the whole item form ONE stream per wavefront: candidate groups of 64 rows (one interval per lane,
+            // two groups in flight) are tested and their hits appended to the ring; batches are taken from its head.  The
+            // event loads of the next batch are always in flight, across candidate groups (round 2 / the first round-3
+            // version drained and restarted the load pipeline every 128 candidates and issued a batch of discarded loads
+            // each time; the scatter is bound by how many bytes a wavefront keeps in flight).
+            int tail = 0, head = 0;                  // entries produced / handed to load_batch (wave-uniform)
+            int next_m = 0;                          // oldest candidate group in flight
+            float2 rg_a, rg_b;
+            int row_a, row_b;
+            rg_a = load_range(0, row_a);
+            rg_b = load_range(1, row_b);
+            auto more = [&]() { return (next_m * 4 * nwaves + wid) * 16 < total_rows; };      // (wave-uniform)
+            auto top_up = [&]() {                    // keep two batches' worth of entries ahead of the loads while candidates last
+                while (tail - head < 8 * kQ && more()) {
+                    const bool hit = rg_a.y >= band_lo && rg_a.x < band_hi;      // (NaN for an empty / absent row)
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+                    if (hit) ring[(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0))) & (kRing - 1)] = row_a;
+                    tail += __builtin_popcountll(mask);
+                    rg_a = rg_b;
+                    row_a = row_b;
+                    ++next_m;
+                    rg_b = load_range(next_m + 1, row_b);
                 }
-                nlist = list_rows(mk, win_lo);
-                load_batch(qa, bs, 0, min(nlist - win_lo, kWaveCap));
-                load_batch(qb, bs, 16, min(nlist - win_lo, kWaveCap));
+                __builtin_amdgcn_wave_barrier();
+            };
+            // Two register sets in turn.  Every load_batch is UNCONDITIONAL on the path to the process() that follows it: the
+            // hardware counts outstanding loads in order, and where a path may or may not have issued the younger batch the
+            // compiler has to wait for the smaller count — i.e. for the prefetch itself.
+            // (ring capacity: at most 8 kQ - 1 + 64 entries are ahead of `head`, 8 kQ behind it are still being worked on)
+            Quad qa[kQ], qb[kQ];
+            top_up();
+            load_batch(qa, head);
+            int rem_a = tail - head, rem_b;
+            head += 4 * kQ;
+            for (;;) {
+                top_up();
+                load_batch(qb, head);
+                rem_b = tail - head;
+                head += 4 * kQ;
+                process(qa, rem_a);
+                if (rem_b <= 0) break;               // (the stream had run dry when qb was issued)
+                top_up();
+                load_batch(qa, head);
+                rem_a = tail - head;
+                head += 4 * kQ;
+                process(qb, rem_b);
+                if (rem_a <= 0) break;
             }
         } else {
-            const int nlists = w.Md > 0 ? 2 : 1;
             for (int li = 0; li < nlists; ++li)
                 for (int t = im.le; t < im.he; ++t) {
                     const int *cl = (li ? d.cls : g.cls) + ((size_t)b * TEF_MAX_PASSES + t) * 3;
@@ -1413,79 +1198,25 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
                     const int n0 = cl[0], n01 = cl[1], n012 = cl[2];
                     double *gc = img_c + WP, *gt = img_t + WP;          // (the band proper: past the halo row)
                     if (c == 0) {
-                        splat_run_general(w, im, rdelta, g, d, b, c, s0, n0, bs.pl, bs.mt, gc, gt, r0, nrows);
-                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n01, n012 - n01, bs.pl, bs.mt, gc, gt, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0, n0, pl, mt, gc, gt, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n01, n012 - n01, pl, mt, gc, gt, r0, nrows);
                     } else {
-                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n0, n012 - n0, bs.pl, bs.mt, gc, gt, r0, nrows);
+                        splat_run_general(w, im, rdelta, g, d, b, c, s0 + n0, n012 - n0, pl, mt, gc, gt, r0, nrows);
                     }
                 }
-            // (this path's loads end HERE, explicitly: the barriers of this loop do not wait for loads, and whatever the
-            // compiler thinks may still be in flight when it comes round to the integer path, it waits for in there)
-            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
         }
-        // ---- the next item's list and first loads (wave-local), before this item's statistics ----
-        mk = mkn;
-        nlist = list_rows(mk, 0);
-        {
-            const Bases bn = bases_of(nxt);
-            load_batch(qa, bn, 0, min(nlist, kWaveCap));
-            load_batch(qb, bn, 16, min(nlist, kWaveCap));
-        }
-        // The queue, two items ahead; its answer is taken at the end of this item.  Issued behind the compiler's back: where it
-        // knows of a returning atomic in flight it waits for it at the next join of control flow — here that is a drain
-        // (s_waitcnt vmcnt(0)) of the loads just issued, in every wavefront.
-        if (threadIdx.x == 0)
-            // (s_nop: the address may just have been put into its scalar registers by a vector instruction — v_readlane of a
-            // spilled register — and the hazard recogniser does not look into inline assembly: 5 wait states before a memory
-            // instruction reads them)
-            asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(queued) : "v"(0), "v"(1), "s"(queue + xcd) : "memory");
-        par ^= 1;
-        {
-            const bool wgen = __builtin_amdgcn_ballot_w64(mk.y != 0u) != 0ull;
-            if (lane == 0) {
-                s_wsum[par][wid] = nlist;
-                s_wgen[par][wid] = wgen;
-            }
-        }
-        const long long k2p_te = K2P_NOW();
-        K2P_ADD(4, k2p_te - k2p_tb1);
-        lds_barrier();                                    // every event of the item is in
-        const long long k2p_tb2 = K2P_NOW();
-        K2P_ADD(5, k2p_tb2 - k2p_te);
+        __syncthreads();
         // ---- band statistics of this polarity (round 1: a separate launch over the stored images) ----
         float acc = 0.0f;
         const size_t qpol = ((size_t)j * FB + ib) * 2 + c, o = qpol * HW + (size_t)r0 * W;
         unsigned long long *nzo = nzw + (qpol * nbands + band) * nz_cap;
-#ifdef TEF_X_NOSTATS
-        if (im.tref < -1.0f)
-#endif
-        {
-#ifdef TEF_K2_PROBE
-        if (fixed) band_stats<true>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc, k2p_acc);
-        else band_stats<false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc, k2p_acc);
-#else
-        if (fixed) band_stats<true>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
-        else band_stats<false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
-#endif
-        }
+        if (fixed) band_stats<true, false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
+        else band_stats<false, false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
         const double dacc = wave_sum_to_last((double)acc);
-        if (lane == 63) part[(qpol * nbands + band) * kSplat2Waves + wid] = dacc;      // (image_count_kernel adds the shares, fixed order)
-        if (threadIdx.x == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(queued) : : "memory");      // (the queue's answer, asked for before the statistics)
-            s_item = s_next;
-            s_next = queued;
-        }
-        cur = nxt;
-        const long long k2p_ts = K2P_NOW();
-        K2P_ADD(6, k2p_ts - k2p_tb2);
-        lds_barrier();                                    // the planes are clear again, the queue has moved on
-        K2P_ADD(7, K2P_NOW() - k2p_ts);
+        if ((threadIdx.x & 63) == 63) part[(qpol * nbands + band) * kSplat2Waves + (threadIdx.x >> 6)] = dacc;      // (image_count_kernel adds the wavefronts' shares, fixed order)
+        if (threadIdx.x == 0) s_item = next_item;
+        __syncthreads();                                  // the planes have been read, the next item may clear them
     }
-    if (wid == 1) { K2P_ADD(13, K2P_NOW() - k2p_start); K2P_ADD(14, 1); }
-#ifdef TEF_K2_PROBE
-    if (lane == 0 && blockIdx.x < 1024)
-        for (int k = 0; k < 16; ++k) tef_k2_probe_acc[((size_t)blockIdx.x * 8 + wid) * 16 + k] += (unsigned long long)k2p_acc[k];
-#endif
 }
 
 // K4: per-image statistics from the band parts of K2, stats[q] = (sum A^2 / n, n = #active pixels + 1e-9), and
@@ -2597,7 +2328,7 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
 // Host side
 // ---------------------------------------------------------------------------------------------
 struct Layout {
-    size_t traj, meta, sts, yr, hm, gm, ar, nz, counts, sq, stats, parts, queue, cmax, wmax, defer, cyx, bad, total;
+    size_t traj, meta, yr, ar, nz, counts, sq, stats, parts, queue, cmax, wmax, defer, cyx, bad, total;
     int nz_cap;      // 64-bit words of "C != 0" bits per (image, head, sample, polarity, band)
 };
 
@@ -2622,12 +2353,6 @@ bool make_win(const tef_loss_cfg *c, Win *w)
     w->scaling = c->loss_scaling ? 1 : 0;
     w->comp = c->border_compensation ? 1 : 0;
     w->nrow = (w->Mt + 15) / 16;
-    w->nchunk = (w->Mt + 255) / 256;
-    {
-        const int rows = std::max(1, std::min(c->H, (int)(kSplat2LdsBudget / ((size_t)2 * (c->W + kRowPad) * sizeof(double))) - 2));
-        w->nb2 = (c->H + rows - 1) / rows;
-        w->rpb2 = (c->H + w->nb2 - 1) / w->nb2;      // (= band_geometry(w, 2, ..., kSplat2LdsBudget, 2): equal bands)
-    }
     w->nplanes = (c->kind == TEF_KIND_ITERATIVE) ? c->P + 1 : 2 * c->S;
     if (c->M < 0 || c->Md < 0 || c->off[0] != 0 || c->doff[0] != 0 || c->off[c->P] != c->M || c->doff[c->P] != c->Md)
         return tef::fail("inconsistent slot offsets");
@@ -2697,10 +2422,7 @@ Layout make_layout(const Win &w)
     size_t o = 0;
     L.traj = o;   o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.Mt * sizeof(float2));      // + the original locations
     L.meta = o;   o += align_up(FB * (size_t)w.Mt * sizeof(uint2));
-    L.sts = o;    o += align_up(FB * (size_t)w.S * 2 * (size_t)w.Mt * sizeof(float));
     L.yr = o;     o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.nrow * sizeof(float2));
-    L.hm = o;     o += align_up(FB * (size_t)(w.nplanes + 1) * (size_t)w.nchunk * (size_t)w.nb2 * 2 * sizeof(uint16_t));
-    L.gm = o;     o += align_up(FB * (size_t)w.nchunk * sizeof(uint16_t));
     L.ar = o;     o += align_up(img * sizeof(float2));
     L.stats = o;  o += align_up((size_t)w.nimg * FB * 2 * sizeof(float));
     {
@@ -2769,21 +2491,6 @@ bool ensure_attrs()
 }  // namespace
 
 extern "C" {
-
-#ifdef TEF_K2_PROBE
-// experiment builds only: read and clear K2's phase counters
-int tef_k2_probe_read(unsigned long long *out)
-{
-    static unsigned long long host[1024 * 8 * 16];
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(tef_k2_probe_acc), sizeof(host)) != hipSuccess) return -1;
-    for (int k = 0; k < 16; ++k) out[k] = 0;
-    for (size_t i = 0; i < sizeof(host) / sizeof(host[0]); ++i) out[i & 15] += host[i];
-    memset(host, 0, sizeof(host));
-    if (hipMemcpyToSymbol(HIP_SYMBOL(tef_k2_probe_acc), host, sizeof(host)) != hipSuccess) return -1;
-    return 0;
-}
-#endif
 
 size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg)
 {
@@ -2894,9 +2601,7 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
     char *ws = (char *)workspace;
     float2 *traj = (float2 *)(ws + L.traj);
     uint2 *meta = (uint2 *)(ws + L.meta);
-    float *sts = (float *)(ws + L.sts);
     float2 *yr = (float2 *)(ws + L.yr);
-    uint16_t *hm = (uint16_t *)(ws + L.hm), *gm = (uint16_t *)(ws + L.gm);
     int *queue = (int *)(ws + L.queue);
     int *bad = (int *)(ws + L.bad);
     float2 *ar = (float2 *)(ws + L.ar);
@@ -2910,9 +2615,9 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
         int chunks = (w.Mt + 255) / 256;
         dim3 grid(xcd_grid(FB, chunks));
         if (w.kind == TEF_KIND_ITERATIVE)
-            TEF_LAUNCH_TIMED(tef::PROF_WARP, iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, sts, yr, hm, gm, queue, bad, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_WARP, iter_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, yr, queue, bad, chunks);
         else
-            TEF_LAUNCH_TIMED(tef::PROF_WARP, linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, sts, yr, hm, gm, queue, bad, chunks);
+            TEF_LAUNCH_TIMED(tef::PROF_WARP, linear_warp_kernel, grid, dim3(256), 0, st, w, fl, g, d, traj, meta, yr, queue, bad, chunks);
     }
     if (int rc = tef::check_launch("warp_kernel")) return rc;
     int rows, nbands;
@@ -2930,10 +2635,10 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
         grid = std::max(8u, (grid + 7u) & ~7u);
         if (w.comp || w.kind != TEF_KIND_ITERATIVE)
             TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel<0>, dim3(grid), dim3(kSplat2Threads), lds, st, w, g, d, traj, meta,
-                             sts, hm, gm, ar, nz, L.nz_cap, (double *)(ws + L.parts), rows, nbands, queue);
+                             yr, ar, nz, L.nz_cap, (double *)(ws + L.parts), rows, nbands, queue);
         else
             TEF_LAUNCH_TIMED(tef::PROF_SPLAT, splat_stats_kernel<1>, dim3(grid), dim3(kSplat2Threads), lds, st, w, g, d, traj, meta,
-                             sts, hm, gm, ar, nz, L.nz_cap, (double *)(ws + L.parts), rows, nbands, queue);
+                             yr, ar, nz, L.nz_cap, (double *)(ws + L.parts), rows, nbands, queue);
     }
     if (int rc = tef::check_launch("splat_stats_kernel")) return rc;
     int *bad_img = bad + FB * ((w.Mt + 255) / 256 + 1);
