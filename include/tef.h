@@ -404,6 +404,11 @@ size_t tef_l2_norm_scratch_bytes(void);
 int tef_l2_norm(const float *x, size_t n, void *scratch, float *out, float *step, void *stream);
 int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const float *norm, float max_norm, double lr,
                        double beta1, double beta2, double eps, const float *step, void *stream);
+/* The same with the hyper-parameters read from DEVICE memory at run time, hp = {lr, beta1, beta2, eps, max_norm} (doubles;
+ * max_norm <= 0: no clipping): a training window captured in a hipGraph follows a learning-rate schedule — the host
+ * refreshes the five numbers before a replay (an ordinary copy, outside the graph) — instead of being captured again. */
+int tef_adam_clip_step_hp(float *p, float *g, float *m, float *v, size_t n, const float *norm, const double *hp,
+                          const float *step, void *stream);
 
 /* ---- validation metrics (loss/flow_val.py; evaluation only, batch 1, no gradients) ---------------------------------
  * Flow maps are planar [H][W] (fx, fy separately); event lists are loc [N][2] = (y, x), ts [N], mask [N][2]. */

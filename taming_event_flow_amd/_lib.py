@@ -171,6 +171,7 @@ SIGNATURES = {
     "tef_l2_norm": (ctypes.c_int, [_fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_adam_clip_step": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, ctypes.c_float, ctypes.c_double,
                                           ctypes.c_double, ctypes.c_double, ctypes.c_double, _fp, _fp]),
+    "tef_adam_clip_step_hp": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_gru_blend": (ctypes.c_int, [_fp, _fp, _fp, ctypes.c_size_t, _fp, _fp]),
     "tef_gru_blend_backward": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_size_t, _fp, _fp, _fp, _fp]),
     "tef_val_event_step": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int,

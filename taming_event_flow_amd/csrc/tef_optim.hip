@@ -52,11 +52,18 @@ __global__ __launch_bounds__(256) void norm_final_kernel(const double *__restric
 
 // torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False) on flat buffers, gradient clipped by `scale` first and
 // cleared afterwards.  Op order of torch's _single_tensor_adam: lerp, mul + addcmul, sqrt / sqrt(bc2) + eps, addcdiv.
+// Hyper-parameters: by value (hp == nullptr), or read from DEVICE memory, hp = {lr, beta1, beta2, eps, max_norm} as doubles:
+// a window captured in a hipGraph then follows a learning-rate schedule without being captured again (the host refreshes
+// the five numbers before a replay).
 __global__ __launch_bounds__(256) void adam_clip_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                         float *__restrict__ v, size_t n, const float *__restrict__ norm,
                                                         float max_norm, double lr, double b1d, double b2d, double epsd,
-                                                        const float *__restrict__ step)
+                                                        const double *__restrict__ hp, const float *__restrict__ step)
 {
+    if (hp) {
+        lr = hp[0]; b1d = hp[1]; b2d = hp[2]; epsd = hp[3];
+        max_norm = (float)hp[4];
+    }
     const float t = step[0];
     float scale = 1.0f;
     if (max_norm > 0.0f) {
@@ -119,7 +126,22 @@ int tef_adam_clip_step(float *p, float *g, float *m, float *v, size_t n, const f
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm, max_norm, lr, beta1,
-                       beta2, eps, step);
+                       beta2, eps, (const double *)nullptr, step);
+    return tef::check_launch("adam_clip_kernel");
+}
+
+int tef_adam_clip_step_hp(float *p, float *g, float *m, float *v, size_t n, const float *norm, const double *hp,
+                          const float *step, void *stream)
+{
+    if (!p || !g || !m || !v || !norm || !step || !hp) return tef::fail("tef_adam_clip_step_hp: null pointer"), TEF_ERR_INVALID;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)
+        return tef::fail("tef_adam_clip_step_hp: buffers must be 16-byte aligned"), TEF_ERR_INVALID;
+    const size_t n4 = n >> 2;
+    unsigned blocks = (unsigned)((n4 + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, norm, 0.0f, 0.0, 0.0, 0.0,
+                       0.0, hp, step);
     return tef::check_launch("adam_clip_kernel");
 }
 

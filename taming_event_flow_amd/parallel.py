@@ -98,6 +98,12 @@ class FusedAdam:
         self.step_count = torch.zeros((1,), dtype=torch.float32, device=flat_g.device)
         self.norm = torch.zeros((1,), dtype=torch.float32, device=flat_g.device)
         self.scratch = torch.empty((_lib.lib().tef_l2_norm_scratch_bytes(),), dtype=torch.uint8, device=flat_g.device)
+        # lr, beta1, beta2, eps, max_norm as the KERNEL reads them: device memory, refreshed from param_groups[0] whenever a
+        # value changed (refresh_hyperparams).  A window captured in a hipGraph therefore follows a learning-rate schedule
+        # or a load_state_dict without being captured again.
+        self.hp = torch.zeros((5,), dtype=torch.float64, device=flat_g.device)
+        self._hp_uploaded = None
+        self._max_norm = -1.0
 
     @property
     def lr(self):
@@ -139,19 +145,33 @@ class FusedAdam:
             if k != "params":
                 self.param_groups[0][k] = tuple(v) if k == "betas" else v
 
+    def refresh_hyperparams(self):
+        """Upload (lr, betas, eps, max_norm) if any of them changed since the last upload.  Called by step() outside graph
+        capture and by CapturedWindow.replay() before the graph is launched; the copy is stream-ordered before whatever
+        is enqueued next and blocks the host only when something changed (a pageable source)."""
+        g = self.param_groups[0]
+        vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(self._max_norm))
+        if vals != self._hp_uploaded:
+            self.hp.copy_(torch.tensor(vals, dtype=torch.float64))
+            self._hp_uploaded = vals
+
     def step(self, max_norm=None):
         """Clip the (already reduced) flat gradient to `max_norm` (None: no clipping), apply Adam, clear the gradient.
         -> the gradient's global norm before clipping (a 1-element device tensor, overwritten by the next step).  The
-        learning rate is read from param_groups[0]["lr"] at every call (a captured window holds the value it was captured
-        with: re-capture after changing it)."""
+        hyper-parameters are read by the kernel from device memory (`hp`): param_groups[0] at the time of the call — or,
+        for a captured window, at the time of each replay."""
         lib, n = self._lib.lib(), self.bucket.flat.numel()
         st = self._lib.stream_ptr()
+        self._max_norm = -1.0 if max_norm is None else float(max_norm)
+        if not (self.hp.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self.refresh_hyperparams()      # (inside a capture: the values are uploaded before every replay instead)
+        elif self._hp_uploaded is None or self._hp_uploaded[4] != self._max_norm:
+            raise RuntimeError("FusedAdam.step: captured with a max_norm no eager step has uploaded (run a warm-up window)")
         self._lib.check(lib.tef_l2_norm(self.bucket.flat.data_ptr(), n, self.scratch.data_ptr(), self.norm.data_ptr(),
                                         self.step_count.data_ptr(), st), "tef_l2_norm")
-        self._lib.check(lib.tef_adam_clip_step(self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.m.data_ptr(),
-                                               self.v.data_ptr(), n, self.norm.data_ptr(),
-                                               -1.0 if max_norm is None else float(max_norm), self.lr, self.betas[0],
-                                               self.betas[1], self.eps, self.step_count.data_ptr(), st), "tef_adam_clip_step")
+        self._lib.check(lib.tef_adam_clip_step_hp(self.flat_p.data_ptr(), self.bucket.flat.data_ptr(), self.m.data_ptr(),
+                                                  self.v.data_ptr(), n, self.norm.data_ptr(), self.hp.data_ptr(),
+                                                  self.step_count.data_ptr(), st), "tef_adam_clip_step_hp")
         return self.norm.view(())
 
 

@@ -72,6 +72,8 @@ class SyntheticSequences:
 
 
 _RETIRED_GRAPHS = []      # hipGraphs of closed CapturedWindows (see CapturedWindow.close)
+def retired_graph_count():
+    return len(_RETIRED_GRAPHS)
 
 
 def release_retired_graphs():
@@ -89,20 +91,29 @@ def release_retired_graphs():
 class CapturedWindow:
     """A loss window captured by Trainer.capture_window.  `inputs[t]` is pass t's batch dict of STATIC tensors: write
     the next window's data into them (`.copy_`), then `replay()`.  `new_seq` is the reference's reset flag for the
-    window's first pass (train_flow.py:83-87); a captured window is P passes long by construction, so sequences must
-    change at window boundaries (DSEC: 200 passes per sequence, P = 10)."""
+    window's first pass (train_flow.py:83-87); a captured window is P passes long by construction: for sequences that
+    change in the middle of a window feed the passes through a `WindowRunner`."""
 
-    def __init__(self, trainer, graph, graph_tail, inputs, states, graph_mid=None):
+    def __init__(self, trainer, graph, graph_tail, inputs, states, graph_mid=None, signature=None, loss_out=None):
         self.trainer, self.graph, self.graph_tail, self.inputs, self.states = trainer, graph, graph_tail, inputs, states
         self.graph_mid = graph_mid        # DP with overlap: the encoder half of the last weight-gradient reduction
+        self.signature, self.loss_out = signature, loss_out      # (what Trainer.capture_window parks a closed window under)
+        # buffers the graphs read and write that nothing else refers to (the per-pass working copies of the inputs, allocated
+        # BEFORE the capture, i.e. outside the graphs' private pool): they must live as long as the graphs can run — until
+        # round 5 they died with capture_window()'s frame and the next allocation of the caller landed in them
+        self.keep = None
         # a list: replay() appends (start, local work done, stop) events around each DP reduction — start -> stop is the
         # reduction as the main stream sees it, local work done -> stop the part of it nothing was left to hide
         self.allreduce_events = None
 
-    def replay(self, new_seq=False):
-        if parallel.any_rank(new_seq):       # host-side exchange, outside the graph; all ranks reset together
+    def replay(self, new_seq=False, exchange=True):
+        if (parallel.any_rank(new_seq) if exchange else new_seq):       # host-side exchange, outside the graph; all ranks reset together
             for s in self.states:            # loss containers and gradients are already clear at a window boundary
                 s.zero_()
+        if self.trainer.fused_opt is not None:
+            self.trainer.fused_opt.refresh_hyperparams()      # lr / betas / eps / clip as they are NOW (a schedule, a restored checkpoint)
+        if self.loss_out is not None:
+            self.trainer.last_loss = self.loss_out            # (the graph's own output tensor: eager windows in between re-point it)
         self.graph.replay()
         if self.graph_tail is not None:      # DP: the collectives run between the graphs, never captured
             ev = None
@@ -147,6 +158,20 @@ class CapturedWindow:
         live = torch.cuda.is_available() and torch.cuda.is_initialized()
         if live:
             torch.cuda.synchronize()
+        # A window closed while its trainer lives is PARKED there, graphs, pool and all: capture_window() for the same batch
+        # shapes hands it out again instead of capturing (a retired graph pins its private pool — a whole window's memory —
+        # for the life of the process; with this, what is retained is one window per distinct shape and trainer, and it is
+        # retired once, with the trainer).  Hyper-parameters are read from device memory at every replay, the inputs are
+        # static buffers the caller fills: a parked window is as good as a new capture.
+        tr = self.trainer
+        if (tr is not None and self.signature is not None and getattr(tr, "_parked", None) is not None
+                and self.signature not in tr._parked and os.environ.get("TEF_DESTROY_GRAPHS", "0") != "1"):
+            tr._parked[self.signature] = {"graph": self.graph, "graph_tail": self.graph_tail, "graph_mid": self.graph_mid,
+                                          "inputs": self.inputs, "states": self.states, "loss_out": self.loss_out,
+                                          "keep": self.keep}
+            self.graph = self.graph_tail = self.graph_mid = None
+            self.inputs = self.states = self.keep = None
+            return
         if os.environ.get("TEF_DESTROY_GRAPHS", "0") != "1":
             # default: the graphs are RETIRED, not destroyed — they (and their private memory pool) stay allocated until the
             # process ends or release_retired_graphs() is called.  The wait after destruction cuts the late writes from 6 %
@@ -155,16 +180,45 @@ class CapturedWindow:
         self.graph_tail = None
         self.graph_mid = None
         self.graph = None
-        self.inputs = self.states = None
+        self.inputs = self.states = self.keep = None
         if live:
             torch.cuda.synchronize()
 
     def __del__(self):
-        if not sys.is_finalizing():
-            try:
+        try:                       # (a destructor must not raise — not even at interpreter shutdown, when `sys` may be gone)
+            if not sys.is_finalizing():
                 self.close()
-            except Exception:      # noqa: BLE001  (a destructor must not raise)
-                pass
+        except Exception:          # noqa: BLE001
+            pass
+
+
+class WindowRunner:
+    """Pass-by-pass front end of a captured window with the reference's reset semantics (train_flow.py:83-87: `new_seq` in
+    ANY slot, at ANY pass, resets loss containers, recurrent states and gradients).  Passes are collected in the window's
+    static input buffers; P of them are one replay.  A reset at pass k of a window discards the k passes collected so far
+    — in the reference they were run and then thrown away by the reset: nothing of them survives but a log line — and the
+    window starts again at this pass, with the recurrent state cleared at the replay.  Under DP every rank exchanges its
+    flag at every pass (parallel.any_rank), exactly like Trainer.step."""
+
+    def __init__(self, window):
+        self.window, self.count, self.pending_reset = window, 0, False
+
+    def step(self, inputs, new_seq=False):
+        """-> True when this pass completed a window (an optimiser step happened)."""
+        if parallel.any_rank(new_seq):
+            self.count, self.pending_reset = 0, True
+        dst = self.window.inputs[self.count]
+        for k in dst:
+            dst[k].copy_(inputs[k], non_blocking=True)
+        self.count += 1
+        if self.count < len(self.window.inputs):
+            return False
+        reset, self.count, self.pending_reset = self.pending_reset, 0, False
+        if reset:      # (the flag has been exchanged already: clear the states here, replay without another exchange)
+            for s_ in self.window.states:
+                s_.zero_()
+        self.window.replay(new_seq=False, exchange=False)
+        return True
 
 
 class Trainer:
@@ -200,6 +254,7 @@ class Trainer:
             self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
         self.last_grad_norm = None
+        self._parked = {}       # closed captured windows by batch-shape signature (CapturedWindow.close)
         # DP: the gradient bucket is reduced in two pieces — [encoders | residual blocks, decoders, heads], the order of
         # model.parameters() — so that the second piece's all-reduce overlaps the encoders' last weight-gradient reduction
         # (TEF_DP_OVERLAP=0: one all-reduce of the whole bucket after everything)
@@ -234,6 +289,9 @@ class Trainer:
         Idempotent; also runs from __del__, so that a trainer dropped with work in flight (or collected late) never has
         its streams' buffers released under a running kernel."""
         eng = getattr(getattr(self.model, "arch", None), "_engine", None) if getattr(self, "model", None) is not None else None
+        parked, self._parked = getattr(self, "_parked", None) or {}, None
+        for rec in parked.values():       # parked windows die with their trainer: retired, like any closed window's graphs
+            _RETIRED_GRAPHS.extend(g_ for g_ in (rec["graph_tail"], rec["graph_mid"], rec["graph"]) if g_ is not None)
         if torch.cuda.is_available() and torch.cuda.is_initialized():
             for st in (self.dec_stream, self.wgrad_stream, self.comm_stream):
                 if st is not None:
@@ -245,11 +303,11 @@ class Trainer:
         self.dec_stream = self.wgrad_stream = None
 
     def __del__(self):
-        if not sys.is_finalizing():
-            try:
+        try:                       # (a destructor must not raise — not even at interpreter shutdown, when `sys` may be gone)
+            if not sys.is_finalizing():
                 self.close()
-            except Exception:      # noqa: BLE001
-                pass
+        except Exception:          # noqa: BLE001
+            pass
 
     def reset(self):
         """train_flow.py:83-87"""
@@ -273,6 +331,30 @@ class Trainer:
             raise ValueError("capture needs at least one eager window (allocations, recurrent state buffers)")
         if self.loss_function.num_passes != 0:
             raise RuntimeError("capture_window must start at a window boundary")
+        signature = (warmup >= 1, parallel.is_distributed(),
+                     tuple(tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(b.items())) for b in batches))
+        rec = self._parked.pop(signature, None) if self._parked is not None else None
+        if rec is not None:
+            # a window of these shapes was captured before and closed: take it out of the park.  The `warmup` windows run
+            # as replays (they are training steps either way); the recurrent state carries on from where the trainer is.
+            cw = CapturedWindow(self, rec["graph"], rec["graph_tail"], rec["inputs"], rec["states"], rec["graph_mid"],
+                                signature, rec["loss_out"])
+            cw.keep = rec["keep"]
+            for dst, src in zip(cw.inputs, batches):
+                for k in dst:
+                    dst[k].copy_(src[k])
+            cur = self.model.arch.states
+            for dst, src in zip(cw.states, cur):
+                if src is None:
+                    dst.zero_()
+                elif dst is not src:
+                    dst.copy_(src.detach())
+            self.model.arch.states = cw.states
+            self.warmup_losses = []
+            for _ in range(warmup):
+                cw.replay()
+                self.warmup_losses.append(float(self.last_loss.item()))
+            return cw
         inputs = [{k: v.clone() for k, v in b.items()} for b in batches]          # public static input buffers
         work = [{k: torch.empty_like(v) for k, v in b.items()} for b in batches]   # update() shifts timestamps in place
 
@@ -329,7 +411,9 @@ class Trainer:
             with torch.cuda.graph(graph_tail, pool=graph.pool()):
                 tail()
         self.model.arch.states = static_states
-        return CapturedWindow(self, graph, graph_tail, inputs, static_states, graph_mid)
+        cw = CapturedWindow(self, graph, graph_tail, inputs, static_states, graph_mid, signature, self.last_loss)
+        cw.keep = work
+        return cw
 
     def step(self, inputs, new_seq=False):
         """One pass (train_flow.py:83-137).  Returns True when an optimiser step happened."""

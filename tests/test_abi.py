@@ -73,3 +73,45 @@ def test_product_path_refuses_cpu_tensors(built):
     cfg["loss"]["iterative_mode"] = "four"
     with pytest.raises(NotImplementedError):
         Iterative(cfg, torch.device("cpu"))
+
+
+def _header_struct_fields(name):
+    """Field names (in order) and total int-sized element count of `struct name` in include/tef.h."""
+    text = open(os.path.join(ROOT, "include", "tef.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#define\s+(\w+)\s+(\d+)", lambda m: m.group(0), text)
+    defines = {k: int(v) for k, v in re.findall(r"#define\s+(TEF_\w+)\s+(\d+)", text)}
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+        for item in names.split(","):
+            item = item.strip().lstrip("*").strip()
+            m = re.match(r"(\w+)\s*(?:\[(.*?)\])?$", item)
+            count = 1
+            if m.group(2):
+                expr = m.group(2)
+                for k, v in defines.items():
+                    expr = expr.replace(k, str(v))
+                count = eval(expr)
+            fields.append((m.group(1), count))
+    return fields
+
+
+def test_integration_doc_structs_match_the_header(built):
+    """INTEGRATION.md section 2 shows a host binding to copy from: its ctypes structures must lay out like include/tef.h
+    (a missing trailing field hands the library a struct 4 bytes short)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes\nlib = ctypes\.CDLL.*?)```", doc, flags=re.S).group(1)
+    code = "\n".join(l for l in block.splitlines() if not l.startswith("lib"))      # (do not load a library here)
+    ns = {}
+    exec(code, ns)
+    for cname in ("tef_events", "tef_loss_cfg"):
+        hdr = _header_struct_fields(cname)
+        doc_fields = [(n, getattr(t, "_length_", 1)) for n, t in ns[cname]._fields_]
+        assert doc_fields == hdr, (cname, doc_fields, hdr)
+    assert ctypes.sizeof(ns["tef_loss_cfg"]) == ctypes.sizeof(built.LossCfg)
+    assert ctypes.sizeof(ns["tef_events"]) == ctypes.sizeof(built.Events) if hasattr(built, "Events") else True

@@ -10,7 +10,8 @@ v=$1; expr=$2; shift 2
 mkdir -p $PKG/build/variants/src
 sed -E "$expr" $PKG/csrc/$SRC.hip > $PKG/build/variants/src/$SRC.$v.hip
 if cmp -s $PKG/csrc/$SRC.hip $PKG/build/variants/src/$SRC.$v.hip; then echo "variant $v: the expression changed nothing" >&2; exit 1; fi
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 -munsafe-fp-atomics "$@" -I /root/repo/include -I $PKG/csrc -c $PKG/build/variants/src/$SRC.$v.hip -o $PKG/build/variants/$SRC.$v.o 2>/dev/null
+UNSAFE=$(python3 -c "import sys; sys.path.insert(0, '/root/repo'); from taming_event_flow_amd import build as b; print('-munsafe-fp-atomics' if '$SRC' in b.UNSAFE_FP_ATOMICS else '')")
+hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -std=c++17 $UNSAFE "$@" -I /root/repo/include -I $PKG/csrc -c $PKG/build/variants/src/$SRC.$v.hip -o $PKG/build/variants/$SRC.$v.o 2>/dev/null
 objs=""
 for f in tef_common tef_loss tef_smooth tef_encode tef_resize tef_val tef_collate tef_conv tef_cell tef_net tef_optim tef_prims; do
   if [ "$f" != "$SRC" ]; then objs="$objs $PKG/build/$f.hip.o"; fi
