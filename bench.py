@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--res", type=int, nargs=2, default=[128, 128])
     ap.add_argument("--flow", default="smooth", choices=["smooth", "iid"])
     ap.add_argument("--warping", default="Iterative", choices=["Iterative", "Linear"])
-    ap.add_argument("--mode", default="loss", choices=["loss", "train", "eval"],
+    ap.add_argument("--mode", default="loss", choices=["loss", "train", "eval", "dropin"],
                     help="loss: IWE + contrast-max loss fwd+bwd (BASELINE.json metric, configs[1]); "
                          "train: full training window, RecEVFlowNet + loss + DP all-reduce + Adam (configs[2]/[3])")
     ap.add_argument("--graph", action="store_true", help="train mode: replay the window from a captured hipGraph")
@@ -222,6 +222,15 @@ def main():
         return bench_train(a, torch, dist, dev, rank, world, lib)
     if a.mode == "eval":
         return bench_eval(a, torch, dist, dev, rank, world, lib)
+    if a.mode == "dropin":
+        out = dropin_extra(a, torch, dev, windows=max(3, min(a.steps, 20)))
+        if rank == 0:
+            print(json.dumps({"metric": "ms per training window, literal train_flow.py loop", "unit": "ms", "n_gpus": 1,
+                              "higher_is_better": False, "data": "synthetic", "value": out.get("dropin_window_ms"),
+                              "config": {"workload": "reference loop body (train_flow.py:83-137) on this package's modules, "
+                                                     f"{a.res[0]}x{a.res[1]} B={a.batch} P={a.passes} N={a.events}"},
+                              "extra": out}))
+        return 0
     H, W = a.res
     B, P, F = a.batch, a.passes, a.heads
     cfg = make_cfg(a)
@@ -605,6 +614,8 @@ def main():
             torch.cuda.synchronize()
             with torch.cuda.stream(torch.cuda.default_stream(dev)):      # (where a training loop runs; not the capture stream above)
                 out["extra"] = train_extra(a, torch, dev)
+                if "error" not in out["extra"]:
+                    out["extra"].update(dropin_extra(a, torch, dev))      # the literal train_flow.py loop, no Trainer
         elif dp_extra is not None:
             out["extra"] = dp_extra
         print(json.dumps(out), flush=True)
@@ -942,6 +953,72 @@ def train_extra(a, torch, dev):
                 "window_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                 "window_frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 "streams": tr_streams}
+    except Exception as e:                                    # noqa: BLE001
+        return {"error": repr(e)}
+
+
+def dropin_extra(a, torch, dev, windows=3):
+    """The number a reference user gets by changing three imports: the reference's loop body restated call for call
+    (train_flow.py:83-87, :101-137 — model(x), * flow_scaling, loss.update, loss(), .item(), backward, clip_grad_norm_,
+    torch.optim.Adam.step, zero_grad() with torch's set_to_none default, detach_states, reset) on this package's
+    RecEVFlowNet / Iterative, no train.Trainer.  ms per window (wall) and the host's share of it."""
+    import copy
+
+    try:
+        from taming_event_flow_amd import train
+        from taming_event_flow_amd.loss.flow import Iterative
+        from taming_event_flow_amd.models.model import RecEVFlowNet
+
+        cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+        cfg["loader"].update(batch_size=a.batch, resolution=list(a.res), max_num_grad_events=a.events)
+        cfg["data"]["passes_loss"] = a.passes
+        torch.manual_seed(1234)
+        model = RecEVFlowNet(cfg["model"].copy(), 2, key="flow").to(dev)
+        model.train()
+        loss_function = Iterative(cfg, dev)
+        optimizer = torch.optim.Adam(model.parameters(), lr=cfg["optimizer"]["lr"])
+        optimizer.zero_grad()
+        src = train.SyntheticSequences(cfg, dev, a.events + a.detached, seq_len=10 ** 9, seed=100)
+        batches = [src.next() for _ in range(a.passes)]
+        state = {"loss": 0.0}
+
+        def window():
+            for inputs in batches:
+                inputs = {k: v.clone() for k, v in inputs.items()}          # (update() shifts the timestamps in place)
+                x = model(inputs["net_input"].to(dev))
+                for i in range(len(x["flow"])):
+                    x["flow"][i] = x["flow"][i] * cfg["loss"]["flow_scaling"]
+                loss_function.update(x["flow"], inputs["event_list"].to(dev), inputs["event_list_pol_mask"].to(dev),
+                                     inputs["d_event_list"].to(dev), inputs["d_event_list_pol_mask"].to(dev))
+                if loss_function.num_passes >= cfg["data"]["passes_loss"]:
+                    loss = loss_function()
+                    state["loss"] += loss.item()
+                    loss.backward()
+                    if cfg["loss"]["clip_grad"] is not None:
+                        torch.nn.utils.clip_grad.clip_grad_norm_(model.parameters(), cfg["loss"]["clip_grad"])
+                    optimizer.step()
+                    optimizer.zero_grad()
+                    model.detach_states()
+                    loss_function.reset()
+
+        loss_function.reset()
+        model.reset_states()
+        window()
+        window()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(windows):
+            window()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / windows
+        arch = model.arch
+        out = {"dropin_workload": "literal train_flow.py loop body (torch.optim.Adam, clip_grad_norm_, zero_grad(set_to_none)), "
+                                  "no train.Trainer", "dropin_window_ms": round(ms, 3), "dropin_windows_timed": windows,
+               "dropin_in_place_grads": bool(arch._bucket is not None and arch.direct_grads),
+               "dropin_deferred_wgrad": bool(arch.deferred_wgrad), "loss_finite": bool(np.isfinite(state["loss"]))}
+        del model, loss_function, optimizer, src, batches
+        release_now(torch)
+        return out
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
 

@@ -13,6 +13,7 @@ The module tree keeps the reference's attribute names (``encoders[i].conv.conv2d
 the ``state_dict`` keys checkpoints are exchanged by (reference utils/utils.py:20-31).
 """
 
+import os
 from collections import namedtuple
 
 import torch.nn as nn
@@ -94,6 +95,14 @@ class MultiResUNetRecurrent(nn.Module):
                                              bias=plan.final_bias) for r in plan.of("pred"))
         self.states = [None] * self.num_states
         self._engine = None
+        # The literal drop-in loop (reference train_flow.py:60-70, :120-131: torch.optim.Adam, clip_grad_norm_,
+        # optimizer.zero_grad() with torch's set_to_none default) never sees train.Trainer.  The network then owns its
+        # gradient accumulators itself: ONE flat buffer with a view per parameter as .grad (re-attached and cleared when the
+        # optimiser has set them to None), which is what the fused pass needs to add parameter gradients in place, to keep
+        # the two halves of a pass apart and to defer the weight gradients of a window to one reduction per layer (flushed
+        # by a callback at the end of backward()).  train.Trainer switches this off and brings its own bucket.
+        self.auto_grads = True
+        self._bucket = None
         # extra factor on the full-resolution flows of the fused pass: a training loop that multiplies the network's
         # output by loss.flow_scaling (reference train_flow.py:107-108) can have the pass do it in its last kernel
         self.flow_scale = 1.0
@@ -113,9 +122,56 @@ class MultiResUNetRecurrent(nn.Module):
             self._engine = PassEngine(self)
         return self._engine
 
+    def own_gradients(self):
+        """-> True when every trainable parameter's .grad is a view of this module's flat buffer (see __init__)."""
+        if not self.auto_grads:
+            return False
+        params = [p for p in self.parameters() if p.requires_grad]
+        if not params or not params[0].is_cuda:
+            return False
+        b = self._bucket
+        if b is None or len(b.params) != len(params) or any(x is not y for x, y in zip(b.params, params)) or \
+                b.flat.device != params[0].device:
+            try:
+                from ..parallel import FlatGradBucket
+                from . import submodules as sm
+            except ImportError:                 # drop-in mode: this directory is the top-level package `models`
+                from parallel import FlatGradBucket
+                import models.submodules as sm
+            old = [p.grad for p in params]
+            self._bucket = b = FlatGradBucket(params)
+            for p, g in zip(params, old):       # (gradients accumulated before the first pass through here)
+                if g is not None:
+                    p.grad.copy_(g)
+            sm.enable_direct_grads(self)
+            sm.enable_deferred_wgrad(self, os.environ.get("TEF_NO_DEFERRED_WGRAD", "0") != "1")
+            sm.AUTO_FLUSH = True
+            # the deferred weight gradients of every few finished backward passes are reduced on a stream of their own
+            # beside the rest of BPTT (as under train.Trainer); the callback at the end of backward() joins it
+            group = int(os.environ.get("TEF_WGRAD_GROUP", "3"))
+            eng = self.engine
+            if self.deferred_wgrad and group > 0 and os.environ.get("TEF_TWO_STREAMS", "1") != "0" and eng.wgrad_stream is None:
+                import torch
+
+                eng.wgrad_stream, eng.wgrad_group = torch.cuda.Stream(device=params[0].device), group
+            return True
+        o, fresh = 0, False
+        for p in params:
+            g = p.grad
+            if g is None or g.data_ptr() != b.flat.data_ptr() + 4 * o or not g.is_contiguous():
+                if not fresh:                   # optimizer.zero_grad(set_to_none=True): the next backward starts from zero
+                    b.flat.zero_()
+                    fresh = True
+                if g is not None:
+                    b.flat[o:o + p.numel()].view_as(p).add_(g)
+                p.grad = b.flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        return True
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engine"] = None                 # workspaces are not part of a checkpoint
+        state["_bucket"] = None
         state["states"] = [None] * self.num_states
         return state
 

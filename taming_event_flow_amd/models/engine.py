@@ -340,6 +340,10 @@ class PassEngine:
         if direct and a.deferred_wgrad and not rec.queued:
             if self._pending and (self._pending[0].plan.B, self._pending[0].plan.H, self._pending[0].plan.W) != (pl.B, pl.H, pl.W):
                 self.flush_window()
+            if not self._pending and a.auto_grads:
+                # nobody calls flush_window for the drop-in loop: at the end of this backward() (autograd runs the queued
+                # callbacks when every node is done)
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
             self._pending.append(rec)       # (keeps the arenas alive until the flush)
             rec.queued = True
             sm._DEFERRED_ENGINES.add(self)
@@ -351,6 +355,13 @@ class PassEngine:
                 self.flush_window(self.wgrad_stream)
         grads = [None] * len(params) if direct else [fresh.get(id(p)) for p in params]
         return dh, dx, grads
+
+    def _end_of_backward(self):
+        """arch.auto_grads: what train.Trainer does after loss.backward() — the window's remaining weight gradients, then wait
+        for the reductions that ran beside BPTT on the weight-gradient stream."""
+        sm.flush_deferred_wgrads()
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
     def flush_window(self, stream=None, parts=(3,), between=None, keep=False):
         """The deferred weight gradients of every backward call since the last flush: one reduction per layer over all
@@ -470,6 +481,8 @@ def run_pass(engine, x, states):
     needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params) or
                                          any(s is not None and s.requires_grad for s in states))
     side = engine.side_stream
+    if needs:
+        engine.arch.own_gradients()          # (the drop-in loop: .grad views of the network's own flat buffer, see arch.py)
     if not needs:
         if side is None or not engine.defer_join:       # (without gradients the split only pays when the caller overlaps)
             flows, new_states, _ = engine.forward(x, list(states), keep=False)

@@ -232,6 +232,9 @@ class Trainer:
         self.model = model.to(device)
         self.model.train()
         self.loss_function = loss_function if loss_function is not None else eval(config["loss"]["warping"])(config, device)
+        arch_own = getattr(self.model, "arch", None)
+        if arch_own is not None and hasattr(arch_own, "auto_grads"):
+            arch_own.auto_grads = False                 # (the trainer's bucket, its flushes, its streams)
         self.bucket = parallel.FlatGradBucket(self.model.parameters())
         submodules.enable_direct_grads(self.model)      # conv kernels add into the bucket's .grad views
         # weight gradients of a window's passes: one long reduction per layer after backward (opt out: TEF_NO_DEFERRED_WGRAD=1)

@@ -224,3 +224,78 @@ def test_reference_format_state_dict_loads_through_load_model(dev, tmp_path):
         ref = z[f"flow0_{i}"]
         err = np.abs(fl.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
         assert err <= 1e-4, (i, err)
+
+
+def _dropin_window(model, loss_function, optimizer, cfg, batches, new_seq=False):
+    """The reference's loop body, call for call (train_flow.py:83-87, :101-137), on this package's modules."""
+    device = next(model.parameters()).device
+    loss = gnorm = None
+    for t, inputs in enumerate(batches):
+        if new_seq and t == 0:
+            loss_function.reset()
+            model.reset_states()
+            optimizer.zero_grad()
+        x = model(inputs["net_input"].to(device))
+        for i in range(len(x["flow"])):
+            x["flow"][i] = x["flow"][i] * cfg["loss"]["flow_scaling"]
+        loss_function.update(x["flow"], inputs["event_list"].to(device), inputs["event_list_pol_mask"].to(device),
+                             inputs["d_event_list"].to(device), inputs["d_event_list_pol_mask"].to(device))
+        if loss_function.num_passes >= cfg["data"]["passes_loss"]:
+            loss = loss_function()
+            loss_value = loss.item()
+            loss.backward()
+            if cfg["loss"]["clip_grad"] is not None:
+                gnorm = torch.nn.utils.clip_grad.clip_grad_norm_(model.parameters(), cfg["loss"]["clip_grad"])
+            optimizer.step()
+            optimizer.zero_grad()
+            model.detach_states()
+            loss_function.reset()
+    return loss_value, (None if gnorm is None else float(gnorm))
+
+
+@pytest.mark.parametrize("trace", ["train_trace_lr1e-5"])
+def test_literal_dropin_loop_reproduces_the_reference_trace(dev, trace):
+    """No train.Trainer: torch.optim.Adam, clip_grad_norm_ and optimizer.zero_grad() (torch's set_to_none default) around this
+    package's RecEVFlowNet and Iterative, exactly as train_flow.py wires them — against the reference's recorded two-window
+    trace (loss, pre-clip gradient norm, per-parameter update norms).  The network keeps its own flat gradient buffer
+    (arch.own_gradients) so this caller gets in-place parameter gradients and deferred weight gradients as well."""
+    from taming_event_flow_amd import synth
+    from taming_event_flow_amd.dataloader import encodings
+    from taming_event_flow_amd.loss.flow import Iterative
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    z = np.load(os.path.join(GOLDEN, trace + ".npz"))
+    H, W, B, P = int(z["H"]), int(z["W"]), int(z["B"]), int(z["P"])
+    cfg = {
+        "data": {"passes_loss": P, "scales_loss": 1, "voxel": None},
+        "model": {"name": "RecEVFlowNet", "final_w_scale": 0.01},
+        "loss": {"warping": "Iterative", "iterative_mode": "two", "round_ts": False, "flow_scaling": 32,
+                 "flow_spat_smooth_weight": None, "flow_temp_smooth_weight": None, "clip_grad": float(z["clip"])},
+        "optimizer": {"name": "Adam", "lr": float(z["lr"])},
+        "loader": {"batch_size": B, "resolution": [H, W], "max_num_grad_events": None, "seed": 0},
+    }
+    model = RecEVFlowNet(cfg["model"].copy(), 2, key="flow").to(dev)
+    w = synth.make_model_weights([(k, v.shape) for k, v in model.state_dict().items()], int(z["seed"]))
+    model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    model.train()
+    loss_function = Iterative(cfg, dev)
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg["optimizer"]["lr"])
+    optimizer.zero_grad()
+    for win in range(int(z["windows"])):
+        before = [p.detach().clone() for p in model.parameters()]
+        batches = []
+        for t in range(P):
+            ev, pm = torch.tensor(z[f"ev{win}_{t}"], device=dev), torch.tensor(z[f"pm{win}_{t}"], device=dev)
+            dv, dpm = torch.tensor(z[f"dev{win}_{t}"], device=dev), torch.tensor(z[f"dpm{win}_{t}"], device=dev)
+            batches.append({"net_input": encodings.event_list_to_channels(torch.cat([ev, dv], 1), (H, W)), "event_list": ev,
+                            "event_list_pol_mask": pm, "d_event_list": dv, "d_event_list_pol_mask": dpm})
+        loss, gn = _dropin_window(model, loss_function, optimizer, cfg, batches, new_seq=(win == 0))
+        assert all(p.grad is None for p in model.parameters())       # (torch's zero_grad default: what the next window starts from)
+        delta = np.array([float((p.detach() - b0).double().norm()) for p, b0 in zip(model.parameters(), before)])
+        tol, gtol = (1e-4, 5e-4) if win == 0 else (1e-3, 1e-3)
+        assert abs(loss - float(z[f"loss{win}"])) <= tol * abs(float(z[f"loss{win}"])), (win, loss)
+        assert abs(gn - float(z[f"gnorm{win}"])) <= gtol * float(z[f"gnorm{win}"]), (win, gn)
+        ref = z[f"delta{win}"]
+        assert np.abs(delta - ref).max() <= 5e-2 * ref.max(), win
+    # the caller's set_to_none really is honoured between windows, and the pass stayed on its fast path
+    assert model.arch._bucket is not None and model.arch.direct_grads and model.arch.deferred_wgrad
