@@ -195,7 +195,9 @@ def watchdog():
     boundaries of a run (rendezvous, staging, warm-up, timed region, extras)."""
     import faulthandler
 
-    faulthandler.dump_traceback_later(float(os.environ.get("TEF_BENCH_WATCHDOG_S", "600")), exit=True)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    default = "600" if world == 1 else "180"            # N > 1: a wedged collective costs a metered 8-GPU lease
+    faulthandler.dump_traceback_later(float(os.environ.get("TEF_BENCH_WATCHDOG_S", default)), exit=True)
 
 
 def main():
@@ -521,10 +523,34 @@ def main():
     loss_val = float(last.item())
     assert all(torch.isfinite(g_).all().item() for g_ in last_grads[:4])
 
+    rank_ms, single_ms = None, None
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [round(1e3 * float(t_.item()) / a.steps, 4) for t_ in every]      # each rank's own clock around the K steps
+        elapsed = max(float(t_.item()) for t_ in every)
+        # the same steps on rank 0 ALONE (every other rank waits at the barrier): the N = 1 figure of THIS run, on this box,
+        # for the weak-scaling efficiency of the batch-sharded path (no data-path collective: anything below 1 is contention
+        # for the host, the fabric or the clocks)
+        watchdog()
+        dist.barrier()
+        if rank == 0:
+            n1 = max(10, min(a.steps, 100))
+            if groups:
+                run, per = (lambda k_: groups[k_ % len(groups)][0].replay()), G
+            elif graphs:
+                run, per = (lambda k_: graphs[k_ % len(graphs)][0].replay()), 1
+            else:
+                run, per = step, 1
+            run(0)
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for k_ in range(n1):
+                run(k_)
+            torch.cuda.synchronize()
+            single_ms = 1e3 * (time.perf_counter() - t0_) / (n1 * per)
+        dist.barrier()
 
     events_per_step = B * P * (a.events + a.detached)
     total_events = events_per_step * a.steps * world
@@ -559,6 +585,12 @@ def main():
             "value": round(value, 1), "unit": "events/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * elapsed / a.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # N > 1: every rank's own ms per step (the headline takes the slowest), and rank 0 running the same steps alone
+            "ms_per_step_per_rank": rank_ms,
+            "ms_per_step_min": min(rank_ms) if rank_ms else None, "ms_per_step_max": max(rank_ms) if rank_ms else None,
+            "ms_per_step_rank0_alone": round(single_ms, 4) if single_ms else None,
+            "weak_scaling_efficiency_vs_rank0_alone": (round(single_ms / (1e3 * elapsed / a.steps), 4) if single_ms else None),
+            "backend": (dist.get_backend() if dist else None), "rccl_world_size": (dist.get_world_size() if dist else 1),
             "config": {"workload": f"{a.warping}/two loss fwd+bwd, {H}x{W}, B={B}/GPU, P={P}, F={F}, "
                                    f"N={a.events}+{a.detached} events/pass/sample, {a.flow} flows sigma=2px "
                                    "(BASELINE.json configs[1])",
@@ -1023,7 +1055,7 @@ def dropin_extra(a, torch, dev, windows=3):
         return {"error": repr(e)}
 
 
-def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
+def dp_train_extra(a, torch, dist, dev, rank, world, windows=3):
     """world > 1: the data-parallel TRAINING window (BASELINE configs[3] at this batch size; reference train_flow.py:83-87,
     :120-137 applied to the global batch) — two hipGraphs around the eager gradient all-reduce (train.CapturedWindow) — so
     that the driver's `bench.py --gpus N` line carries the number DP scaling is about.  Called by EVERY rank at the same
@@ -1043,6 +1075,7 @@ def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
     out["rank_checksum"] = float(chk.item())
     out["rank_checksum_expected"] = world * (world + 1) / 2
     failed, err, window, tr = False, None, None, None
+    watchdog()                                           # a phase of its own: capture
     try:
         cfg = copy.deepcopy(train.DEFAULT_CONFIG)
         cfg["loader"].update(batch_size=a.batch, resolution=list(a.res), max_num_grad_events=a.events)
@@ -1058,6 +1091,7 @@ def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
     if parallel.any_rank(failed):                        # (host-side exchange: every rank reaches it)
         out["error"] = err or "window capture failed on another rank"
         return out
+    watchdog()                                           # ... and the timed windows
     try:
         window()
         torch.cuda.synchronize()
@@ -1098,6 +1132,8 @@ def dp_train_extra(a, torch, dist, dev, rank, world, windows=5):
             "dp_train_window_ms": round(ms, 3), "dp_train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": windows,
             "allreduce_ms": round(ar_ms, 3), "allreduce_exposed_ms": round(ex_ms, 3), "allreduce_bytes": nbytes,
             "allreduce_overlap": window.graph_mid is not None,
+            # gloo reduces device tensors through the host and blocks it: the "exposed" time then says nothing about overlap
+            "allreduce_overlap_measured": dist.get_backend() == "nccl",
             # bus bandwidth of a ring all-reduce: every rank sends and receives 2 (N - 1) / N of the buffer
             "allreduce_GBps": round(nbytes * 2.0 * (world - 1) / world / (ar_ms * 1e-3) / 1e9, 2),
             "replicas_bit_identical": bool(lo.item() == hi.item()),

@@ -64,6 +64,7 @@ def needs_build():
 
 
 def build_hip(force=False, verbose=False):
+    force = force or os.environ.get("TEF_FORCE_BUILD", "0") == "1"      # (one full compile on the box: `TEF_FORCE_BUILD=1 python -c "import __graft_entry__ as g; g.build()"`)
     if not force and not needs_build():
         return LIB
     import hashlib

@@ -44,6 +44,12 @@ def test_loss_mode_two_ranks():
     assert x["allreduce_overlap"] is True and 0 <= x["allreduce_exposed_ms"] <= x["allreduce_ms"]
     print("DP window on two ranks sharing one GPU (gloo):", {k: x[k] for k in ("dp_train_window_ms", "allreduce_ms", "allreduce_exposed_ms")})
     assert 0 < x["new_seq_exchange_ms_per_pass"] < 50
+    assert x["allreduce_overlap_measured"] is False and x["windows_timed"] == 3       # (gloo: the exposed time is no overlap measurement)
+    # every rank's own clock, and rank 0 running the same steps alone (the N = 1 figure of this very run)
+    assert len(d["ms_per_step_per_rank"]) == 2 and d["ms_per_step_max"] == max(d["ms_per_step_per_rank"])
+    assert abs(d["ms_per_step_max"] - d["ms_per_step"]) <= 1e-3 and d["ms_per_step_min"] <= d["ms_per_step_max"]
+    assert d["ms_per_step_rank0_alone"] > 0 and 0 < d["weak_scaling_efficiency_vs_rank0_alone"] <= 1.5
+    assert d["rccl_world_size"] == 2 and d["backend"] == "gloo"
 
 
 def test_train_mode_two_ranks_graph():

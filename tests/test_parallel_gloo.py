@@ -96,3 +96,65 @@ def test_bucket_views_and_zero():
     bucket.zero()
     assert all(float(p.grad.abs().sum()) == 0.0 for p in model.parameters())
     assert parallel.shard_range(64, 3, 8) == (24, 32)
+
+
+def _worker4(rank, world, port, q):
+    """The DP window's reduction order at four ranks: the later slice of the bucket first (its all-reduce runs beside the
+    encoders' last weight-gradient reduction), then the earlier slice; clip and the update see the SAME numbers on every
+    rank, and the sum of the shards is the gradient of the global batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from taming_event_flow_amd import parallel
+
+    torch.manual_seed(123)
+    xg = torch.randn(8, 6)
+    lo, hi = parallel.shard_range(8, rank, world)
+    model = _model()
+    bucket = parallel.FlatGradBucket(model.parameters())
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    out = []
+    for step in range(3):                      # three windows: the replicas must stay identical through the updates
+        bucket.zero()
+        _loss(model, xg[lo:hi] + 0.1 * step).backward()
+        split = bucket.offset_of(list(model.parameters())[2])
+        w1 = dist.all_reduce(bucket.flat[split:], op=dist.ReduceOp.SUM, async_op=True)      # "communication stream"
+        # ... the encoder half's last local work would run here ...
+        w1.wait()
+        bucket.all_reduce_range(0, split)
+        bucket.clip_(0.5)
+        opt.step()
+        out.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone().numpy())
+    flag = parallel.any_rank(rank == 3)
+    q.put((rank, out, flag))
+    dist.destroy_process_group()
+
+
+def test_two_range_reduction_keeps_four_replicas_identical():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process run of the same three steps on the full batch
+    torch.manual_seed(123)
+    xg = torch.randn(8, 6)
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    ref = []
+    for step in range(3):
+        opt.zero_grad()
+        _loss(model, xg + 0.1 * step).backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.5)
+        opt.step()
+        ref.append(torch.cat([p.detach().reshape(-1) for p in model.parameters()]).numpy())
+    for rank, out, flag in res:
+        assert flag is True
+        for step in range(3):
+            assert np.array_equal(out[step], res[0][1][step]), (rank, step)          # replicas: bit for bit
+            np.testing.assert_allclose(out[step], ref[step], rtol=2e-5, atol=1e-6)    # = the global-batch run
