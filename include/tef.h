@@ -136,7 +136,9 @@ int tef_loss_forward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_e
 
 /* d loss / d flows as PLANAR [P][F][B][2][H][W] (channel 0 = x, 1 = y: the layout of the model's tensors);
  * grad_out = upstream scalar gradient (device pointer).
- * Must follow tef_loss_forward on the same workspace.  dflows is fully overwritten. */
+ * Must follow tef_loss_forward on the same workspace.  dflows is fully overwritten.  A call that returned an error leaves
+ * the workspace's work lists half-consumed: run tef_loss_forward again before retrying (a second backward on an intact
+ * workspace is fine). */
 int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_events *grad, const tef_events *det,
                       void *workspace, size_t workspace_bytes, const float *grad_out, float *dflows, void *stream);
 

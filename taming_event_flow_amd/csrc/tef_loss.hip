@@ -2683,7 +2683,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
                              stats, grad_out, cyx, wmax, chunks, defer_count, defer, cmax);
             if (int rc = tef::check_launch("chain_bwd_kernel")) return rc;
             const int R = std::max(1, std::min(8, num_cus() / std::max(1, FB)));
-            TEF_LAUNCH_TIMED(tef::PROF_STATS, chain_bwd_finish_kernel, dim3((unsigned)(FB * R)), dim3(256), 0, st, w, fl, g, traj,
+            TEF_LAUNCH_TIMED(tef::PROF_CHAIN_BWD_REST, chain_bwd_finish_kernel, dim3((unsigned)(FB * R)), dim3(256), 0, st, w, fl, g, traj,
                              meta, ar, stats, grad_out, cyx, wmax, defer_count, defer, cmax, R, (int *)(ws + L.queue) + 8);
             finished = true;
         } else if (w.kind == TEF_KIND_ITERATIVE)

@@ -500,13 +500,22 @@ class Trainer:
                 tail_done()
             return
 
+        def layer_path_first():
+            # Weight gradients queued by layer-by-layer modules (not the fused pass: normally none) may belong to parameters of
+            # the decoder slice: they go in BEFORE that slice's all-reduce starts — added behind it they would be lost to the
+            # other replicas without an error.
+            for pk in list(submodules._DEFERRED):
+                submodules.flush_deferred_wgrads(pk)
+
         if stage == 0:         # eager
             def between():
                 tail_done()
                 self._allreduce_tail_begin()
+            layer_path_first()
             eng.flush_window(parts=(2, 1), between=between)
-            submodules.flush_deferred_wgrads()      # (layer-by-layer modules, other engines: normally nothing)
+            submodules.flush_deferred_wgrads()      # (other engines: normally nothing)
         elif stage == 1:       # captured: decoder half, the backward calls stay queued
+            layer_path_first()
             eng.flush_window(parts=(2,), keep=True)
             tail_done()
         else:                  # captured: encoder half

@@ -102,7 +102,8 @@ def test_configs2_full_size():
 
 def test_full_size_window_against_reference():
     """BASELINE configs[2] against the REFERENCE itself at its real size (tests/golden/make_golden_train128.py: RecEVFlowNet +
-    Iterative loss + BPTT on CPU PyTorch, B = 8, 128x128, P = 10 passes of 10 000 events, flow_scaling 2; events and weights
+    Iterative loss + BPTT on CPU PyTorch, B = 8, 128x128, P = 10 passes of 10 000 events, flow_scaling 2 (see the generator for why not
+    32; a recorded `pred_scale` would be applied to the prediction heads' seeded weights); events and weights
     regenerated from the seed, SHA-256 checked).  The loss is held to 1e-4.  The parameter gradients cannot be: at 800 000
     events x 4 heads, flows that differ by 1e-6 px move some events across a floor() / in-bounds decision and each flip
     changes the gradient locally by O(1) — the reference's own float32 and float64 runs differ by 3e-3 ... 8e-3 per parameter
@@ -139,7 +140,8 @@ def test_full_size_window_against_reference():
     tr = train.Trainer(cfg, dev)
     sd = tr.model.state_dict()
     w = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], int(z["seed"]))
-    tr.model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    ps = np.float32(z["pred_scale"]) if "pred_scale" in z.files else np.float32(1.0)      # (the prediction heads' weights: see the generator)
+    tr.model.load_state_dict({k: torch.tensor(v * ps if k.startswith("arch.preds.") else v) for k, v in w.items()})
     tr.reset()
     for t, (ev, pm, dv, dpm) in enumerate(passes):
         ev_, pm_, dv_, dpm_ = (torch.tensor(a_, device=dev) for a_ in (ev, pm, dv, dpm))
