@@ -2164,7 +2164,7 @@ __global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Event
 // polarity-uniform (a splat workgroup skips the other polarity a wavefront at a time).
 // Order inside a (class, tile, row) bucket follows LDS-atomic arrival.
 constexpr int kPackThreads = 1024;
-constexpr int kPackBatch = 4;           // events per thread in flight
+constexpr int kPackBatch = 10;          // events per thread in flight
 constexpr int kPackSlices = 8;          // workgroups per sample
 constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x tiles x rows)
 
@@ -2191,71 +2191,78 @@ __device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, in
 // needs another's result: one launch, no scratch memory, and the scattered stores — about one cache-line access per
 // stored word, which is what paces this kernel: 42 us per pass with one workgroup per sample — are spread over eight
 // compute units per sample.
-__global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__restrict__ ev,
-                                                                  const float *__restrict__ pm, int N, float ts_shift,
-                                                                  const float *__restrict__ ts_override, int pass_idx,
-                                                                  int slot0, int cap,
-                                                                  int H, int W, SortGeom geo, float *__restrict__ ts,
-                                                                  float *__restrict__ y, float *__restrict__ x,
-                                                                  float *__restrict__ mp, float *__restrict__ mn,
-                                                                  uint8_t *__restrict__ bin, int *__restrict__ cls)
+// Round 5: the counting sweep reads whole events (ONE 16-byte load each instead of two strided 4-byte ones) with all of a
+// thread's loads in flight at once (kPackBatch = 10 covers the reference's 10 000 events per pass in one round trip instead
+// of three), and the scan of the bin counters is two DPP wave scans around one barrier instead of a 10-step ladder with 20.
+struct PackArgs {
+    float *ev;
+    const float *pm;
+    int N;
+    float ts_shift;
+    const float *ts_override;
+    int pass_idx, slot0, cap, H, W;
+    SortGeom geo;
+    float *ts, *y, *x, *mp, *mn;
+    uint8_t *bin;
+    int *cls;
+};
+
+__device__ __forceinline__ void pack_events_block(const PackArgs &a, int b, int slice, int nslices, int *cnt)
 {
-    extern __shared__ int cnt[];          // [nbins] all events, [nbins] events of earlier slices, [kPackThreads] scan scratch
+    // cnt: [nbins] all events, [nbins] events of earlier slices, [kPackThreads] scan scratch
+    const SortGeom &geo = a.geo;
+    const int N = a.N, H = a.H, W = a.W;
     const int ntiles = geo.ntx * geo.nty * geo.sub, nbins = 4 * ntiles;       // (bins per event class)
     int *before = cnt + nbins, *part = before + nbins;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int per_slice = (N + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int e_lo = min((int)blockIdx.y * per_slice, N), e_hi = min(e_lo + per_slice, N);
-    const float *evf = ev + (size_t)b * N * 4;
-    const float2 *pmb = reinterpret_cast<const float2 *>(pm) + (size_t)b * N;
+    const int tid = threadIdx.x;
+    const int per_slice = (N + nslices - 1) / nslices;
+    const int e_lo = min(slice * per_slice, N), e_hi = min(e_lo + per_slice, N);
+    const float *evf = a.ev + (size_t)b * N * 4;
+    const float4 *evb = reinterpret_cast<const float4 *>(evf);
+    const float2 *pmb = reinterpret_cast<const float2 *>(a.pm) + (size_t)b * N;
     for (int k = tid; k < 2 * nbins; k += kPackThreads) cnt[k] = 0;
     __syncthreads();
-    // (the sweeps take kPackBatch events per thread at a time, all loads issued before the first use; this one reads the
-    // coordinates only: the time stamps are being shifted in place by the slices' owners)
+    // (the time stamps are being shifted in place by the slices' owners while every workgroup reads the list: the counting
+    // sweep looks at the coordinates only)
     for (int e0 = tid; e0 < N; e0 += kPackThreads * kPackBatch) {
-        float vy[kPackBatch], vx[kPackBatch];
+        float4 v[kPackBatch];
         float2 m[kPackBatch];
 #pragma unroll
         for (int j = 0; j < kPackBatch; ++j) {
             const int e = min(e0 + j * kPackThreads, N - 1);
-            vy[j] = evf[(size_t)e * 4 + 1];
-            vx[j] = evf[(size_t)e * 4 + 2];
+            v[j] = evb[e];
             m[j] = pmb[e];
         }
 #pragma unroll
         for (int j = 0; j < kPackBatch; ++j) {
             const int e = e0 + j * kPackThreads;
             if (e >= N) break;
-            const int key = sort_key(vy[j], vx[j], m[j].x, m[j].y, H, W, geo);
+            const int key = sort_key(v[j].y, v[j].z, m[j].x, m[j].y, H, W, geo);
             atomicAdd(&cnt[key], 1);
             if (e < e_lo) atomicAdd(&before[key], 1);
         }
     }
     __syncthreads();
-    // exclusive scan of the counters: per-thread run of consecutive bins + scan of the run totals
+    // exclusive scan of the counters: per-thread run of consecutive bins, the runs' totals scanned per wavefront (DPP),
+    // the wavefronts' totals by every thread for itself
     const int per = (nbins + kPackThreads - 1) / kPackThreads;
     int lo = min(tid * per, nbins), hi = min(lo + per, nbins), run = 0;
     for (int k = lo; k < hi; ++k) run += cnt[k];
-    part[tid] = run;
+    const int incl = wave_prefix_sum(run);
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
     __syncthreads();
-    for (int s = 1; s < kPackThreads; s <<= 1) {
-        int v = (tid >= s) ? part[tid - s] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    int base = part[tid] - run;
+    int base = incl - run;
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += part[wv];
     for (int k = lo; k < hi; ++k) {
         int c = cnt[k];
         cnt[k] = base + before[k];          // first slot of this slice's share of the bin
         base += c;
-        if (blockIdx.y == 0 && k + 1 < nbins && (k + 1) % ntiles == 0)
-            cls[((size_t)b * TEF_MAX_PASSES + pass_idx) * 3 + (k + 1) / ntiles - 1] = base;   // run ends of the three
-    }                                                                                        // event classes
+        if (slice == 0 && k + 1 < nbins && (k + 1) % ntiles == 0)
+            a.cls[((size_t)b * TEF_MAX_PASSES + a.pass_idx) * 3 + (k + 1) / ntiles - 1] = base;   // run ends of the three
+    }                                                                                            // event classes
     __syncthreads();
-    const bool ts_fixed = ts_override != nullptr;
-    const float ts_value = ts_fixed ? ts_override[0] : 0.0f;
-    const float4 *evb = reinterpret_cast<const float4 *>(evf);
+    const bool ts_fixed = a.ts_override != nullptr;
+    const float ts_value = ts_fixed ? a.ts_override[0] : 0.0f;
     for (int e0 = e_lo + tid; e0 < e_hi; e0 += kPackThreads * kPackBatch) {
         float4 v[kPackBatch];
         float2 m[kPackBatch];
@@ -2269,25 +2276,31 @@ __global__ __launch_bounds__(kPackThreads) void pack_events_kernel(float *__rest
         for (int j = 0; j < kPackBatch; ++j) {
             const int e = e0 + j * kPackThreads;
             if (e >= e_hi) break;
-            const float t = v[j].x + ts_shift;
-            ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
+            const float t = v[j].x + a.ts_shift;
+            a.ev[((size_t)b * N + e) * 4] = t;                    // in-place shift of the caller's list (:457-458)
             const int pos = atomicAdd(&cnt[sort_key(v[j].y, v[j].z, m[j].x, m[j].y, H, W, geo)], 1);
-            const size_t o = (size_t)b * cap + slot0 + pos;
-            ts[o] = ts_fixed ? ts_value : t;
-            y[o] = v[j].y;
-            x[o] = v[j].z;
-            mp[o] = m[j].x;
-            mn[o] = m[j].y;
-            if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
+            const size_t o = (size_t)b * a.cap + a.slot0 + pos;
+            a.ts[o] = ts_fixed ? ts_value : t;
+            a.y[o] = v[j].y;
+            a.x[o] = v[j].z;
+            a.mp[o] = m[j].x;
+            a.mn[o] = m[j].y;
+            if (b == 0) a.bin[a.slot0 + e] = (uint8_t)a.pass_idx;
         }
     }
     // alignment slots up to the next multiple of 64 (a wavefront of the chain kernels belongs to one pass): empty events
-    if (blockIdx.y == 0)
+    if (slice == 0)
         for (int e = N + tid; e < ((N + 63) & ~63); e += kPackThreads) {
-            size_t o = (size_t)b * cap + slot0 + e;
-            ts[o] = y[o] = x[o] = mp[o] = mn[o] = 0.0f;
-            if (b == 0) bin[slot0 + e] = (uint8_t)pass_idx;
+            size_t o = (size_t)b * a.cap + a.slot0 + e;
+            a.ts[o] = a.y[o] = a.x[o] = a.mp[o] = a.mn[o] = 0.0f;
+            if (b == 0) a.bin[a.slot0 + e] = (uint8_t)a.pass_idx;
         }
+}
+
+__global__ __launch_bounds__(kPackThreads) void pack_events_kernel(PackArgs a)
+{
+    extern __shared__ int cnt[];
+    pack_events_block(a, blockIdx.x, blockIdx.y, gridDim.y, cnt);
 }
 
 // flow map of one head of one pass: [B,2,H,W] (ch0 = x, ch1 = y; any batch/channel strides, dense rows)
@@ -2322,6 +2335,33 @@ __global__ __launch_bounds__(256) void pack_flows_kernel(FlowHeads hd, int B, in
     pl[((size_t)b * 2) * HW + p] = fx;
     pl[((size_t)b * 2 + 1) * HW + p] = fy;
     yx[((size_t)i * B + b) * HW + p] = make_float2(fy, fx);
+}
+
+// One pass of update() in ONE launch (round 5; three launches before: the flow maps and the two event lists): blockIdx.y
+// selects the job — [0, sg) slices of the gradient list, [sg, sg + sd) slices of the detached list, then the flow maps
+// (1024 pixels of all F heads per workgroup).
+__global__ __launch_bounds__(kPackThreads) void update_pass_kernel(PackArgs ga, int sg, PackArgs da, int sd, FlowHeads hd, int F,
+                                                                   int B, int HW, float *__restrict__ planar,
+                                                                   float2 *__restrict__ yx)
+{
+    extern __shared__ int cnt[];
+    const int b = blockIdx.x, job = blockIdx.y;
+    if (job < sg) {
+        pack_events_block(ga, b, job, sg, cnt);
+    } else if (job < sg + sd) {
+        pack_events_block(da, b, job - sg, sd, cnt);
+    } else {
+        const int p = (job - sg - sd) * kPackThreads + threadIdx.x;
+        if (p >= HW) return;
+        for (int i = 0; i < F; ++i) {
+            const float *src = hd.src[i];
+            const float fx = src[(size_t)b * hd.sb[i] + p], fy = src[(size_t)b * hd.sb[i] + hd.sc[i] + p];
+            float *pl = planar + (size_t)i * B * 2 * HW;
+            pl[((size_t)b * 2) * HW + p] = fx;
+            pl[((size_t)b * 2 + 1) * HW + p] = fy;
+            yx[((size_t)i * B + b) * HW + p] = make_float2(fy, fx);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2480,7 +2520,10 @@ bool ensure_attrs()
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplat2LdsBudget);
     static const hipError_t e2 = hipFuncSetAttribute((const void *)dflow_splat_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
-    static const hipError_t e3 = hipFuncSetAttribute((const void *)pack_events_kernel,
+    static const hipError_t e3a = hipFuncSetAttribute((const void *)pack_events_kernel,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)((2 * kMaxSortBins + kPackThreads) * sizeof(int)));
+    static const hipError_t e3 = e3a != hipSuccess ? e3a : hipFuncSetAttribute((const void *)update_pass_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)((2 * kMaxSortBins + kPackThreads) * sizeof(int)));
     if (e3 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e3);
@@ -2499,14 +2542,17 @@ size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg)
     return make_layout(w).total;
 }
 
-int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx,
-                    int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
-                    uint8_t *bin, int *cls, void *stream)
+}  // extern "C"
+
+namespace {
+// argument block, LDS bytes and workgroups per sample of one pack job (N > 0)
+bool pack_job(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx, int slot0, int cap,
+              int H, int W, float *ts, float *y, float *x, float *mp, float *mn, uint8_t *bin, int *cls, PackArgs *a,
+              size_t *lds, int *slices)
 {
     if (B < 1 || N < 0 || slot0 < 0 || (slot0 & 63) || slot0 + ((N + 63) & ~63) > cap || pass_idx < 0 ||
         pass_idx >= TEF_MAX_PASSES || H < 1 || W < 1)
-        return tef::fail("tef_pack_events: bad sizes (slot0 must be a multiple of 64, cap must hold N rounded up to 64)"), TEF_ERR_INVALID;
-    if (N == 0) return 0;
+        return tef::fail("tef_pack_events: bad sizes (slot0 must be a multiple of 64, cap must hold N rounded up to 64)");
     SortGeom geo;
     geo.tw = 16;
     geo.th = 8;
@@ -2519,14 +2565,32 @@ int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, co
         if (geo.tw <= geo.th) geo.tw *= 2; else geo.th *= 2;
     }
     int nbins = 4 * geo.ntx * geo.nty * geo.sub;
-    size_t lds = (size_t)(2 * nbins + kPackThreads) * sizeof(int);
+    *lds = (size_t)(2 * nbins + kPackThreads) * sizeof(int);
+    *slices = N >= 4 * kPackThreads ? kPackSlices : 1;
+    a->ev = ev; a->pm = pm; a->N = N; a->ts_shift = ts_shift; a->ts_override = ts_override; a->pass_idx = pass_idx;
+    a->slot0 = slot0; a->cap = cap; a->H = H; a->W = W; a->geo = geo;
+    a->ts = ts; a->y = y; a->x = x; a->mp = mp; a->mn = mn; a->bin = bin; a->cls = cls;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+int tef_pack_events(float *ev, const float *pm, int B, int N, float ts_shift, const float *ts_override, int pass_idx,
+                    int slot0, int cap, int H, int W, float *ts, float *y, float *x, float *mp, float *mn,
+                    uint8_t *bin, int *cls, void *stream)
+{
+    PackArgs a;
+    size_t lds;
+    int slices;
+    if (!pack_job(ev, pm, B, N, ts_shift, ts_override, pass_idx, slot0, cap, H, W, ts, y, x, mp, mn, bin, cls, &a, &lds, &slices))
+        return TEF_ERR_INVALID;
+    if (N == 0) return 0;
     if (!ensure_attrs()) return TEF_ERR_LAUNCH;
-    const int slices = N >= 4 * kPackThreads ? kPackSlices : 1;
     hipStream_t st = (hipStream_t)stream;
     {
         tef::ProfScope ps(tef::PROF_PACK, st);
-        hipLaunchKernelGGL(pack_events_kernel, dim3(B, slices), dim3(kPackThreads), lds, st, ev, pm, N, ts_shift, ts_override,
-                           pass_idx, slot0, cap, H, W, geo, ts, y, x, mp, mn, bin, cls);
+        hipLaunchKernelGGL(pack_events_kernel, dim3(B, slices), dim3(kPackThreads), lds, st, a);
     }
     return tef::check_launch("pack_events_kernel");
 }
@@ -2570,6 +2634,34 @@ int tef_update_pass(const float *const *flows, const long *stride_b, const long 
                     const tef_events *grad, const tef_events *det, void *stream)
 {
     if (!grad || !det) return tef::fail("tef_update_pass: null event store"), TEF_ERR_INVALID;
+    if (flows && stride_b && stride_c && planar && yx && F >= 1 && F <= kMaxHeads && B >= 1 && H >= 1 && W >= 1 && (N > 0 || Nd > 0)) {
+        // the whole pass in ONE launch: [gradient list slices | detached list slices | flow-map blocks] per sample
+        PackArgs ga{}, da{};
+        size_t lg = 0, ld = 0;
+        int sg = 0, sd = 0;
+        if (N > 0 && !pack_job(ev, pm, B, N, (float)pass_idx, ts_override, pass_idx, slot0, grad->cap, H, W, (float *)grad->ts,
+                               (float *)grad->y, (float *)grad->x, (float *)grad->mp, (float *)grad->mn, (uint8_t *)grad->bin,
+                               (int *)grad->cls, &ga, &lg, &sg))
+            return TEF_ERR_INVALID;
+        if (Nd > 0 && !pack_job(dev, dpm, B, Nd, (float)pass_idx, dts_override, pass_idx, dslot0, det->cap, H, W, (float *)det->ts,
+                                (float *)det->y, (float *)det->x, (float *)det->mp, (float *)det->mn, (uint8_t *)det->bin,
+                                (int *)det->cls, &da, &ld, &sd))
+            return TEF_ERR_INVALID;
+        FlowHeads hd{};
+        for (int i = 0; i < F; ++i) {
+            if (!flows[i]) return tef::fail("tef_update_pass: null flow map"), TEF_ERR_INVALID;
+            hd.src[i] = flows[i]; hd.sb[i] = stride_b[i]; hd.sc[i] = stride_c[i];
+        }
+        if (!ensure_attrs()) return TEF_ERR_LAUNCH;
+        const int HW = H * W, sf = (HW + kPackThreads - 1) / kPackThreads;
+        hipStream_t st = (hipStream_t)stream;
+        {
+            tef::ProfScope ps(tef::PROF_PACK, st);
+            hipLaunchKernelGGL(update_pass_kernel, dim3(B, sg + sd + sf), dim3(kPackThreads), std::max(lg, ld), st, ga, sg, da, sd, hd,
+                               F, B, HW, planar, (float2 *)yx);
+        }
+        return tef::check_launch("update_pass_kernel");
+    }
     if (int rc = tef_pack_flows(flows, stride_b, stride_c, F, B, H, W, planar, yx, stream)) return rc;
     if (N > 0) {
         if (int rc = tef_pack_events(ev, pm, B, N, (float)pass_idx, ts_override, pass_idx, slot0, grad->cap, H, W, (float *)grad->ts,
