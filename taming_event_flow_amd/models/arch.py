@@ -130,6 +130,8 @@ class MultiResUNetRecurrent(nn.Module):
         if not params or not params[0].is_cuda:
             return False
         b = self._bucket
+        if b is None and all(p.grad is not None and p.grad.is_contiguous() for p in params):
+            return False                        # the caller keeps gradient buffers of its own (and flushes what it defers)
         if b is None or len(b.params) != len(params) or any(x is not y for x, y in zip(b.params, params)) or \
                 b.flat.device != params[0].device:
             try:
@@ -145,7 +147,10 @@ class MultiResUNetRecurrent(nn.Module):
                     p.grad.copy_(g)
             sm.enable_direct_grads(self)
             sm.enable_deferred_wgrad(self, os.environ.get("TEF_NO_DEFERRED_WGRAD", "0") != "1")
-            sm.AUTO_FLUSH = True
+            for m_ in self.modules():           # (layer-by-layer passes through this network flush at the end of backward too)
+                for v_ in vars(m_).values():
+                    if isinstance(v_, sm.PackedWeights):
+                        v_.auto_flush = True
             # the deferred weight gradients of every few finished backward passes are reduced on a stream of their own
             # beside the rest of BPTT (as under train.Trainer); the callback at the end of backward() joins it
             group = int(os.environ.get("TEF_WGRAD_GROUP", "3"))

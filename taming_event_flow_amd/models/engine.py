@@ -340,7 +340,7 @@ class PassEngine:
         if direct and a.deferred_wgrad and not rec.queued:
             if self._pending and (self._pending[0].plan.B, self._pending[0].plan.H, self._pending[0].plan.W) != (pl.B, pl.H, pl.W):
                 self.flush_window()
-            if not self._pending and a.auto_grads:
+            if not self._pending and a.auto_grads and a._bucket is not None:
                 # nobody calls flush_window for the drop-in loop: at the end of this backward() (autograd runs the queued
                 # callbacks when every node is done)
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)

@@ -170,7 +170,7 @@ class _ConvFn(torch.autograd.Function):
                 flush_deferred_wgrads(packer)
             packer.pending_meta = meta
             packer.pending.append((g if g_formed else dout, x0, x1, gate1))
-            if AUTO_FLUSH and not _DEFERRED:
+            if getattr(packer, "auto_flush", False) and not _DEFERRED:
                 # a network that owns its gradient buffers (arch.own_gradients: the drop-in loop, nobody flushes): at the end
                 # of this backward()
                 torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
@@ -216,7 +216,6 @@ class _ConvFn(torch.autograd.Function):
 
 _MAX_PARTS = 16        # TEF_CONV_MAX_PARTS (include/tef.h)
 _DEFERRED = set()      # packers with queued weight-gradient parts
-AUTO_FLUSH = False     # set by arch.own_gradients(): deferred weight gradients are flushed by a callback at the end of backward()
 _DEFERRED_ENGINES = set()      # pass engines (models/engine.py) holding the backward calls of an unfinished window
 
 
