@@ -43,8 +43,12 @@
 namespace {
 
 constexpr float kEps = 1e-9f;
-constexpr int kSplatThreads = 1024;
-constexpr size_t kSplatLdsBudget = 141 * 1024;   // K7's two planes of 64 + 2 halo rows at 128 x 128 (beside ~22 KiB of run tables and per-wavefront row lists)
+// K7: TWO 512-thread workgroups per CU, each with the two planes of a 32-row band (+ 2 halo rows) at 128 x 128 (round 5; one
+// 1024-thread workgroup with 64-row bands before: 640 items over 256 workgroups are 2.5 each — the queue's longest-first
+// order still left a sixth of the kernel to the workgroups that drew three; 1280 items over 512 balance to a few per cent,
+// and one workgroup's clearing / write-out overlaps the other's sweep: 0.134 -> 0.119 ms)
+constexpr int kSplatThreads = 512;
+constexpr size_t kSplatLdsBudget = 73 * 1024;    // (beside ~5 KiB of run tables and per-wavefront row lists)
 constexpr int kRowPad = 8;                  // 8-byte LDS rows are W + 8 wide: rows 16 banks apart, so the few-row
                                             // neighbourhood a sorted wavefront hits spreads over all 64 banks
 constexpr int kMaxImages = 448;             // sum_s 2^s * (P/2^s + 1) <= 6*64 + 63
@@ -1953,13 +1957,13 @@ __device__ __forceinline__ void dflow_fixed(float fiy, float fix, float fy0, flo
     atomicAdd(q0 + WP + 1, to_fixed(b1.y));
 }
 
-// Persistent like K2: one workgroup per CU pulls (map k, head, sample, row band) items from the per-XCD queues
+// Persistent like K2: two workgroups per CU pull (map k, head, sample, row band) items from the per-XCD queues
 // [8, 16); the band holds BOTH components of the map's gradient (2 planes x (64 + 2 halo) rows at 128x128), so an
 // event's position, taps and weights are computed once for its eight accumulations, and per 16-slot row the workgroup
 // reads K1's interval of the plane the events sampled the map at (plane k for earlier passes, k + 1 for later ones, the
 // original locations — trajectory plane `nplanes` — for pass k) and loads the row only if it can touch the band.  An event
 // visit is two 8-byte loads (vector, position) at 32-bit offsets from scalar bases.
-__global__ __launch_bounds__(kSplatThreads) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
+__global__ __launch_bounds__(kSplatThreads, 4) void dflow_splat_kernel(Win w, Events g, const float2 *__restrict__ traj,
                                                                     const float2 *__restrict__ yr,
                                                                     const float2 *__restrict__ cyx,
                                                                     const uint32_t *__restrict__ cmax,
@@ -2795,7 +2799,7 @@ int tef_loss_backward(const tef_loss_cfg *cfg, const float *flows_yx, const tef_
     band_geometry(w, 2, &rows, &nbands, &lds, kSplatLdsBudget, 2);
     {
         const long items = (long)w.P * FB * nbands;
-        unsigned grid = (unsigned)std::min<long>(items, num_cus());
+        unsigned grid = (unsigned)std::min<long>(items, 2 * num_cus());
         grid = std::max(8u, (grid + 7u) & ~7u);
         TEF_LAUNCH_TIMED(tef::PROF_DFLOW, dflow_splat_kernel, dim3(grid), dim3(kSplatThreads), lds, st, w, g, traj,
                          (const float2 *)(ws + L.yr), cyx, cmax, dflows, rows, nbands, (int *)(ws + L.queue) + 8);
