@@ -3,7 +3,7 @@
 #   tools/refresh_profiles.sh [ROUND_TAG]        (default r02)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-R=${1:-r04}
+R=${1:-r05}
 O=gpurun_out/final
 mkdir -p $O
 timeout 400 python bench.py > $O/${R}_loss_bench.json 2> $O/loss_bench.err
