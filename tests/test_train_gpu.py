@@ -562,10 +562,12 @@ def test_loss_workspace_lease():
 
 def test_graph_teardown_leaves_no_late_writes():
     """Regression test of the round-3 / round-4 corruption: a captured multi-stream window is created,
-    replayed and dropped, then a fresh one-stream trainer is built from the same seed — its parameters must be bit-identical
-    to the first such trainer's every time.  Without the second wait in CapturedWindow.close(), 6 % of these iterations
-    found two weights of the new trainer's first convolution overwritten (one decremented by an ulp, one zeroed) by writes
-    the destroyed hipGraph left behind."""
+    replayed and dropped together with its trainer, then a fresh one-stream trainer is built from the same seed — its
+    parameters must be bit-identical to the first such trainer's every time.  When dropped graphs were DESTROYED, 6 % of these
+    iterations found two weights of the new trainer's first convolution overwritten (one decremented by an ulp, one zeroed)
+    by writes the destroyed hipGraph left behind.  The shipped path never destroys a graph: a closed window is parked in its
+    trainer, a dying trainer retires its graphs (kept allocated until the process ends) — this test holds that line; the
+    destroying path itself is exercised by test_destroying_retired_graphs_diagnostic below."""
     import copy
 
     import __graft_entry__ as g
@@ -601,3 +603,50 @@ def test_graph_teardown_leaves_no_late_writes():
         got = fresh_weights()
         bad = (got != expected).nonzero().reshape(-1)
         assert bad.numel() == 0, (it, bad[:4].tolist(), expected[bad[:4]].tolist(), got[bad[:4]].tolist())
+
+
+@pytest.mark.xfail(strict=False, reason="diagnostic: destroying captured multi-stream hipGraphs on this ROCm stack can leave late "
+                                        "device-side writes (DESIGN 9d); passes when the runtime behaves")
+def test_destroying_retired_graphs_diagnostic():
+    """train.release_retired_graphs() — the only way to give retired graphs' memory back before the process ends — on the
+    workload of the test above: a few rounds of (capture, replay, drop, release) followed by a fresh trainer whose parameters
+    must still be what the seed makes them.  Not part of the contract (the default never destroys a graph); it tells when
+    the work-around can go."""
+    import copy
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import train
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"].update(batch_size=2, resolution=[64, 64], max_num_grad_events=1500)
+    cfg["data"].update(passes_loss=4)
+    cfg["optimizer"].update(lr=0.0, capturable=True)
+
+    def fresh_weights():
+        torch.manual_seed(7)
+        tr = train.Trainer(cfg, dev, streams=False)
+        w = torch.cat([p.detach().reshape(-1) for p in tr.model.parameters()]).clone()
+        tr.close()
+        return w
+
+    expected = fresh_weights()
+    for it in range(4):
+        torch.manual_seed(7)
+        tr = train.Trainer(cfg, dev, streams=True)
+        src = train.SyntheticSequences(cfg, dev, 2000, seq_len=10 ** 9, seed=3, jitter=300)
+        tr.reset()
+        win = tr.capture_window([src.next() for _ in range(4)], warmup=1)
+        win()
+        float(tr.last_loss.item())
+        win.close()
+        tr.close()
+        del win, tr, src
+        assert train.retired_graph_count() > 0
+        train.release_retired_graphs()
+        assert train.retired_graph_count() == 0
+        got = fresh_weights()
+        bad = (got != expected).nonzero().reshape(-1)
+        assert bad.numel() == 0, (it, bad[:4].tolist())
