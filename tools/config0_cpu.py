@@ -4,7 +4,10 @@ plumbing, no GPU"): the reference itself and the C port (oracle/) timed side by 
 backward of one Iterative/two window (P = 10, F = 4), min and median of >= 5 repetitions.  Needs /root/reference.
 
     python tools/config0_cpu.py > profiles/r04_config0_cpu.json
+    python tools/config0_cpu.py --batch 8 --events 10000 --threads 8 > profiles/r05_config1_cpu_b8.json
+        (the BASELINE window bench.py times, B = 8: the reference itself against the port that serves as `cpu_baseline`)
 """
+import argparse
 import json
 import os
 import sys
@@ -24,10 +27,16 @@ import warnings  # noqa: E402
 warnings.filterwarnings("ignore")
 from loss.flow import Iterative  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--events", type=int, nargs="*", default=[1000, 10000])
+ap.add_argument("--threads", type=int, nargs="*", default=[1, 8])
+args = ap.parse_args()
 H = W = 128
-P, F, B = 10, 4, 1
-out = {"config": "BASELINE configs[0]: Iterative/two fwd+bwd, 128x128, B=1, P=10, F=4", "host_cores": os.cpu_count(), "rows": []}
-for N in (1000, 10000):
+P, F, B = 10, 4, args.batch
+out = {"config": f"BASELINE configs[{0 if B == 1 else 1}]: Iterative/two fwd+bwd, 128x128, B={B}, P=10, F=4", "host_cores": os.cpu_count(),
+       "rows": []}
+for N in args.events:
     rng = np.random.default_rng(5)
     win = synth.make_window(rng, B, H, W, P, F, N, 0, sigma=2.0)
     cfg = {"loader": {"resolution": [H, W], "batch_size": B},
@@ -52,7 +61,7 @@ for N in (1000, 10000):
         l, _ = ow.iterative(backward=True)
         return time.perf_counter() - t0, float(l)
 
-    for threads in (1, 8):
+    for threads in args.threads:
         torch.set_num_threads(threads)
         oracle.threads(threads)
         for name, fn in (("reference (CPU PyTorch)", ref_once), ("port (oracle/tef_oracle.c)", port_once)):
