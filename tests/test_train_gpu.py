@@ -605,8 +605,10 @@ def test_graph_teardown_leaves_no_late_writes():
         assert bad.numel() == 0, (it, bad[:4].tolist(), expected[bad[:4]].tolist(), got[bad[:4]].tolist())
 
 
-@pytest.mark.xfail(strict=False, reason="diagnostic: destroying captured multi-stream hipGraphs on this ROCm stack can leave late "
-                                        "device-side writes (DESIGN 9d); passes when the runtime behaves")
+@pytest.mark.skipif(os.environ.get("TEF_RUN_DESTROY_DIAGNOSTIC", "0") != "1",
+                    reason="opt-in diagnostic (TEF_RUN_DESTROY_DIAGNOSTIC=1, in a process of its own): destroying captured "
+                           "multi-stream hipGraphs on this ROCm stack leaves late device-side writes (DESIGN 9d) — round 5 saw it "
+                           "pass alone and take the interpreter down with a segmentation fault behind 21 other trainer tests")
 def test_destroying_retired_graphs_diagnostic():
     """train.release_retired_graphs() — the only way to give retired graphs' memory back before the process ends — on the
     workload of the test above: a few rounds of (capture, replay, drop, release) followed by a fresh trainer whose parameters

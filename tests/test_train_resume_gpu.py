@@ -93,7 +93,7 @@ def test_recapture_of_the_same_shapes_retains_nothing_more(dev):
     tr, wins = _fresh(cfg, dev, 1)
     n0 = train.retired_graph_count()
     reserved, losses = [], []
-    for it in range(20):
+    for it in range(12):
         cw = tr.capture_window(_clone(wins[0]), warmup=1)
         tr.optimizer.param_groups[0]["lr"] = 1e-4 * (1 + it)
         before = _params(tr)
@@ -106,7 +106,7 @@ def test_recapture_of_the_same_shapes_retains_nothing_more(dev):
         reserved.append(torch.cuda.memory_reserved())
     assert train.retired_graph_count() == n0
     assert reserved[-1] <= reserved[1] + (4 << 20), [r >> 20 for r in reserved]
-    assert all(np.isfinite(losses)) and len(set(losses)) > 10
+    assert all(np.isfinite(losses)) and len(set(losses)) > 6
     # eager passes between two captures: the parked window picks up the trainer's state as it is then
     for b in _clone(wins[0]):
         tr.step(b)
