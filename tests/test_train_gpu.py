@@ -589,7 +589,7 @@ def test_graph_teardown_leaves_no_late_writes():
         return w
 
     expected = fresh_weights()
-    for it in range(12):
+    for it in range(8):
         torch.manual_seed(7)
         tr = train.Trainer(cfg, dev, streams=True)
         src = train.SyntheticSequences(cfg, dev, 2000, seq_len=10 ** 9, seed=3, jitter=300)
