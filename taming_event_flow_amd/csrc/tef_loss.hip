@@ -2177,14 +2177,14 @@ constexpr int kMaxSortBins = 12288;     // 48 KiB of LDS counters (4 classes x t
 // line of an interleaved flow map or (A, R) image per pixel row — so events that follow each other in a pass start on
 // the same line: the 4 lanes the texture path handles per cycle of a 16-byte gather then ask for one or two lines
 // instead of three or four (the chain kernels are bound by the L1's line lookups: DESIGN.md section 9b).
-struct SortGeom { int tw, th, ntx, nty, sub; };
+struct SortGeom { int tw, th, ntx, nty, sub, ltw, lth; };      // (tw = 1 << ltw, th = 1 << lth)
 __device__ __forceinline__ int sort_key(float y, float x, float mp, float mn, int H, int W, const SortGeom &g)
 {
     // pos-only (mask exactly (1, 0)), neg-only ((0, 1)), general (both polarities or other values), collate padding
     int cls = (mp != 0.0f) ? (mn != 0.0f ? 2 : 0) : (mn != 0.0f ? 1 : 3);
     if ((mp != 0.0f && mp != 1.0f) || (mn != 0.0f && mn != 1.0f)) cls = 2;     // general mask values: fp64 splat path
     const int yi = min(max((int)y, 0), H - 1), xi = min(max((int)x, 0), W - 1);
-    const int ty = yi / g.th, tx = xi / g.tw;
+    const int ty = yi >> g.lth, tx = xi >> g.ltw;
     const int row = g.sub > 1 ? yi - ty * g.th : 0;
     return ((cls * g.nty + ty) * g.ntx + tx) * g.sub + row;
 }
@@ -2205,14 +2205,166 @@ struct PackArgs {
     float ts_shift;
     const float *ts_override;
     int pass_idx, slot0, cap, H, W;
+    int stage;          // pack_events_fast: slots per staging round
     SortGeom geo;
     float *ts, *y, *x, *mp, *mn;
     uint8_t *bin;
     int *cls;
 };
 
+// Lists of up to kPackFastMax events (the reference's 10 000 per pass and sample) — round 5.  What paces a pack workgroup:
+// one compute unit streams ~60 GB/s (a 240 KB list: 4-6 us per sweep), and a scattered 4-byte store or a 16-byte gather costs
+// the L1 one line look-up per lane.  The slice scheme below has each of eight workgroups count the whole list, then sweep its
+// EVENT slice and scatter five words per event (17.7 us per pass); one workgroup doing everything through LDS needs three
+// sweeps (21 us); walking the slots and gathering the events 28 us.
+// Here the slices are SLOT ranges.  Every workgroup counts the whole list once; the counting atomic returns the event's
+// rank inside its bin, so after the scan of the counters each thread knows the slot of its events (bin and rank stay in
+// registers).  Workgroup s takes the slots [lo_s, hi_s): the boundaries s N / S moved up to the next bin boundary, the same
+// in every workgroup — whole bins, so the ranks (which differ between workgroups: arrival order) never cross a boundary.
+// It re-reads just ITS events (exec-masked loads), writes them into an SoA staging area in LDS at slot - lo_s, and copies
+// that out with coalesced stores; a range longer than the staging area (skewed lists) takes several rounds.  No workgroup
+// needs another's result.  The in-place shift of an event's time stamp is done by the workgroup that stages it (nobody else
+// reads that word: the counting sweep looks at the coordinates only).
+//   cnt: [nbins] counters, [16] wavefront totals, [2] range boundaries, then five staging arrays of `stage` words
+constexpr int kPackFastMax = 16 * kPackThreads;
+constexpr size_t kPackFastLds = 144 * 1024;
+__device__ __forceinline__ void pack_events_fast(const PackArgs &a, int b, int slice, int nslices, int *cnt)
+{
+    const SortGeom &geo = a.geo;
+    const int N = a.N, H = a.H, W = a.W, stage = a.stage;
+    const int ntiles = geo.ntx * geo.nty * geo.sub, nbins = 4 * ntiles;
+    int *part = cnt + nbins, *bound = part + 16;
+    float *st_ts = reinterpret_cast<float *>(bound + 2), *st_y = st_ts + stage, *st_x = st_y + stage, *st_mp = st_x + stage,
+          *st_mn = st_mp + stage;
+    const int tid = threadIdx.x;
+    float *evw = a.ev + (size_t)b * N * 4;
+    const float4 *evb = reinterpret_cast<const float4 *>(evw);
+    const float2 *pmb = reinterpret_cast<const float2 *>(a.pm) + (size_t)b * N;
+    for (int k = tid; k < nbins; k += kPackThreads) cnt[k] = 0;
+    if (tid < 2) bound[tid] = N;
+    __syncthreads();
+    constexpr int kHalf = 8, kRounds = 2;    // staging sweep: events per thread and load round (the rounds cover kPackFastMax)
+    constexpr int kEv = kHalf * kRounds;
+    int slot[kEv] = {}, rank[kEv] = {};      // slot: first the bin, after the scan the event's slot
+    {   // counting sweep: coordinates and masks only (8 + 8 bytes per event), every load of the thread in flight at once
+        float2 yx[kEv], mk[kEv];
+#pragma unroll
+        for (int j = 0; j < kEv; ++j) {
+            if (j * kPackThreads >= N) break;
+            const int e = min(tid + j * kPackThreads, N - 1);
+            yx[j] = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(evb) + (uint32_t)e * 16u + 4u);
+            mk[j] = *at_bytes(pmb, (uint32_t)e * 8u);
+        }
+#pragma unroll
+        for (int j = 0; j < kEv; ++j) {
+            if (j * kPackThreads >= N) break;
+            slot[j] = sort_key(yx[j].x, yx[j].y, mk[j].x, mk[j].y, H, W, geo);
+            if (tid + j * kPackThreads < N) rank[j] = atomicAdd(&cnt[slot[j]], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counters, in place (as in the slice scheme); the slot range of this workgroup
+    const int t_lo = (int)((long)slice * N / nslices), t_hi = slice + 1 == nslices ? N : (int)((long)(slice + 1) * N / nslices);
+    const int per = (nbins + kPackThreads - 1) / kPackThreads;
+    const int lo = min(tid * per, nbins), hi = min(lo + per, nbins);
+    int run = 0;
+    for (int k = lo; k < hi; ++k) run += cnt[k];
+    const int incl = wave_prefix_sum(run);
+    if ((tid & 63) == 63) part[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - run;
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += part[wv];
+    // The range boundaries: the first bin start at or past the targets.  Starts never decrease, so exactly one thread has the
+    // start of its first bin below a target and the start of the next thread's first bin (or N) at or past it: it writes the
+    // boundary with a plain store (an atomicMin by every thread — up to 1024 lanes on ONE LDS word — took 5 us).
+    const int first = base;
+    int b_lo = N, b_hi = N;
+    for (int k = lo; k < hi; ++k) {
+        const int c = cnt[k];
+        cnt[k] = base;
+        if (base >= t_lo) b_lo = min(b_lo, base);
+        if (base >= t_hi) b_hi = min(b_hi, base);
+        base += c;
+    }
+    if (lo < hi) {
+        const int next = hi == nbins ? N : base;      // start of the next thread's first bin
+        if (first < t_lo && next >= t_lo) bound[0] = min(b_lo, next);
+        if (first < t_hi && next >= t_hi) bound[1] = min(b_hi, next);
+    }
+    if (tid == 0) {
+        if (t_lo <= 0) bound[0] = 0;
+        if (t_hi <= 0) bound[1] = 0;
+    }
+    __syncthreads();
+    if (slice == 0 && tid < 3) a.cls[((size_t)b * TEF_MAX_PASSES + a.pass_idx) * 3 + tid] = cnt[(tid + 1) * ntiles];      // run ends of the three event classes
+    const int s_lo = slice == 0 ? 0 : bound[0], s_hi = slice + 1 == nslices ? N : bound[1];
+#pragma unroll
+    for (int j = 0; j < kEv; ++j)            // (every entry: the staging rounds look at whole load rounds)
+        slot[j] = tid + j * kPackThreads < N ? cnt[slot[j]] + rank[j] : -1;
+    const bool ts_fixed = a.ts_override != nullptr;
+    const float ts_value = ts_fixed ? a.ts_override[0] : 0.0f;
+    const size_t o0 = (size_t)b * a.cap + a.slot0;
+    for (int s0 = s_lo; s0 < s_hi; s0 += stage) {
+        const int n = min(stage, s_hi - s0);
+#pragma unroll
+        for (int h = 0; h < kRounds; ++h) {
+            if (h * kHalf * kPackThreads >= N) break;
+            float4 v[kHalf];
+            float2 m[kHalf];
+            int tv = tid;
+            asm volatile("" : "+v"(tv));     // (addresses formed here, per round: hoisted out of the loops they were 96 registers and spills)
+#pragma unroll
+            for (int j = 0; j < kHalf; ++j) {
+                const unsigned q = (unsigned)(slot[h * kHalf + j] - s0);
+                if (q < (unsigned)n) {       // this round stages the event: the only read of its time stamp, then the shift
+                    const uint32_t e = (uint32_t)(tv + (h * kHalf + j) * kPackThreads);
+                    v[j] = *at_bytes(evb, e * 16u);
+                    m[j] = *at_bytes(pmb, e * 8u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kHalf; ++j) {
+                const unsigned q = (unsigned)(slot[h * kHalf + j] - s0);
+                if (q < (unsigned)n) {
+                    const uint32_t e = (uint32_t)(tv + (h * kHalf + j) * kPackThreads);
+                    const float t = v[j].x + a.ts_shift;
+                    *at_bytes(evw, e * 16u) = t;                 // in-place shift of the caller's list (:457-458)
+                    st_ts[q] = ts_fixed ? ts_value : t;
+                    st_y[q] = v[j].y;
+                    st_x[q] = v[j].z;
+                    st_mp[q] = m[j].x;
+                    st_mn[q] = m[j].y;
+                }
+            }
+            asm volatile("" ::: "memory");
+        }
+        lds_barrier();                       // (LDS only: __syncthreads() would wait for the time-stamp stores to be acknowledged)
+        for (int q = tid; q < n; q += kPackThreads) {
+            const size_t o = o0 + s0 + q;
+            a.ts[o] = st_ts[q];
+            a.y[o] = st_y[q];
+            a.x[o] = st_x[q];
+            a.mp[o] = st_mp[q];
+            a.mn[o] = st_mn[q];
+            if (b == 0) a.bin[a.slot0 + s0 + q] = (uint8_t)a.pass_idx;
+        }
+        if (s0 + stage < s_hi) lds_barrier();
+    }
+    // alignment slots up to the next multiple of 64: empty events
+    if (slice + 1 == nslices)
+        for (int e = N + tid; e < ((N + 63) & ~63); e += kPackThreads) {
+            const size_t o = o0 + e;
+            a.ts[o] = a.y[o] = a.x[o] = a.mp[o] = a.mn[o] = 0.0f;
+            if (b == 0) a.bin[a.slot0 + e] = (uint8_t)a.pass_idx;
+        }
+}
+
 __device__ __forceinline__ void pack_events_block(const PackArgs &a, int b, int slice, int nslices, int *cnt)
 {
+    if (a.stage > 0) {
+        pack_events_fast(a, b, slice, nslices, cnt);
+        return;
+    }
     // cnt: [nbins] all events, [nbins] events of earlier slices, [kPackThreads] scan scratch
     const SortGeom &geo = a.geo;
     const int N = a.N, H = a.H, W = a.W;
@@ -2356,7 +2508,7 @@ __global__ __launch_bounds__(kPackThreads) void update_pass_kernel(PackArgs ga, 
         pack_events_block(da, b, job - sg, sd, cnt);
     } else {
         const int p = (job - sg - sd) * kPackThreads + threadIdx.x;
-        if (p >= HW) return;
+        if (p < HW)
         for (int i = 0; i < F; ++i) {
             const float *src = hd.src[i];
             const float fx = src[(size_t)b * hd.sb[i] + p], fy = src[(size_t)b * hd.sb[i] + hd.sc[i] + p];
@@ -2526,10 +2678,10 @@ bool ensure_attrs()
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSplatLdsBudget);
     static const hipError_t e3a = hipFuncSetAttribute((const void *)pack_events_kernel,
                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      (int)((2 * kMaxSortBins + kPackThreads) * sizeof(int)));
+                                                      (int)std::max((2 * kMaxSortBins + kPackThreads) * sizeof(int), kPackFastLds));
     static const hipError_t e3 = e3a != hipSuccess ? e3a : hipFuncSetAttribute((const void *)update_pass_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)((2 * kMaxSortBins + kPackThreads) * sizeof(int)));
+                                                     (int)std::max((2 * kMaxSortBins + kPackThreads) * sizeof(int), kPackFastLds));
     if (e3 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e3);
     if (e1 != hipSuccess || e2 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e1 != hipSuccess ? e1 : e2);
     return true;
@@ -2568,9 +2720,23 @@ bool pack_job(float *ev, const float *pm, int B, int N, float ts_shift, const fl
         if (tiles4 * geo.sub <= kMaxSortBins) break;
         if (geo.tw <= geo.th) geo.tw *= 2; else geo.th *= 2;
     }
+    geo.ltw = __builtin_ctz(geo.tw);
+    geo.lth = __builtin_ctz(geo.th);
     int nbins = 4 * geo.ntx * geo.nty * geo.sub;
+    *slices = N > kPackFastMax ? kPackSlices : 1;
     *lds = (size_t)(2 * nbins + kPackThreads) * sizeof(int);
-    *slices = N >= 4 * kPackThreads ? kPackSlices : 1;
+    a->stage = 0;
+    if (N <= kPackFastMax) {
+        // slot-range slices (pack_events_fast); the staging area holds twice the even share of a workgroup, whatever is over
+        // that (skewed lists) takes more rounds
+        *slices = N >= 2 * kPackThreads ? kPackSlices : 1;
+        const size_t head = (size_t)(nbins + 16 + 2) * sizeof(int);
+        const int room = (int)((kPackFastLds - head) / (5 * sizeof(float))) & ~63;      // slots the staging area can hold
+        a->stage = std::min(room, (2 * ((N + *slices - 1) / *slices) + 63) & ~63);
+        // (at least 84 KiB: ONE workgroup per compute unit.  With less, two of a launch's 64 + 128 workgroups were placed on one
+        // compute unit while others stayed empty, and every phase of both took twice as long)
+        *lds = std::max(head + (size_t)5 * a->stage * sizeof(float), (size_t)84 * 1024);
+    }
     a->ev = ev; a->pm = pm; a->N = N; a->ts_shift = ts_shift; a->ts_override = ts_override; a->pass_idx = pass_idx;
     a->slot0 = slot0; a->cap = cap; a->H = H; a->W = W; a->geo = geo;
     a->ts = ts; a->y = y; a->x = x; a->mp = mp; a->mn = mn; a->bin = bin; a->cls = cls;

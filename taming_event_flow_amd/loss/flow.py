@@ -34,6 +34,7 @@ class _SoA:
         self.cap_hint = cap_hint      # slots the previous window of this module needed: allocated in one go
         self.off = [0]
         self.ts = self.y = self.x = self.mp = self.mn = self.bin = None
+        self._ref = None
         # per (sample, pass): ends of the pos-only / neg-only / both-polarity runs (written by tef_pack_events)
         self.cls = torch.zeros((B, _lib.TEF_MAX_PASSES, 3), dtype=torch.int32, device=device)
 
@@ -48,6 +49,7 @@ class _SoA:
         self.ts, self.y, self.x, self.mp, self.mn = new
         self.bin = nbin
         self.cap = cap
+        self._ref = None
 
     def append(self, ev, pm, pass_idx, ts_override):
         """Pack one pass ([B,N,4], [B,N,2]); shifts ev[:, :, 0] in place by pass_idx."""
@@ -93,6 +95,13 @@ class _SoA:
         return _lib.Events(self.ts.data_ptr(), self.y.data_ptr(), self.x.data_ptr(), self.mp.data_ptr(),
                            self.mn.data_ptr(), self.bin.data_ptr(), self.cls.data_ptr(), self.cap)
 
+    def struct_ref(self):
+        """byref() of a struct kept until the buffers change (update() hands it to the library once per pass)."""
+        if self._ref is None or self._ref[0] != self.cap or self.cap == 0:
+            st = self.struct()
+            self._ref = (self.cap, st, ctypes.byref(st))
+        return self._ref[2]
+
 
 class _Window:
     """Device state of one loss window (everything the kernels read)."""
@@ -105,6 +114,7 @@ class _Window:
         self.det = _SoA(B, device, res, hints[1])
         self.workspace = None
         self.scratch = None
+        self.pass_args = None      # ctypes argument arrays of tef_update_pass, refilled per pass
         self.leases = []          # weak references to the tokens of evaluations whose autograd graph still reads the buffers
         self.cfg = None
 
@@ -300,16 +310,23 @@ class BaseEventWarping(torch.nn.Module):
                 d_ovr = ((d_event_list[:, :, 0].min() + float(t)) + 0.5).reshape(1).contiguous()
             win.keep = getattr(win, "keep", []) + [ovr, d_ovr]       # alive until the pack kernels have run
         slot0, dslot0 = win.grad.reserve(N), win.det.reserve(Nd)
-        srcs = [f.detach() for f in flow_list]
-        ptrs = (ctypes.c_void_p * F)(*[s_.data_ptr() for s_ in srcs])
-        sb = (ctypes.c_long * F)(*[s_.stride(0) for s_ in srcs])
-        sc = (ctypes.c_long * F)(*[s_.stride(1) for s_ in srcs])
-        g, d = win.grad.struct(), win.det.struct()
-        rc = _lib.lib().tef_update_pass(ptrs, sb, sc, F, B, H, W, win.flows[t].data_ptr(), win.flows_yx[t].data_ptr(),
+        # host time per call matters to a loss-only caller (ten calls per window, the kernel takes ~15 us): the argument
+        # arrays and the two event-store structs are kept per window and refilled, no view tensors are made
+        args = win.pass_args
+        if args is None or len(args[0]) != F:
+            args = win.pass_args = ((ctypes.c_void_p * F)(), (ctypes.c_long * F)(), (ctypes.c_long * F)())
+        ptrs, sb, sc = args
+        for i, f in enumerate(flow_list):
+            ptrs[i] = f.data_ptr()
+            sb[i] = f.stride(0)
+            sc[i] = f.stride(1)
+        per_pass = F * B * 2 * H * W * 4
+        rc = _lib.lib().tef_update_pass(ptrs, sb, sc, F, B, H, W, win.flows.data_ptr() + t * per_pass,
+                                        win.flows_yx.data_ptr() + t * per_pass,
                                         event_list.data_ptr(), pol_mask.data_ptr(), N, None if ovr is None else ovr.data_ptr(),
                                         d_event_list.data_ptr(), d_pol_mask.data_ptr(), Nd,
-                                        None if d_ovr is None else d_ovr.data_ptr(), t, slot0, dslot0, ctypes.byref(g),
-                                        ctypes.byref(d), _lib.stream_ptr())
+                                        None if d_ovr is None else d_ovr.data_ptr(), t, slot0, dslot0, win.grad.struct_ref(),
+                                        win.det.struct_ref(), _lib.stream_ptr())
         _lib.check(rc, "tef_update_pass")
         win.grad.commit(N)
         win.det.commit(Nd)

@@ -1,7 +1,8 @@
 """tef_pack_events on its own (the AoS -> SoA packing + sort of one pass; reference bookkeeping loss/flow.py:443-476):
 the stored pass is a permutation of the input grouped pos-only | neg-only | general | padding, the class run ends are
 reported, the caller's time stamps are shifted in place (:457-458), the pass is padded to a multiple of 64 slots with
-empty events — for a list short enough for one workgroup per sample and for one that takes the multi-workgroup path."""
+empty events — for lists one workgroup per sample sorts whole (rank from the counting atomic, permutation in LDS) and for one
+long enough to take the multi-workgroup slice scheme."""
 import ctypes
 
 import numpy as np
@@ -15,8 +16,8 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("N", [700, 9001])
-def test_pack_is_a_grouped_sorted_permutation(N):
+@pytest.mark.parametrize("N,skew", [(700, False), (9001, False), (16384, False), (20000, False), (9001, True), (2048, True)])
+def test_pack_is_a_grouped_sorted_permutation(N, skew):
     assert torch.cuda.is_available()
     import __graft_entry__ as g
 
@@ -29,6 +30,10 @@ def test_pack_is_a_grouped_sorted_permutation(N):
     rng = np.random.default_rng(N)
     ev = np.stack([np.sort(rng.random((B, N)), axis=1), rng.integers(0, H, (B, N)), rng.integers(0, W, (B, N)),
                    rng.choice([-1.0, 1.0], (B, N))], axis=2).astype(np.float32)
+    if skew:      # nearly every event on one pixel row of one tile: one workgroup's slot range holds the list (several staging rounds)
+        ev[:, 7:, 1] = 77.0
+        ev[:, 7:, 2] = rng.integers(32, 48, (B, N - 7)).astype(np.float32)
+        ev[:, 7:, 3] = 1.0
     pm = np.stack([ev[..., 3] > 0, ev[..., 3] < 0], axis=2).astype(np.float32)
     pm[:, ::97] = 1.0                      # some events carry both polarities (general class)
     pm[:, 5::211] = 0.0                    # collate padding
