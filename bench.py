@@ -241,6 +241,7 @@ def main():
     # ---- stage `windows` distinct loss windows (untimed): synthetic inputs -> HBM -> update() -----------------
     staged, host_windows = [], []
     t_updates = []
+    t_updates_deferred = []
     for wi in range(a.windows):
         rng = np.random.default_rng(1000 * rank + wi)
         win = synth.make_window(rng, B, H, W, P, F, a.events, a.detached, sigma=2.0, kind=a.flow)
@@ -275,8 +276,30 @@ def main():
         torch.cuda.synchronize()
         t_updates.append((time.perf_counter() - t0, 1e-3 * e0.elapsed_time(e1)))
         staged.append((L, flows))
+        # the same window through a deferred update(): P recorded passes + ONE tef_update_window launch (the module's
+        # `defer_update`; copies of the lists, the time stamps of the originals are already shifted)
+        L2 = cls(cfg, dev)
+        L2.defer_update = True
+        for rep in range(2):
+            copies = [[x_.clone() for x_ in evs[t]] for t in range(P)]
+            for c_ in copies:
+                c_[0][:, :, 0] -= 0.0      # (touch: the clone kernels have run before the clock starts)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            for t in range(P):
+                L2.update(flows[t], *copies[t])
+            t_rec = time.perf_counter() - t0
+            L2._flush_updates()
+            t_flush = time.perf_counter() - t0 - t_rec
+            e1.record()
+            torch.cuda.synchronize()
+            t_def = (time.perf_counter() - t0, 1e-3 * e0.elapsed_time(e1), t_rec, t_flush)
+            L2.reset()
+        t_updates_deferred.append(t_def)
     # the first window also pays for one-time costs (code-object load, first allocations): report a warm one
     t_update, t_update_dev = min(t_updates)
+    t_update_def, t_update_def_dev, t_update_def_rec, t_update_def_flush = min(t_updates_deferred)
 
     def step(k):
         # loss forward + backward w.r.t. the F*P flow tensors; autograd.grad hands the gradient
@@ -610,6 +633,11 @@ def main():
             # update() (AoS -> SoA packing + sort of the P passes) is outside the timed region as SURVEY.md section 8d
             # defines the metric; this is the rate with its wall time added to every step
             "value_including_update": round(events_per_step * world / (elapsed / a.steps + t_update), 1),
+            # update() deferred to the evaluation: P recorded passes + one tef_update_window launch per window
+            "ms_deferred_update_per_window": round(1e3 * t_update_def, 3),
+            "ms_deferred_update_per_window_device": round(1e3 * t_update_def_dev, 3),
+            "ms_deferred_update_host": {"record_P_passes": round(1e3 * t_update_def_rec, 3), "flush_call": round(1e3 * t_update_def_flush, 3)},
+            "value_including_deferred_update": round(events_per_step * world / (elapsed / a.steps + t_update_def), 1),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 4),
             "allocator_events_in_timed_region": alloc_delta,
             "launch_probe": probe,

@@ -122,6 +122,27 @@ int tef_update_pass(const float *const *flows, const long *stride_b, const long 
                     const float *dpm, int Nd, const float *dts_override, int pass_idx, int slot0, int dslot0,
                     const tef_events *grad, const tef_events *det, void *stream);
 
+/* One pass of a window for tef_update_window: the per-pass arguments of tef_update_pass as a record (HOST memory; flows /
+ * stride_b / stride_c are host arrays of F entries). */
+typedef struct tef_update_desc {
+    const float *const *flows;
+    const long *stride_b, *stride_c;
+    float *ev;
+    const float *pm;
+    const float *ts_override;
+    float *dev;
+    const float *dpm;
+    const float *dts_override;
+    int N, Nd, pass_idx, slot0, dslot0;
+} tef_update_desc;
+
+/* All the passes of a window (loss/flow.py:443-476 called passes_loss times) in ONE launch per ~20 passes: for a caller
+ * that holds the whole window — a staged window, a loss-only caller, an update() whose work is deferred to the evaluation
+ * (taming_event_flow_amd.loss.flow: `defer_update`).  Same effect as tef_update_pass per record, the in-place time shift
+ * of the callers' event lists included.  planar / yx: slot [0][0] of the window's flow buffers (pass t lands at [t]). */
+int tef_update_window(const tef_update_desc *passes, int npass, int F, int B, int H, int W, float *planar, float *yx,
+                      const tef_events *grad, const tef_events *det, void *stream);
+
 /* Workspace (bytes) needed by tef_loss_forward + tef_loss_backward for this window. */
 size_t tef_loss_workspace_bytes(const tef_loss_cfg *cfg);
 

@@ -25,6 +25,14 @@ class Events(ctypes.Structure):
                 ("cap", ctypes.c_int)]
 
 
+class UpdateDesc(ctypes.Structure):
+    """struct tef_update_desc (include/tef.h)"""
+
+    _fields_ = [("flows", _fp), ("stride_b", _fp), ("stride_c", _fp), ("ev", _fp), ("pm", _fp), ("ts_override", _fp),
+                ("dev", _fp), ("dpm", _fp), ("dts_override", _fp), ("N", ctypes.c_int), ("Nd", ctypes.c_int),
+                ("pass_idx", ctypes.c_int), ("slot0", ctypes.c_int), ("dslot0", ctypes.c_int)]
+
+
 class LossCfg(ctypes.Structure):
     """struct tef_loss_cfg (include/tef.h)"""
 
@@ -96,6 +104,8 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_long), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        _fp, _fp, _fp, _fp, ctypes.c_int, _fp, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_int, ctypes.POINTER(Events), ctypes.POINTER(Events), _fp]),
+    "tef_update_window": (ctypes.c_int, [ctypes.POINTER(UpdateDesc), ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, _fp, _fp, ctypes.POINTER(Events), ctypes.POINTER(Events), _fp]),
     "tef_encode_events": (ctypes.c_int, [_fp, _fp, _fp, _fp, ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _fp]),
     "tef_encode_event_lists": (ctypes.c_int, [_fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,

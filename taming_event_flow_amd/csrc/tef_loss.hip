@@ -2520,6 +2520,64 @@ __global__ __launch_bounds__(kPackThreads) void update_pass_kernel(PackArgs ga, 
     }
 }
 
+// All passes of a window in ONE launch (tef_update_window; blockIdx.z = pass): what a caller that holds the whole window —
+// a loss-only caller, a staged benchmark window, a deferred update() — pays ten launches and ten host calls for otherwise.
+// The per-pass records travel in the kernel arguments: a fixed header, then `npass` records of a PassRec followed by the F
+// (pointer, batch stride, channel stride) triples of the pass's flow maps.
+struct PassRec {
+    float *ev; const float *pm; const float *tso;
+    float *dev; const float *dpm; const float *dtso;
+    int N, Nd, slot0, dslot0, pass_idx, sg, sd, stage_g, stage_d, pad_;
+};
+constexpr int kWindowRecBytes = 3328;
+struct WindowArgs {
+    int npass, F, B, H, W, rec_bytes;
+    SortGeom geo;
+    Events g, d;
+    float *planar;
+    float2 *yx;
+    unsigned char recs[kWindowRecBytes] __attribute__((aligned(8)));
+};
+__global__ __launch_bounds__(kPackThreads) void update_window_kernel(WindowArgs wa)
+{
+    extern __shared__ int cnt[];
+    const int b = blockIdx.x, job = blockIdx.y, z = blockIdx.z;
+    const unsigned char *rp = wa.recs + (size_t)z * wa.rec_bytes;
+    const PassRec &r = *reinterpret_cast<const PassRec *>(rp);
+    const int HW = wa.H * wa.W;
+    auto args = [&](bool det) {
+        const Events &E = det ? wa.d : wa.g;
+        PackArgs a;
+        a.ev = det ? r.dev : r.ev; a.pm = det ? r.dpm : r.pm; a.N = det ? r.Nd : r.N; a.ts_shift = (float)r.pass_idx;
+        a.ts_override = det ? r.dtso : r.tso; a.pass_idx = r.pass_idx; a.slot0 = det ? r.dslot0 : r.slot0; a.cap = E.cap;
+        a.H = wa.H; a.W = wa.W; a.stage = det ? r.stage_d : r.stage_g; a.geo = wa.geo;
+        a.ts = const_cast<float *>(E.ts); a.y = const_cast<float *>(E.y); a.x = const_cast<float *>(E.x);
+        a.mp = const_cast<float *>(E.mp); a.mn = const_cast<float *>(E.mn); a.bin = const_cast<uint8_t *>(E.bin);
+        a.cls = const_cast<int *>(E.cls);
+        return a;
+    };
+    if (job < r.sg) {
+        pack_events_block(args(false), b, job, r.sg, cnt);
+    } else if (job < r.sg + r.sd) {
+        pack_events_block(args(true), b, job - r.sg, r.sd, cnt);
+    } else {
+        const int p = (job - r.sg - r.sd) * kPackThreads + threadIdx.x;
+        if (p >= HW) return;
+        const unsigned char *fp = rp + sizeof(PassRec);
+        float *planar = wa.planar + (size_t)r.pass_idx * wa.F * wa.B * 2 * HW;
+        float2 *yx = wa.yx + (size_t)r.pass_idx * wa.F * wa.B * HW;
+        for (int i = 0; i < wa.F; ++i) {
+            const float *src = *reinterpret_cast<const float *const *>(fp + (size_t)i * 24);
+            const long sb = *reinterpret_cast<const long *>(fp + (size_t)i * 24 + 8), sc = *reinterpret_cast<const long *>(fp + (size_t)i * 24 + 16);
+            const float fx = src[(size_t)b * sb + p], fy = src[(size_t)b * sb + sc + p];
+            float *pl = planar + (size_t)i * wa.B * 2 * HW;
+            pl[((size_t)b * 2) * HW + p] = fx;
+            pl[((size_t)b * 2 + 1) * HW + p] = fy;
+            yx[((size_t)i * wa.B + b) * HW + p] = make_float2(fy, fx);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------------------------
@@ -2682,7 +2740,10 @@ bool ensure_attrs()
     static const hipError_t e3 = e3a != hipSuccess ? e3a : hipFuncSetAttribute((const void *)update_pass_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
                                                      (int)std::max((2 * kMaxSortBins + kPackThreads) * sizeof(int), kPackFastLds));
-    if (e3 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e3);
+    static const hipError_t e3b = hipFuncSetAttribute((const void *)update_window_kernel,
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      (int)std::max((2 * kMaxSortBins + kPackThreads) * sizeof(int), kPackFastLds));
+    if (e3 != hipSuccess || e3b != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e3 != hipSuccess ? e3 : e3b);
     if (e1 != hipSuccess || e2 != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", e1 != hipSuccess ? e1 : e2);
     return true;
 }
@@ -2844,6 +2905,64 @@ int tef_update_pass(const float *const *flows, const long *stride_b, const long 
                                      (float *)det->y, (float *)det->x, (float *)det->mp, (float *)det->mn, (uint8_t *)det->bin,
                                      (int *)det->cls, stream))
             return rc;
+    }
+    return 0;
+}
+
+int tef_update_window(const tef_update_desc *passes, int npass, int F, int B, int H, int W, float *planar, float *yx,
+                      const tef_events *grad, const tef_events *det, void *stream)
+{
+    if (!passes || npass < 1 || !grad || !det || !planar || !yx || F < 1 || F > kMaxHeads || B < 1 || H < 1 || W < 1)
+        return tef::fail("tef_update_window: bad arguments (1..16 heads)"), TEF_ERR_INVALID;
+    if (!ensure_attrs()) return TEF_ERR_LAUNCH;
+    const int rec_bytes = (int)sizeof(PassRec) + 24 * F;
+    const int per_launch = kWindowRecBytes / rec_bytes;
+    const int HW = H * W, sf = (HW + kPackThreads - 1) / kPackThreads;
+    hipStream_t st = (hipStream_t)stream;
+    for (int p0 = 0; p0 < npass; p0 += per_launch) {
+        WindowArgs wa{};
+        wa.npass = std::min(per_launch, npass - p0); wa.F = F; wa.B = B; wa.H = H; wa.W = W; wa.rec_bytes = rec_bytes;
+        wa.g = to_events(grad); wa.d = to_events(det);
+        wa.planar = planar; wa.yx = (float2 *)yx;
+        size_t lds = 0;
+        int jobs = 0;
+        for (int q = 0; q < wa.npass; ++q) {
+            const tef_update_desc &u = passes[p0 + q];
+            if (!u.flows || !u.stride_b || !u.stride_c || u.N < 0 || u.Nd < 0 || (u.N > 0 && (!u.ev || !u.pm)) || (u.Nd > 0 && (!u.dev || !u.dpm)))
+                return tef::fail("tef_update_window: null pointer in a pass record"), TEF_ERR_INVALID;
+            PassRec r{};
+            PackArgs ga{}, da{};
+            size_t lg = 0, ld = 0;
+            int sg = 0, sd = 0;
+            if (u.N > 0 && !pack_job(u.ev, u.pm, B, u.N, (float)u.pass_idx, u.ts_override, u.pass_idx, u.slot0, grad->cap, H, W,
+                                     (float *)grad->ts, (float *)grad->y, (float *)grad->x, (float *)grad->mp, (float *)grad->mn,
+                                     (uint8_t *)grad->bin, (int *)grad->cls, &ga, &lg, &sg))
+                return TEF_ERR_INVALID;
+            if (u.Nd > 0 && !pack_job(u.dev, u.dpm, B, u.Nd, (float)u.pass_idx, u.dts_override, u.pass_idx, u.dslot0, det->cap, H, W,
+                                      (float *)det->ts, (float *)det->y, (float *)det->x, (float *)det->mp, (float *)det->mn,
+                                      (uint8_t *)det->bin, (int *)det->cls, &da, &ld, &sd))
+                return TEF_ERR_INVALID;
+            if (u.pass_idx < 0 || u.pass_idx >= TEF_MAX_PASSES) return tef::fail("tef_update_window: pass index out of range"), TEF_ERR_INVALID;
+            if (u.N > 0) wa.geo = ga.geo; else if (u.Nd > 0) wa.geo = da.geo;      // (a function of H and W only)
+            r.ev = u.ev; r.pm = u.pm; r.tso = u.ts_override; r.dev = u.dev; r.dpm = u.dpm; r.dtso = u.dts_override;
+            r.N = u.N; r.Nd = u.Nd; r.slot0 = u.slot0; r.dslot0 = u.dslot0; r.pass_idx = u.pass_idx; r.sg = sg; r.sd = sd;
+            r.stage_g = ga.stage; r.stage_d = da.stage;
+            unsigned char *rp = wa.recs + (size_t)q * rec_bytes;
+            memcpy(rp, &r, sizeof(r));
+            for (int i = 0; i < F; ++i) {
+                if (!u.flows[i]) return tef::fail("tef_update_window: null flow map"), TEF_ERR_INVALID;
+                memcpy(rp + sizeof(PassRec) + (size_t)i * 24, &u.flows[i], 8);
+                memcpy(rp + sizeof(PassRec) + (size_t)i * 24 + 8, &u.stride_b[i], 8);
+                memcpy(rp + sizeof(PassRec) + (size_t)i * 24 + 16, &u.stride_c[i], 8);
+            }
+            lds = std::max(lds, std::max(lg, ld));
+            jobs = std::max(jobs, sg + sd + sf);
+        }
+        {
+            tef::ProfScope ps(tef::PROF_PACK, st);
+            hipLaunchKernelGGL(update_window_kernel, dim3(B, jobs, wa.npass), dim3(kPackThreads), lds, st, wa);
+        }
+        if (int rc = tef::check_launch("update_window_kernel")) return rc;
     }
     return 0;
 }

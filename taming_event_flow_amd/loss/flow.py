@@ -115,6 +115,7 @@ class _Window:
         self.workspace = None
         self.scratch = None
         self.pass_args = None      # ctypes argument arrays of tef_update_pass, refilled per pass
+        self.pending = []          # passes recorded by a deferred update() (BaseEventWarping.defer_update)
         self.leases = []          # weak references to the tokens of evaluations whose autograd graph still reads the buffers
         self.cfg = None
 
@@ -190,6 +191,12 @@ class BaseEventWarping(torch.nn.Module):
         self._passes = 0
         self._num_flows = None
         self._win = None
+        # Not in the reference: update() only records the pass and the whole window is packed in ONE launch when the loss
+        # is evaluated (tef_update_window) — for callers to whom ten launches and ten host calls per window matter (a
+        # loss-only caller; inside a training window update() hides behind the network on a side stream anyway).  The
+        # in-place shift of the callers' time stamps (loss/flow.py:457-458) then happens at the evaluation, and the lists
+        # must not be changed between update() and the evaluation.  Off by default: reference behaviour.
+        self.defer_update = bool(config["loss"].get("defer_update", False))
 
         # timescales for loss computation (loss/flow.py:42-44)
         self.passes_loss = []
@@ -278,15 +285,20 @@ class BaseEventWarping(torch.nn.Module):
         F = len(flow_list)
         H, W = self.res
 
-        def plain(t, last):
-            return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.shape[2] == last and t.is_contiguous()
-                    and t.data_ptr() % 16 == 0)
-
-        fast = (F <= 16 and plain(event_list, 4) and plain(pol_mask, 2) and plain(d_event_list, 4) and plain(d_pol_mask, 2)
-                and event_list.shape[0] == self.batch_size and d_event_list.shape[0] == self.batch_size
-                and pol_mask.shape[:2] == event_list.shape[:2] and d_pol_mask.shape[:2] == d_event_list.shape[:2]
-                and all(f.is_cuda and f.dtype == torch.float32 and tuple(f.shape) == (self.batch_size, 2, H, W)
-                        and f.stride(3) == 1 and f.stride(2) == W for f in flow_list))
+        # (written for few attribute look-ups: this check is a third of the host time of a call)
+        B, f32 = self.batch_size, torch.float32
+        es, ds = event_list.shape, d_event_list.shape
+        fast = F <= 16 and len(es) == 3 and len(ds) == 3
+        if fast:
+            N, Nd = es[1], ds[1]
+            fshape, ftail = (B, 2, H, W), (W, 1)
+            fast = (es == (B, N, 4) and pol_mask.shape == (B, N, 2) and ds == (B, Nd, 4) and d_pol_mask.shape == (B, Nd, 2)
+                    and event_list.dtype is f32 and pol_mask.dtype is f32 and d_event_list.dtype is f32 and d_pol_mask.dtype is f32
+                    and event_list.is_cuda and pol_mask.is_cuda and d_event_list.is_cuda and d_pol_mask.is_cuda
+                    and event_list.is_contiguous() and pol_mask.is_contiguous() and d_event_list.is_contiguous()
+                    and d_pol_mask.is_contiguous()
+                    and not ((event_list.data_ptr() | pol_mask.data_ptr() | d_event_list.data_ptr() | d_pol_mask.data_ptr()) & 15)
+                    and all(f.shape == fshape and f.dtype is f32 and f.is_cuda and f.stride()[2:] == ftail for f in flow_list))
         if not fast or (self._num_flows is not None and F != self._num_flows) or self._passes >= max(self.passes_loss):
             self.update_base(flow_list)          # (also where malformed calls get their error messages)
             self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
@@ -310,6 +322,15 @@ class BaseEventWarping(torch.nn.Module):
                 d_ovr = ((d_event_list[:, :, 0].min() + float(t)) + 0.5).reshape(1).contiguous()
             win.keep = getattr(win, "keep", []) + [ovr, d_ovr]       # alive until the pack kernels have run
         slot0, dslot0 = win.grad.reserve(N), win.det.reserve(Nd)
+        if self.defer_update:
+            # the pass is only recorded (its tensors stay referenced, nothing is launched, the caller's time stamps are not
+            # shifted yet): _flush_updates() hands the whole window to the library in one call when the loss is evaluated
+            win.pending.append((list(flow_list), event_list, pol_mask, d_event_list, d_pol_mask, N, Nd, ovr, d_ovr, t, slot0, dslot0))
+            win.grad.commit(N)
+            win.det.commit(Nd)
+            win.flow_refs.append(list(flow_list))
+            self._passes += 1
+            return
         # host time per call matters to a loss-only caller (ten calls per window, the kernel takes ~15 us): the argument
         # arrays and the two event-store structs are kept per window and refilled, no view tensors are made
         args = win.pass_args
@@ -332,6 +353,35 @@ class BaseEventWarping(torch.nn.Module):
         win.det.commit(Nd)
         win.flow_refs.append(list(flow_list))
         self._passes += 1
+
+    def _flush_updates(self):
+        """Deferred update() calls (`defer_update`): all recorded passes of the window in one tef_update_window call."""
+        win = self._win
+        if win is None or not win.pending:
+            return
+        F, B = self._num_flows, self.batch_size
+        H, W = self.res
+        n = len(win.pending)
+        descs = (_lib.UpdateDesc * n)()
+        keep = []
+        for k, (flows, ev, pm, dev, dpm, N, Nd, ovr, d_ovr, t, slot0, dslot0) in enumerate(win.pending):
+            ptrs = (ctypes.c_void_p * F)(*[f.data_ptr() for f in flows])
+            sb = (ctypes.c_long * F)(*[f.stride(0) for f in flows])
+            sc = (ctypes.c_long * F)(*[f.stride(1) for f in flows])
+            keep += [ptrs, sb, sc]
+            d = descs[k]
+            d.flows = ctypes.cast(ptrs, ctypes.c_void_p)
+            d.stride_b = ctypes.cast(sb, ctypes.c_void_p)
+            d.stride_c = ctypes.cast(sc, ctypes.c_void_p)
+            d.ev, d.pm = ev.data_ptr(), pm.data_ptr()
+            d.ts_override = None if ovr is None else ovr.data_ptr()
+            d.dev, d.dpm = dev.data_ptr(), dpm.data_ptr()
+            d.dts_override = None if d_ovr is None else d_ovr.data_ptr()
+            d.N, d.Nd, d.pass_idx, d.slot0, d.dslot0 = N, Nd, t, slot0, dslot0
+        rc = _lib.lib().tef_update_window(descs, n, F, B, H, W, win.flows.data_ptr(), win.flows_yx.data_ptr(),
+                                          win.grad.struct_ref(), win.det.struct_ref(), _lib.stream_ptr())
+        _lib.check(rc, "tef_update_window")
+        win.pending = []
 
     def _smooth_weights(self, P):
         ws = -1.0 if self.flow_spat_smooth_weight is None else float(self.flow_spat_smooth_weight)
@@ -362,6 +412,7 @@ class BaseEventWarping(torch.nn.Module):
         if win is None or self._passes != P:
             raise RuntimeError(f"loss called after {self._passes} update() calls; data.passes_loss={P} are required")
         lib = _lib.lib()
+        self._flush_updates()
         win.cfg = cfg = self._make_cfg()
         nbytes = lib.tef_loss_workspace_bytes(ctypes.byref(cfg))
         if nbytes == 0:

@@ -21,11 +21,12 @@ def make_cfg(meta):
     }
 
 
-def run_hip(kind, cfg, win, dev, grad_scale=None, loss_scaling=True, border_compensation=True):
+def run_hip(kind, cfg, win, dev, grad_scale=None, loss_scaling=True, border_compensation=True, defer=False):
     from taming_event_flow_amd.loss.flow import Iterative, Linear
 
     P, F = len(win["flows"]), len(win["flows"][0])
     L = (Iterative if kind == "Iterative" else Linear)(cfg, dev, loss_scaling=loss_scaling)
+    L.defer_update = defer
     L.border_compensation = border_compensation      # an attribute read at forward time (reference loss/flow.py:671)
     flows = [[torch.tensor(win["flows"][t][i], device=dev, requires_grad=True) for i in range(F)] for t in range(P)]
     evs = []
@@ -247,6 +248,26 @@ def test_bitwise_reproducible(dev):
     for l, g, _ in runs[1:]:
         assert l == runs[0][0]
         assert np.array_equal(g, runs[0][1])
+
+
+@pytest.mark.parametrize("kind,round_ts,P", [("Iterative", False, 6), ("Iterative", True, 6), ("Linear", False, 4), ("Iterative", False, 24)])
+def test_deferred_update_is_the_same_window(kind, round_ts, P, dev):
+    """`defer_update`: update() only records the passes and the evaluation packs the whole window in one launch
+    (tef_update_window; 24 passes take two).  Same loss and gradients, bit for bit (the accumulators are exact, the order of the
+    events inside a sort bin is free), and the callers' time stamps end up shifted in place exactly as by the per-pass calls."""
+    from taming_event_flow_amd import synth
+
+    rng = np.random.default_rng(5)
+    win = synth.make_window(rng, 2, 64, 80, P, 2, 3000, 700, sigma=2.0, ragged=True)
+    meta = dict(H=64, W=80, B=2, P=P, S=1, mode="two", spat=None, temp=None, round_ts=round_ts)
+    l0, g0, ev0 = run_hip(kind, make_cfg(meta), win, dev)
+    l1, g1, ev1 = run_hip(kind, make_cfg(meta), win, dev, defer=True)
+    assert l0 == l1
+    assert np.array_equal(g0, g1)
+    for (a, ad), (b, bd) in zip(ev0, ev1):
+        assert torch.equal(a, b) and torch.equal(ad, bd)
+    t = P // 2
+    assert torch.equal(ev1[t][0][:, :, 0].cpu(), torch.tensor(win["ev"][t][:, :, 0]) + float(t))
 
 
 @pytest.mark.parametrize("kind", ["Iterative", "Linear"])
