@@ -18,8 +18,10 @@ import torch
 
 try:
     from .. import _lib
+    from ..models.lazy import LazyFlow as _LazyFlow, plain_of as _plain_of
 except ImportError:      # drop-in mode: this package's directory itself is on sys.path
     import _lib
+    from models.lazy import LazyFlow as _LazyFlow, plain_of as _plain_of
 
 __all__ = ["BaseEventWarping", "Linear", "Iterative"]
 
@@ -191,6 +193,7 @@ class BaseEventWarping(torch.nn.Module):
         self._passes = 0
         self._num_flows = None
         self._win = None
+        self._side = None       # the stream update() ran on when it was handed flows that live on the network's side stream
         # Not in the reference: update() only records the pass and the whole window is packed in ONE launch when the loss
         # is evaluated (tef_update_window) — for callers to whom ten launches and ten host calls per window matter (a
         # loss-only caller; inside a training window update() hides behind the network on a side stream anyway).  The
@@ -255,6 +258,7 @@ class BaseEventWarping(torch.nn.Module):
             self._hints = (max(self._win.grad.n, getattr(self, "_hints", (0, 0))[0]), max(self._win.det.n, getattr(self, "_hints", (0, 0))[1]))
         self._passes = 0
         self._win = None
+        self._side = None
 
     def _update_events(self, event_list, pol_mask, d_event_list, d_pol_mask):
         """Shared tail of Linear.update / Iterative.update (loss/flow.py:246-263, :456-476)."""
@@ -279,6 +283,29 @@ class BaseEventWarping(torch.nn.Module):
         self._passes += 1
 
     def _update_pass(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
+        """update() of one pass.  Flow maps that are still on the network's side stream (models/lazy.py: the literal
+        train_flow.py loop on this package's model) are packed THERE, beside the next pass's encoders; the evaluation of the
+        loss waits for that stream."""
+        side = None
+        if any(type(f) is _LazyFlow for f in flow_list):
+            plains = []
+            for f in flow_list:
+                pl, st = _plain_of(f)
+                plains.append(pl)
+                side = side or st
+            flow_list = plains
+        if side is None:
+            return self._update_pass_here(flow_list, event_list, pol_mask, d_event_list, d_pol_mask)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)               # (the loader's tensors of this pass are produced on the caller's stream)
+        for t_ in (event_list, pol_mask, d_event_list, d_pol_mask):
+            if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                t_.record_stream(side)       # (the caller may drop them before the side stream has read them)
+        self._side = side
+        with torch.cuda.stream(side):
+            return self._update_pass_here(flow_list, event_list, pol_mask, d_event_list, d_pol_mask)
+
+    def _update_pass_here(self, flow_list, event_list, pol_mask, d_event_list, d_pol_mask):
         """One pass of update(): flow maps + both event lists handed to the library in ONE call (tef_update_pass) when the
         caller's tensors are in the layout the reference's loader produces (contiguous fp32); anything else takes the
         call-by-call path, which converts."""
@@ -412,6 +439,8 @@ class BaseEventWarping(torch.nn.Module):
         if win is None or self._passes != P:
             raise RuntimeError(f"loss called after {self._passes} update() calls; data.passes_loss={P} are required")
         lib = _lib.lib()
+        if self._side is not None:           # update() ran on the network's side stream (LazyFlow inputs)
+            torch.cuda.current_stream().wait_stream(self._side)
         self._flush_updates()
         win.cfg = cfg = self._make_cfg()
         nbytes = lib.tef_loss_workspace_bytes(ctypes.byref(cfg))

@@ -159,6 +159,13 @@ class MultiResUNetRecurrent(nn.Module):
                 import torch
 
                 eng.wgrad_stream, eng.wgrad_group = torch.cuda.Stream(device=params[0].device), group
+            # ... and the decoder half of a pass runs on a side stream beside the next pass's encoders, its flows handed out
+            # as LazyFlow tensors (models/lazy.py: scaling and the loss container's update() stay on that stream)
+            if os.environ.get("TEF_TWO_STREAMS", "1") != "0" and os.environ.get("TEF_LAZY_FLOWS", "1") != "0" and eng.side_stream is None:
+                import torch
+
+                eng.side_stream = torch.cuda.Stream(device=params[0].device)
+                eng.lazy_flows = True
             return True
         o, fresh = 0, False
         for p in params:

@@ -39,6 +39,7 @@ except ImportError:      # drop-in mode: this package's directory itself is on s
     import _lib
 
 from . import submodules as sm
+from .lazy import LazyFlow
 
 ACT = _lib.ACT
 
@@ -63,6 +64,7 @@ class PassEngine:
         self._ws = {}                 # one workspace per stream the engine launches on
         self.side_stream = None       # set: passes that record a graph run as two nodes on two streams (module docstring)
         self.defer_join = False       # with side_stream: leave the flows on the side stream (the caller joins)
+        self.lazy_flows = False       # with side_stream, without defer_join: hand the flows out as LazyFlow tensors (models/lazy.py)
         self.debug_delay = None       # tests: cycles of spinning put in front of the (encoder halves, decoder halves[, weight-gradient groups])
         # two-stream windows: the deferred weight gradients of every `wgrad_group` finished backward passes are reduced on
         # `wgrad_stream` while BPTT goes on (the encoder chain leaves the side stream idle about half of the time and
@@ -359,6 +361,7 @@ class PassEngine:
     def _end_of_backward(self):
         """arch.auto_grads: what train.Trainer does after loss.backward() — the window's remaining weight gradients, then wait
         for the reductions that ran beside BPTT on the weight-gradient stream."""
+        self.join()          # (pre-activation gradients of the decoder halves were formed on the side stream)
         sm.flush_deferred_wgrads()
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
@@ -508,6 +511,10 @@ def run_pass(engine, x, states):
             if delay[1]:
                 torch.cuda._sleep(int(delay[1]))
             flows = _DecFn.apply(engine, holder[0], len(states), *new_states, *params)
+        if engine.lazy_flows and not engine.defer_join:
+            # the literal train_flow.py loop (no Trainer): the flows stay on the side stream as LazyFlow tensors — scaling
+            # them and the loss container's update() run there, anything else joins first (models/lazy.py)
+            return [LazyFlow.wrap(f, side) for f in flows], list(new_states)
         if not engine.defer_join:
             main.wait_stream(side)
         return list(flows), list(new_states)

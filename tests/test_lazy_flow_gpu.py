@@ -1,0 +1,118 @@
+"""models/lazy.py: the flows of a training pass stay on the network's side stream as LazyFlow tensors when the model is
+driven by the literal train_flow.py loop (no train.Trainer) — scaling and the loss container's update() run on that stream,
+every other consumer sees joined flows."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+
+    g.build()
+    return torch.device("cuda:0")
+
+
+def _model(dev, seed=3):
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    torch.manual_seed(seed)
+    m = RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01}, 2, key="flow").to(dev)
+    m.train()
+    return m
+
+
+def test_unaware_consumers_see_joined_flows(dev):
+    """The side stream is held back by a spinning kernel in front of every decoder half; whatever an unaware caller does with
+    the returned flows — arithmetic, reductions, stacking, copies to the host, attribute reads — gives the values of a model
+    that joins before returning (TEF_LAZY_FLOWS=0 behaviour: engine.lazy_flows off)."""
+    from taming_event_flow_amd.models.lazy import LazyFlow, plain_of
+
+    x = torch.rand(2, 2, 32, 32, device=dev)
+    ref_m, m = _model(dev), _model(dev)
+    for mm in (ref_m, m):
+        mm.reset_states()
+        mm.arch.own_gradients()
+    ref_m.arch.engine.lazy_flows = False
+    ref = [f.detach().clone() for f in ref_m(x)["flow"]]
+    torch.cuda.synchronize()
+    m.arch.engine.debug_delay = (0, 40_000_000)          # ~20 ms in front of the decoder half
+    out = m(x)["flow"]
+    assert all(type(f) is LazyFlow for f in out) and m.arch.engine.lazy_flows
+    assert out[0].shape == ref[0].shape and out[0].dtype == torch.float32 and out[0].is_cuda       # attribute reads
+    got_sum = float((out[3] * out[3]).sum().item())                                               # arithmetic + reduction
+    assert abs(got_sum - float((ref[3] * ref[3]).sum().item())) <= 1e-5 * abs(got_sum) + 1e-12
+    stacked = torch.stack([f[:, :, :8, :8] for f in out])                                         # a torch function over a list
+    assert type(stacked) is torch.Tensor
+    assert torch.equal(stacked, torch.stack([f[:, :, :8, :8] for f in ref]))
+    for f, r in zip(out, ref):
+        assert np.array_equal(f.detach().cpu().numpy(), r.cpu().numpy())                           # host copies
+    scaled = out[1] * 32.0                                                                         # stays lazy, right values
+    assert type(scaled) is LazyFlow
+    assert torch.equal(scaled + 0.0, ref[1] * 32.0)
+    assert type(32 * out[2]) is LazyFlow and type(out[2].mul(2.0)) is LazyFlow
+    assert type(out[2] * torch.ones((), device=dev)) is torch.Tensor                               # tensor factor: joined
+    pl, side = plain_of(out[0])
+    assert type(pl) is torch.Tensor and side is m.arch.engine.side_stream
+
+
+def test_lazy_loop_matches_joined_loop(dev):
+    """Two windows of the literal loop (model, * flow_scaling, loss.update, loss, backward, clip, Adam, zero_grad) with lazy
+    flows and either stream held back, against the same loop on a model that joins before returning: same losses, same
+    parameters up to what Adam makes of the summation-order noise of the weight-gradient atomics."""
+    from taming_event_flow_amd import synth
+    from taming_event_flow_amd.dataloader import encodings
+    from taming_event_flow_amd.loss.flow import Iterative
+
+    B, H, W, P, N = 2, 32, 32, 3, 600
+    cfg = {"data": {"passes_loss": P, "scales_loss": 1}, "loader": {"batch_size": B, "resolution": [H, W]},
+           "loss": {"iterative_mode": "two", "round_ts": False, "flow_scaling": 32, "flow_spat_smooth_weight": None,
+                    "flow_temp_smooth_weight": None}}
+    rng = np.random.default_rng(11)
+    wins = [synth.make_window(rng, B, H, W, P, 1, N, 100, sigma=1.0) for _ in range(2)]
+
+    def run(lazy, delay):
+        m = _model(dev, seed=9)
+        m.reset_states()
+        L = Iterative(cfg, dev)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        opt.zero_grad()
+        losses = []
+        for win in wins:
+            for t in range(P):
+                ev, pm = torch.tensor(win["ev"][t], device=dev), torch.tensor(win["pm"][t], device=dev)
+                dv, dpm = torch.tensor(win["dev"][t], device=dev), torch.tensor(win["dpm"][t], device=dev)
+                inp = encodings.event_list_to_channels(torch.cat([ev, dv], 1), (H, W))
+                if t == 0 and not losses:
+                    m.arch.own_gradients()
+                    m.arch.engine.lazy_flows = lazy
+                    m.arch.engine.debug_delay = delay
+                x = m(inp)
+                for i in range(len(x["flow"])):
+                    x["flow"][i] = x["flow"][i] * cfg["loss"]["flow_scaling"]
+                L.update(x["flow"], ev, pm, dv, dpm)
+                del ev, pm, dv, dpm, inp                      # (the caller drops its tensors right away)
+            loss = L()
+            losses.append(loss.item())
+            loss.backward()
+            torch.nn.utils.clip_grad.clip_grad_norm_(m.parameters(), 100.0)
+            opt.step()
+            opt.zero_grad()
+            m.detach_states()
+            L.reset()
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in m.parameters()]
+
+    l0, p0 = run(False, None)
+    for delay in ((0, 20_000_000), (20_000_000, 0)):
+        l1, p1 = run(True, delay)
+        assert l1[0] == l0[0], (l0, l1)
+        assert abs(l1[1] - l0[1]) <= 1e-4 * abs(l0[1]), (l0, l1)
+        for a, b in zip(p0, p1):           # (Adam: an element whose gradient is summation noise moves by +-lr per step either way)
+            assert (a - b).abs().max().item() <= 2 * 2 * 1e-4 + 1e-5

@@ -297,5 +297,6 @@ def test_literal_dropin_loop_reproduces_the_reference_trace(dev, trace):
         assert abs(gn - float(z[f"gnorm{win}"])) <= gtol * float(z[f"gnorm{win}"]), (win, gn)
         ref = z[f"delta{win}"]
         assert np.abs(delta - ref).max() <= 5e-2 * ref.max(), win
+    assert model.arch.engine.lazy_flows          # (the flows stayed on the side stream: models/lazy.py)
     # the caller's set_to_none really is honoured between windows, and the pass stayed on its fast path
     assert model.arch._bucket is not None and model.arch.direct_grads and model.arch.deferred_wgrad

@@ -1,11 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/c4
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/c4/pytest.log 2>&1; tail -5 gpurun_out/c4/pytest.log
-timeout 600 python bench.py > gpurun_out/c4/bench.json 2> gpurun_out/c4/bench.err
-tail -3 gpurun_out/c4/bench.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/c4/bench.json'))
-for k in ('value','ms_per_step','ms_update_per_window','ms_update_per_window_device','value_including_update','ms_deferred_update_per_window','ms_deferred_update_host','value_including_deferred_update'): print(k, d[k])
-print(d['extra'])
-PY
+mkdir -p gpurun_out/c5
+timeout 1200 python -m pytest tests/test_lazy_flow_gpu.py tests/test_train_resume_gpu.py tests/test_train_gpu.py tests/test_model_api.py -m gpu -x -q > gpurun_out/c5/pytest.log 2>&1; tail -5 gpurun_out/c5/pytest.log
+for i in 1 2; do
+TEF_LAZY_FLOWS=0 timeout 600 python bench.py --mode dropin --steps 5 2>/dev/null | cut -c150-200
+timeout 600 python bench.py --mode dropin --steps 5 2>/dev/null | cut -c150-200
+done
