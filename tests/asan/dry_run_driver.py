@@ -145,6 +145,40 @@ for kind, S, P in (("Iterative", 1, 4), ("Iterative", 2, 8), ("Linear", 1, 4), (
     L.reset()
 print("ok: loss modules", flush=True)
 
+# the one-call forms of update() straight through the C ABI (the Python fast path wants device tensors): one pass
+# (tef_update_pass) and a whole window with the most heads and passes the records can describe (tef_update_window: the
+# records travel in the kernel arguments, several launches)
+import ctypes  # noqa: E402
+
+for F, P, N, Nd in ((2, 6, 500, 120), (16, 64, 70, 0), (1, 3, 0, 40), (4, 10, 20000, 5000)):
+    B, H, W = 2, 24, 28
+    flows = [[torch.zeros(B, 2, H, W) for _ in range(F)] for _ in range(P)]
+    planar, yx = torch.zeros(P, F, B, 2, H, W), torch.zeros(P, F, B, H, W, 2)
+    g, d = loss_flow._SoA(B, dev, (H, W)), loss_flow._SoA(B, dev, (H, W))
+    evs = [(torch.rand(B, N, 4), torch.ones(B, N, 2), torch.rand(B, Nd, 4), torch.ones(B, Nd, 2)) for _ in range(P)]
+    descs = (_lib.UpdateDesc * P)()
+    keep = []
+    for t in range(P):
+        slot0, dslot0 = g.reserve(N), d.reserve(Nd)
+        ptrs = (ctypes.c_void_p * F)(*[f.data_ptr() for f in flows[t]])
+        sb = (ctypes.c_long * F)(*[f.stride(0) for f in flows[t]])
+        sc = (ctypes.c_long * F)(*[f.stride(1) for f in flows[t]])
+        keep += [ptrs, sb, sc]
+        u = descs[t]
+        u.flows, u.stride_b, u.stride_c = (ctypes.cast(x_, ctypes.c_void_p) for x_ in (ptrs, sb, sc))
+        ev, pm, dv, dpm = evs[t]
+        u.ev, u.pm, u.dev, u.dpm = ev.data_ptr(), pm.data_ptr(), dv.data_ptr(), dpm.data_ptr()
+        u.N, u.Nd, u.pass_idx, u.slot0, u.dslot0 = N, Nd, t, slot0, dslot0
+        g.commit(N)
+        d.commit(Nd)
+    _lib.check(lib.tef_update_window(descs, P, F, B, H, W, planar.data_ptr(), yx.data_ptr(), g.struct_ref(), d.struct_ref(), None),
+               "tef_update_window")
+    t = P - 1
+    _lib.check(lib.tef_update_pass(keep[-3], keep[-2], keep[-1], F, B, H, W, planar[t].data_ptr(), yx[t].data_ptr(),
+                                   evs[t][0].data_ptr(), evs[t][1].data_ptr(), N, None, evs[t][2].data_ptr(), evs[t][3].data_ptr(), Nd,
+                                   None, t, descs[t].slot0, descs[t].dslot0, g.struct_ref(), d.struct_ref(), None), "tef_update_pass")
+print("ok: tef_update_pass / tef_update_window", flush=True)
+
 # encodings + validation metrics (batch 1)
 H, W = 40, 52
 ev, pm = synth.make_event_pass(rng, 1, 3000, H, W)

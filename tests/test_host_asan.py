@@ -32,4 +32,5 @@ def test_host_paths_clean_under_asan_ubsan():
     r = _run()
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "HOST SANITIZER RUN CLEAN" in out, out[-3000:]
+    assert "ok: tef_update_pass / tef_update_window" in out, out[-3000:]
     assert "AddressSanitizer" not in out and "runtime error" not in out, out[-3000:]
