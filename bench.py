@@ -225,7 +225,11 @@ def main():
     if a.mode == "eval":
         return bench_eval(a, torch, dist, dev, rank, world, lib)
     if a.mode == "dropin":
-        out = dropin_extra(a, torch, dev, windows=max(3, min(a.steps, 20)))
+        if os.environ.get("TEF_BENCH_DROPIN_STREAM", "0") == "1":      # (experiment: the caller's stream is not the null stream)
+            with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                out = dropin_extra(a, torch, dev, windows=max(3, min(a.steps, 20)))
+        else:
+            out = dropin_extra(a, torch, dev, windows=max(3, min(a.steps, 20)))
         if rank == 0:
             print(json.dumps({"metric": "ms per training window, literal train_flow.py loop", "unit": "ms", "n_gpus": 1,
                               "higher_is_better": False, "data": "synthetic", "value": out.get("dropin_window_ms"),
@@ -675,7 +679,9 @@ def main():
             with torch.cuda.stream(torch.cuda.default_stream(dev)):      # (where a training loop runs; not the capture stream above)
                 out["extra"] = train_extra(a, torch, dev)
                 if "error" not in out["extra"]:
-                    out["extra"].update(dropin_extra(a, torch, dev))      # the literal train_flow.py loop, no Trainer
+                    out["extra"].update(dropin_extra(a, torch, dev, windows=10))      # the literal train_flow.py loop, no Trainer
+                    # (10 windows: the loop ends with ~17 ms of backward still queued, which 3 timed windows showed as + 5.7 ms each)
+                    out["extra"].update(dropin_fresh_process(a))
         elif dp_extra is not None:
             out["extra"] = dp_extra
         print(json.dumps(out), flush=True)
@@ -1017,6 +1023,25 @@ def train_extra(a, torch, dev):
         return {"error": repr(e)}
 
 
+def dropin_fresh_process(a):
+    """The same loop in a process of its own (`bench.py --mode dropin`), which is where a train_flow.py user runs it.  Inside
+    this process — after the staged loss windows, the graph captures and the Trainer's streams — the loop is 4-5 ms per
+    window slower than in a fresh one, and on one stream (TEF_LAZY_FLOWS=0) a fresh process is 10-18 ms SLOWER than this one
+    (the host side of ~1 600 launches per window depends on what the runtime's queues have seen)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "dropin", "--steps", "6", "--batch", str(a.batch), "--passes",
+           str(a.passes), "--events", str(a.events), "--detached", str(a.detached), "--res", str(a.res[0]), str(a.res[1])]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        e = json.loads(line)["extra"]
+        return {"dropin_fresh_process_window_ms": e.get("dropin_window_ms"), "dropin_fresh_process_host_ms": e.get("dropin_host_ms"),
+                "dropin_fresh_process_windows_timed": e.get("dropin_windows_timed")}
+    except Exception as e:                                    # noqa: BLE001
+        return {"dropin_fresh_process_error": repr(e)}
+
+
 def dropin_extra(a, torch, dev, windows=3):
     """The number a reference user gets by changing three imports: the reference's loop body restated call for call
     (train_flow.py:83-87, :101-137 — model(x), * flow_scaling, loss.update, loss(), .item(), backward, clip_grad_norm_,
@@ -1052,7 +1077,9 @@ def dropin_extra(a, torch, dev, windows=3):
                                      inputs["d_event_list"].to(dev), inputs["d_event_list_pol_mask"].to(dev))
                 if loss_function.num_passes >= cfg["data"]["passes_loss"]:
                     loss = loss_function()
+                    t_i = time.perf_counter()
                     state["loss"] += loss.item()
+                    state["item_s"] = state.get("item_s", 0.0) + time.perf_counter() - t_i
                     loss.backward()
                     if cfg["loss"]["clip_grad"] is not None:
                         torch.nn.utils.clip_grad.clip_grad_norm_(model.parameters(), cfg["loss"]["clip_grad"])
@@ -1066,16 +1093,42 @@ def dropin_extra(a, torch, dev, windows=3):
         window()
         window()
         torch.cuda.synchronize()
+        import gc
+
+        gc_mode = os.environ.get("TEF_BENCH_GC", "on")
+        if gc_mode == "freeze":
+            gc.collect()
+            gc.freeze()
+        elif gc_mode == "off":
+            gc.collect()
+            gc.disable()
+        state["item_s"] = 0.0
+        ms0 = torch.cuda.memory_stats(dev)
         t0 = time.perf_counter()
         for _ in range(windows):
             window()
+        t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
         ms = 1e3 * (time.perf_counter() - t0) / windows
+        if gc_mode == "off":
+            gc.enable()
+        elif gc_mode == "freeze":
+            gc.unfreeze()
         arch = model.arch
         out = {"dropin_workload": "literal train_flow.py loop body (torch.optim.Adam, clip_grad_norm_, zero_grad(set_to_none)), "
                                   "no train.Trainer", "dropin_window_ms": round(ms, 3), "dropin_windows_timed": windows,
                "dropin_in_place_grads": bool(arch._bucket is not None and arch.direct_grads),
-               "dropin_deferred_wgrad": bool(arch.deferred_wgrad), "loss_finite": bool(np.isfinite(state["loss"]))}
+               "dropin_deferred_wgrad": bool(arch.deferred_wgrad), "loss_finite": bool(np.isfinite(state["loss"])),
+               # flows handed out as LazyFlow tensors (models/lazy.py): decoder half, scaling and update() beside the next encoders
+               "dropin_lazy_flows": bool(arch.engine.lazy_flows),
+               # host view of a window: waiting in loss.item() (the GPU is behind) / everything else (enqueueing)
+               "dropin_host_ms": {"in_loss_item": round(1e3 * state["item_s"] / windows, 3),
+                                  "enqueue": round(1e3 * (t_host - state["item_s"]) / windows, 3)},
+               # hipMalloc / hipFree calls of torch's caching allocator inside the timed windows (each one synchronises the device)
+               "dropin_allocator_events": {k: int(torch.cuda.memory_stats(dev).get(k, 0) - ms0.get(k, 0))
+                                           for k in ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")},
+               "dropin_streams": [int(st.cuda_stream) if st is not None else None
+                                  for st in (arch.engine.side_stream, arch.engine.wgrad_stream, torch.cuda.current_stream())]}
         del model, loss_function, optimizer, src, batches
         release_now(torch)
         return out
