@@ -886,7 +886,7 @@ constexpr size_t x3_lds_bytes()
     return sizeof(__bf16) * ((size_t)2 * 2 * ((128 >> LOGW) + 2) * ((1 << LOGW) + 2) * 8 + (size_t)2 * 2 * 3 * 2 * TR * 8);
 }
 
-template <int TR, int LOGW, bool GATED>
+template <int TR, int LOGW, bool GATED, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(GemmArgs g)
 {
     constexpr int W = 1 << LOGW, R = 128 >> LOGW, PW = W + 2, NPIX = (R + 2) * PW;
@@ -904,6 +904,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(GemmArgs g)
     const int col0 = blockIdx.x * 128, img = col0 / HW, y0 = (col0 - img * HW) >> LOGW;
     const int C0 = g.G.C0, Ct = g.G.C0 + g.G.C1;
     const int nch8 = g.lda / HK, nch = (nch8 + 1) >> 1;
+    int c_begin = 0, c_end = nch;                    // chunks of 16 channels this workgroup reduces over
+    if (EPI == EPI_SLAB) {                           // (g.ksplit counts chunks of 8 and is even: the launcher checks)
+        c_begin = blockIdx.z * (g.ksplit >> 1);
+        c_end = min(nch, c_begin + (g.ksplit >> 1));
+        if (c_begin >= c_end) return;
+    }
 
     // ---- patch staging: item = (pixel of the patch, group of 4 channels); scalar loads (coalesced along the pixels), then
     //      4 hi + 4 lo as two 8-byte LDS writes ----
@@ -1042,16 +1048,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(GemmArgs g)
         }
     };
 
-    load_patch(0);
-    load_w(0, 0);
+    load_patch(c_begin);
+    load_w(c_begin, 0);
     store_patch();
     store_w(0);
     __syncthreads();
     int wb = 0;
-    for (int c = 0; c < nch; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
 #pragma unroll
         for (int sub = 0; sub < 3; ++sub) {
-            const bool last = c == nch - 1 && sub == 2;
+            const bool last = c == c_end - 1 && sub == 2;
             const int nc = sub == 2 ? c + 1 : c, ns = sub == 2 ? 0 : sub + 1;
             if (!last) load_w(nc, ns);                       // the next sub-stage's weights in flight under the matrix work
             if (sub == 2 && !last) load_patch(c + 1);
@@ -1076,6 +1082,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(GemmArgs g)
                 const int r = row0 + wr * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (r >= row_end) continue;
                 float v = acc[i][j][e];
+                if (EPI == EPI_SLAB) {               // this slab's partial sums, reduced with the epilogue by splitk_reduce_kernel
+                    g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + col0 + pl] = v;
+                    continue;
+                }
                 if (g.bias) v += g.bias[r];
                 v = apply_act(v, g.act);
                 if (r < g.split) {
@@ -1114,16 +1124,16 @@ inline bool conv_math_x3()
     return on;
 }
 
-template <int TR, int LOGW, bool GATED>
-int launch_x3(const GemmArgs &g, hipStream_t st)
+template <int TR, int LOGW, bool GATED, int EPI>
+int launch_x3(const GemmArgs &g, int z, hipStream_t st)
 {
     constexpr size_t lds = x3_lds_bytes<TR, LOGW>();
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv3x3_x3_kernel<TR, LOGW, GATED>,
+    static const hipError_t attr = hipFuncSetAttribute((const void *)conv3x3_x3_kernel<TR, LOGW, GATED, EPI>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", attr), TEF_ERR_LAUNCH;
     const int rows = (g.row_end ? g.row_end : g.rows) - g.row_off;
-    dim3 grid((g.cols + 127) / 128, (rows + TR - 1) / TR, 1);
-    hipLaunchKernelGGL((conv3x3_x3_kernel<TR, LOGW, GATED>), grid, dim3(256), lds, st, g);
+    dim3 grid((g.cols + 127) / 128, (rows + TR - 1) / TR, EPI == EPI_SLAB ? z : 1);
+    hipLaunchKernelGGL((conv3x3_x3_kernel<TR, LOGW, GATED, EPI>), grid, dim3(256), lds, st, g);
     return tef::check_launch("conv3x3_x3_kernel");
 }
 
@@ -1793,7 +1803,7 @@ inline int halo_logw(const tef_conv_desc *d)
 }
 
 // layers whose packed weights carry bf16 hi / lo copies for conv3x3_x3_kernel (TEF_CONV_MATH=bf16x3)
-inline bool x3_split_copies(const tef_conv_desc *d) { return conv_math_x3() && d->stride == 1 && halo_logw(d) >= 5; }
+inline bool x3_split_copies(const tef_conv_desc *d) { return conv_math_x3() && d->stride == 1 && halo_logw(d) >= 4; }
 
 // Any other 3x3 stride-1 layer whose rows are a multiple of 4 pixels runs on W x (128 / W) rectangles: returns
 // log2(tile width), the widest of 128 / 64 / 32 / 16 / 8 that wastes the least of the image's columns and rows
@@ -1824,13 +1834,16 @@ template <int LOGW, int EPI, bool GATED, bool GEN, bool S2D = false>
 int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
     constexpr int IPT = (LOGW == 3 && !GEN) ? 2 : 1;
-    // opt-in: error-compensated bf16 splits (conv3x3_x3_kernel) for launches of more than 32 rows that are not split over k
+    // opt-in: error-compensated bf16 splits (conv3x3_x3_kernel) for launches of more than 32 rows: whole reductions, or slabs
+    // of an even number of 8-channel chunks (its k-step is 16 channels)
+    constexpr bool X3 = (EPI == EPI_FWD || EPI == EPI_SLAB) && !GEN && !S2D && LOGW >= 4;
     bool x3 = false;
-    if constexpr (EPI == EPI_FWD && !GEN && !S2D && LOGW >= 5) x3 = conv_math_x3() && z == 1 && g.s2d_ct == 0;
+    // (a slab of fewer than four 16-channel k-steps is all prologue: the fp32 kernel keeps those)
+    if constexpr (X3) x3 = conv_math_x3() && g.s2d_ct == 0 && (EPI == EPI_FWD ? z == 1 : ((g.ksplit & 1) == 0 && g.ksplit >= 8));
     auto launch_rows_x3 = [&](const GemmArgs &a) -> int {
-        if constexpr (EPI == EPI_FWD && !GEN && !S2D && LOGW >= 5) {
+        if constexpr (X3) {
             const int rows = (a.row_end ? a.row_end : a.rows) - a.row_off;
-            return rows > 64 ? launch_x3<128, LOGW, GATED>(a, st) : launch_x3<64, LOGW, GATED>(a, st);
+            return rows > 64 ? launch_x3<128, LOGW, GATED, EPI>(a, z, st) : launch_x3<64, LOGW, GATED, EPI>(a, z, st);
         }
         return TEF_ERR_LAUNCH;
     };
@@ -2191,7 +2204,7 @@ int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, 
         hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, rows,
                            row0, d->N, q.Ct, nch, nch2, wp + (size_t)d->N * q.Kp, w2 + (size_t)q.Ct * q.K2p);
         if (int rc = tef::check_launch("pack_halo_kernel")) return rc;
-        if (x3_split_copies(d)) {      // the whole matrices again after every part (small: the layers with >= 32-pixel rows)
+        if (x3_split_copies(d)) {      // the whole matrices again after every part (the layers with >= 16-pixel rows)
             hipStream_t st = (hipStream_t)stream;
             const size_t n1 = (size_t)d->N * ((nch + 1) / 2) * 9 * XC, n2_ = (size_t)q.Ct * ((nch2 + 1) / 2) * 9 * XC;
             float *h1 = wp + (size_t)d->N * q.Kp, *h2 = w2 + (size_t)q.Ct * q.K2p;
@@ -2261,6 +2274,7 @@ int tef_conv_forward_blend(const tef_conv_desc *d, const float *x0, const float 
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
         g.ksplit = (nch + z - 1) / z;
+        if (conv_math_x3()) g.ksplit = (g.ksplit + 1) & ~1;      // (whole 16-channel k-steps per slab for conv3x3_x3_kernel)
         z = (nch + g.ksplit - 1) / g.ksplit;
         if (int rc = launch_halo_s2<EPI_SLAB>(g, logw, z, st)) return rc;
         size_t n = (size_t)d->N * q.M;
@@ -2276,6 +2290,7 @@ int tef_conv_forward_blend(const tef_conv_desc *d, const float *x0, const float 
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
         g.ksplit = (nch + z - 1) / z;
+        if (conv_math_x3()) g.ksplit = (g.ksplit + 1) & ~1;      // (whole 16-channel k-steps per slab for conv3x3_x3_kernel)
         z = (nch + g.ksplit - 1) / g.ksplit;
         if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
         size_t n = (size_t)d->N * q.M;
@@ -2436,6 +2451,7 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
             if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
             g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
             g.ksplit = (nch2 + z - 1) / z;
+            if (conv_math_x3()) g.ksplit = (g.ksplit + 1) & ~1;
             z = (nch2 + g.ksplit - 1) / g.ksplit;
             if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
             size_t n = (size_t)q.Ct * q.Min;
