@@ -682,6 +682,7 @@ def main():
                     out["extra"].update(dropin_extra(a, torch, dev, windows=10))      # the literal train_flow.py loop, no Trainer
                     # (10 windows: the loop ends with ~17 ms of backward still queued, which 3 timed windows showed as + 5.7 ms each)
                     out["extra"].update(dropin_fresh_process(a))
+                    out["extra"].update(train_window_other_math(a))
         elif dp_extra is not None:
             out["extra"] = dp_extra
         print(json.dumps(out), flush=True)
@@ -1021,6 +1022,26 @@ def train_extra(a, torch, dev):
                 "streams": tr_streams}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
+
+
+def train_window_other_math(a):
+    """The captured training window with the EXPERIMENTAL convolution math (TEF_CONV_MATH=bf16x3: forward and input gradients of
+    the 16 ... 128-pixel-row levels on error-compensated bf16 splits, 1e-5 per layer — not the arithmetic `train_window_ms` and
+    the parity statements are made with).  The switch is read once per process: a child process."""
+    import subprocess
+
+    if os.environ.get("TEF_CONV_MATH", "fp32") != "fp32":
+        return {}
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--graph", "--steps", "8", "--warmup", "2", "--batch",
+           str(a.batch), "--passes", str(a.passes), "--events", str(a.events), "--detached", str(a.detached), "--res",
+           str(a.res[0]), str(a.res[1]), "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, TEF_CONV_MATH="bf16x3"))
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"train_window_ms_experimental_bf16x3_convolutions": d.get("ms_per_step"),
+                "train_window_experimental_note": "TEF_CONV_MATH=bf16x3, off by default: 1e-5 per layer, 5e-4 on BPTT gradient norms"}
+    except Exception as e:                                    # noqa: BLE001
+        return {"train_window_experimental_error": repr(e)}
 
 
 def dropin_fresh_process(a):
