@@ -73,6 +73,7 @@ struct GemmArgs {
     // halo kernel: this launch covers rows [row_off, row_end) of the problem (row_end = 0: all of them) — a row count just
     // past a multiple of the tile height is worked as whole large tiles plus one launch of 32-row tiles (launch_halo_w)
     int row_off, row_end;
+    int dgrad;            // this launch is an input gradient (TEF_CONV_MATH=bf16x3_dgrad takes only those)
 };
 
 __device__ __forceinline__ void store_blend(const GemmArgs &g, size_t idx, float v)
@@ -1114,15 +1115,19 @@ __global__ __launch_bounds__(256) void split_halo_weights_kernel(const float *__
     out[n + idx] = (__bf16)(v - (float)h);
 }
 
-// TEF_CONV_MATH=bf16x3 (read once per process)
-inline bool conv_math_x3()
+// TEF_CONV_MATH (read once per process): bf16x3 = forward and input gradients, bf16x3_dgrad = input gradients only (the
+// forward — and with it every activation mask — stays on exact fp32 products)
+inline int conv_math_mode()
 {
-    static const bool on = [] {
+    static const int mode = [] {
         const char *e = getenv("TEF_CONV_MATH");
-        return e && (strcmp(e, "bf16x3") == 0);
+        if (e && strcmp(e, "bf16x3") == 0) return 2;
+        if (e && strcmp(e, "bf16x3_dgrad") == 0) return 1;
+        return 0;
     }();
-    return on;
+    return mode;
 }
+inline bool conv_math_x3() { return conv_math_mode() != 0; }
 
 template <int TR, int LOGW, bool GATED, int EPI>
 int launch_x3(const GemmArgs &g, int z, hipStream_t st)
@@ -1839,7 +1844,8 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
     constexpr bool X3 = (EPI == EPI_FWD || EPI == EPI_SLAB) && !GEN && !S2D && LOGW >= 4;
     bool x3 = false;
     // (a slab of fewer than four 16-channel k-steps is all prologue: the fp32 kernel keeps those)
-    if constexpr (X3) x3 = conv_math_x3() && g.s2d_ct == 0 && (EPI == EPI_FWD ? z == 1 : ((g.ksplit & 1) == 0 && g.ksplit >= 8));
+    if constexpr (X3) x3 = (conv_math_mode() == 2 || (conv_math_mode() == 1 && g.dgrad)) && g.s2d_ct == 0 &&
+                           (EPI == EPI_FWD ? z == 1 : ((g.ksplit & 1) == 0 && g.ksplit >= 8));
     auto launch_rows_x3 = [&](const GemmArgs &a) -> int {
         if constexpr (X3) {
             const int rows = (a.row_end ? a.row_end : a.rows) - a.row_off;
@@ -2447,6 +2453,7 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
         if (int logw = halo_mode(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
+            g.dgrad = 1;
             int z = halo_splits(d, q.Ct, q.Min, nch2);
             if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
             g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;

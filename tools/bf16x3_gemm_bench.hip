@@ -112,6 +112,111 @@ __global__ __launch_bounds__(256) void gemm_bf16x3(const float *__restrict__ A, 
             }
 }
 
+// ---- (2) three-way split (hi + mid + lo = 24 bits), six products: exact-fp32-level products ------------------------------------
+__global__ __launch_bounds__(256) void gemm_bf16x6(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                   int M, int N, int K)
+{
+    __shared__ __attribute__((aligned(16))) __bf16 Ah[2][TM][LDH], Am[2][TM][LDH], Al[2][TM][LDH], Bh[2][TN][LDH], Bm[2][TN][LDH], Bl[2][TN][LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;                 // 2 x 2 wavefronts of 64 x 64
+    const int row0 = blockIdx.y * TM, col0 = blockIdx.x * TN;
+    // staging: 128 rows x 8 float4 per operand = 1024 pieces, 4 per thread
+    float4 ra[4], rb[4];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = tid + p * 256, r = piece >> 3, q = (piece & 7) * 4;
+            ra[p] = *reinterpret_cast<const float4 *>(A + (size_t)(row0 + r) * K + k0 + q);
+            rb[p] = *reinterpret_cast<const float4 *>(B + (size_t)(col0 + r) * K + k0 + q);
+        }
+    };
+    auto split_store = [&](float4 v, __bf16 *hi, __bf16 *mid, __bf16 *lo) {
+        float x[4] = {v.x, v.y, v.z, v.w};
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (__bf16)x[e];
+            const float r1 = x[e] - (float)h[e];
+            m[e] = (__bf16)r1;
+            l[e] = (__bf16)(r1 - (float)m[e]);
+        }
+        *reinterpret_cast<bf16x4 *>(hi) = h;
+        *reinterpret_cast<bf16x4 *>(mid) = m;
+        *reinterpret_cast<bf16x4 *>(lo) = l;
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int piece = tid + p * 256, r = piece >> 3, q = (piece & 7) * 4;
+            split_store(ra[p], &Ah[buf][r][q], &Am[buf][r][q], &Al[buf][r][q]);
+            split_store(rb[p], &Bh[buf][r][q], &Bm[buf][r][q], &Bl[buf][r][q]);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    auto multiply = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 16) {
+            // 32x32x16: lane l holds row (l & 31), k = 8 * (l >> 5) .. + 7 of the 16
+            const int ko = ks + 8 * (lane >> 5);
+            bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wr * 64 + i * 32 + (lane & 31);
+                ah[i] = *reinterpret_cast<const bf16x8 *>(&Ah[buf][r][ko]);
+                am[i] = *reinterpret_cast<const bf16x8 *>(&Am[buf][r][ko]);
+                al[i] = *reinterpret_cast<const bf16x8 *>(&Al[buf][r][ko]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = wc * 64 + j * 32 + (lane & 31);
+                bh[j] = *reinterpret_cast<const bf16x8 *>(&Bh[buf][c][ko]);
+                bm[j] = *reinterpret_cast<const bf16x8 *>(&Bm[buf][c][ko]);
+                bl[j] = *reinterpret_cast<const bf16x8 *>(&Bl[buf][c][ko]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+    load(0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = BK; k0 < K; k0 += BK) {
+        load(k0);
+        multiply(buf);
+        store(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    multiply(buf);
+    // C/D layout of the 32x32 tiles: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = row0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int c = col0 + wc * 64 + j * 32 + (lane & 31);
+                C[(size_t)r * N + c] = acc[i][j][e];
+            }
+}
+
 // ---- (0) fp32 MFMA, same structure ------------------------------------------------------------------------------------------
 constexpr int LDF = BK + 4;
 __global__ __launch_bounds__(256) void gemm_f32(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
@@ -206,13 +311,15 @@ int main(int argc, char **argv)
     auto run = [&](int which, const char *name) {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
         for (int rep = 0; rep < 3; ++rep) {
-            if (which) hipLaunchKernelGGL(gemm_bf16x3, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            if (which == 2) hipLaunchKernelGGL(gemm_bf16x6, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            else if (which) hipLaunchKernelGGL(gemm_bf16x3, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
             else hipLaunchKernelGGL(gemm_f32, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
         }
         hipEventRecord(a);
         const int reps = 20;
         for (int rep = 0; rep < reps; ++rep) {
-            if (which) hipLaunchKernelGGL(gemm_bf16x3, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            if (which == 2) hipLaunchKernelGGL(gemm_bf16x6, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+            else if (which) hipLaunchKernelGGL(gemm_bf16x3, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
             else hipLaunchKernelGGL(gemm_f32, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
         }
         hipEventRecord(b); hipEventSynchronize(b);
@@ -232,5 +339,6 @@ int main(int argc, char **argv)
     printf("M = %d, N = %d, K = %d (%.1f GFLOP)\n", M, N, K, 2.0 * M * N * K / 1e9);
     run(0, "fp32 MFMA 32x32x2");
     run(1, "bf16 x 3 on MFMA 32x32x16");
+    run(2, "bf16 3-way, 6 products");
     return 0;
 }
