@@ -1,8 +1,6 @@
 """models/lazy.py: the flows of a training pass stay on the network's side stream as LazyFlow tensors when the model is
 driven by the literal train_flow.py loop (no train.Trainer) — scaling and the loss container's update() run on that stream,
 every other consumer sees joined flows."""
-import os
-
 import numpy as np
 import pytest
 import torch
