@@ -306,6 +306,14 @@ int tef_upsample_bilinear_crop(const float *x, const float *x2, int planes, int 
 int tef_upsample_bilinear_crop_backward(const float *dy, int planes, int H, int W, int scale_h, int scale_w, float mul,
                                         int crop_top, int crop_left, float *dx, void *stream);
 
+/* The two x2 up-samplings of a decoder level of RecEVFlowNet (models/arch.py:236-238: features + encoder skip, and the
+ * previous prediction; align_corners=False, models/submodules.py:264) and their adjoints as ONE launch each: tensors a and b
+ * share H x W, b has no second addend. */
+int tef_upsample2x_pair(const float *xa, const float *xa2, int planes_a, float *ya, const float *xb, int planes_b, float *yb,
+                        int H, int W, void *stream);
+int tef_upsample2x_pair_backward(const float *dya, int planes_a, float *dxa, const float *dyb, int planes_b, float *dxb, int H,
+                                 int W, void *stream);
+
 /* ---- fused ConvGRU cell: ConvGRU.forward, models/submodules.py:134-152, and its backward -------------------------------
  * x (the cell input) and h (previous state, zeros for a fresh sequence, :141-143) are [B,C,H,W]; gates are 3x3.
  * Forward: (u, r) = sigmoid(conv([x, h]; update | reset weights)), o = tanh(conv([x, h * r]; out weights)),

@@ -148,6 +148,9 @@ SIGNATURES = {
     "tef_upsample_bilinear_crop_backward": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                            ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, _fp,
                                                            _fp]),
+    "tef_upsample2x_pair": (ctypes.c_int, [_fp, _fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int, _fp]),
+    "tef_upsample2x_pair_backward": (ctypes.c_int, [_fp, ctypes.c_int, _fp, _fp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                                    _fp]),
     "tef_convgru_workspace_bytes": (ctypes.c_size_t, [ctypes.POINTER(GruDesc)]),
     "tef_convgru_cell_fwd": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 10 + [_fp, ctypes.c_size_t, _fp]),
     "tef_convgru_cell_bwd": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 5

@@ -296,8 +296,13 @@ int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, c
     for (int k = 0; k < g.lv; ++k) {
         const int lvl = g.lvl[k];
         // features + encoder skip, x2 (arch.py:236 "sum" skip + UpsampleConvLayer's interpolate), previous prediction x2
-        TEF_TRY(tef_upsample_bilinear_crop(cur, tape + t.hn[lvl], g.B * g.src[k], g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upx[k], stream));
-        if (pred) TEF_TRY(tef_upsample_bilinear_crop(pred, nullptr, g.B * p->nout, g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upp[k], stream));
+        if (pred && !(g.w[lvl] & 1))      // both in one launch
+            TEF_TRY(tef_upsample2x_pair(cur, tape + t.hn[lvl], g.B * g.src[k], tape + t.upx[k], pred, g.B * p->nout, tape + t.upp[k], g.h[lvl],
+                                        g.w[lvl], stream));
+        else {
+            TEF_TRY(tef_upsample_bilinear_crop(cur, tape + t.hn[lvl], g.B * g.src[k], g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upx[k], stream));
+            if (pred) TEF_TRY(tef_upsample_bilinear_crop(pred, nullptr, g.B * p->nout, g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upp[k], stream));
+        }
         const float *x0 = pred ? tape + t.upp[k] : tape + t.upx[k], *x1 = pred ? tape + t.upx[k] : nullptr;
         TEF_TRY(tef_conv_forward(&D.dec[k], x0, x1, nullptr, p->dec[k].wp, p->dec[k].bias, tape + t.d[k], ws, ws_bytes, stream));
         TEF_TRY(tef_conv_forward(&D.pred[k], tape + t.d[k], nullptr, nullptr, p->pred[k].wp, p->pred[k].bias, tape + t.p[k], ws, ws_bytes, stream));
@@ -372,12 +377,14 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         TEF_TRY(conv_bwd(D.dec[k], p->dec[k], gtape + q.gd[k], x0, x1, gtape + q.dx0[k], k ? gtape + q.dx1[k] : nullptr, ws, ws_bytes, stream));
         ran |= bit_dec(k);
         const float *dupx = k ? gtape + q.dx1[k] : gtape + q.dx0[k], *dupp = k ? gtape + q.dx0[k] : nullptr;
-        TEF_TRY(tef_upsample_bilinear_crop_backward(dupx, g.B * g.src[k], g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, gtape + q.skip[k], stream));
         skip_grads[k] = d_feat = gtape + q.skip[k];
         d_prev_pred = nullptr;
-        if (dupp) {
-            TEF_TRY(tef_upsample_bilinear_crop_backward(dupp, g.B * p->nout, g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, gtape + q.dprev[k], stream));
+        if (dupp) {       // both adjoints in one launch
+            TEF_TRY(tef_upsample2x_pair_backward(dupx, g.B * g.src[k], gtape + q.skip[k], dupp, g.B * p->nout, gtape + q.dprev[k], g.h[lvl],
+                                                 g.w[lvl], stream));
             d_prev_pred = gtape + q.dprev[k];
+        } else {
+            TEF_TRY(tef_upsample_bilinear_crop_backward(dupx, g.B * g.src[k], g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, gtape + q.skip[k], stream));
         }
     }
     // residual blocks, last first

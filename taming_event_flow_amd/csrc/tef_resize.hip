@@ -50,12 +50,10 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float *__restri
 // sh = sw = 2 without crop, W a multiple of 2 (the decoder levels): one thread per 4 consecutive outputs of a row — they
 // read input columns 2j - 1 .. 2j + 2 of two input rows (8 values instead of 16) and leave as one 16-byte store.  The
 // per-output expression is the one above (same weights from src_index, same order of operations).
-__global__ __launch_bounds__(256) void upsample2x_fwd4_kernel(const float *__restrict__ x, const float *__restrict__ x2,
-                                                              int planes, int H, int W, float mul, float *__restrict__ y)
+__device__ __forceinline__ void upsample2x_fwd4_item(const float *__restrict__ x, const float *__restrict__ x2, size_t idx, int H,
+                                                      int W, float mul, float *__restrict__ y)
 {
     const int Ho = 2 * H, Wo = 2 * W, W4 = Wo >> 2;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)planes * Ho * W4) return;
     const int j = (int)(idx % W4);
     const size_t t = idx / W4;
     const int oy = (int)(t % Ho), pl = (int)(t / Ho);
@@ -89,6 +87,23 @@ __global__ __launch_bounds__(256) void upsample2x_fwd4_kernel(const float *__res
         o[e] = mul * (ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11));
     }
     *reinterpret_cast<float4 *>(y + ((size_t)pl * Ho + oy) * Wo + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__global__ __launch_bounds__(256) void upsample2x_fwd4_kernel(const float *__restrict__ x, const float *__restrict__ x2,
+                                                              int planes, int H, int W, float mul, float *__restrict__ y)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * (2 * H) * (W >> 1)) return;
+    upsample2x_fwd4_item(x, x2, idx, H, W, mul, y);
+}
+// two tensors of one geometry in one launch (a decoder level of RecEVFlowNet: features + skip, and the previous prediction)
+__global__ __launch_bounds__(256) void upsample2x_fwd4_pair_kernel(const float *__restrict__ xa, const float *__restrict__ xa2,
+                                                                   int planes_a, float *__restrict__ ya,
+                                                                   const float *__restrict__ xb, int planes_b,
+                                                                   float *__restrict__ yb, int H, int W)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, na = (size_t)planes_a * (2 * H) * (W >> 1);
+    if (idx < na) upsample2x_fwd4_item(xa, xa2, idx, H, W, 1.0f, ya);
+    else if (idx - na < (size_t)planes_b * (2 * H) * (W >> 1)) upsample2x_fwd4_item(xb, nullptr, idx - na, H, W, 1.0f, yb);
 }
 
 // Exact adjoint, separable: dX = Ry^T dY Rx with the forward's 1-D weights (same expressions as the forward, so the pair
@@ -139,12 +154,10 @@ __global__ __launch_bounds__(128) void upsample_bwd_kernel(const float *__restri
 // neighbourhood — vertical sums first, then the horizontal one, in ascending order: the same additions in the same
 // order as the row kernel above.  (That one launches a 128-thread workgroup per input row: at the deep levels, rows of
 // 8 and 16 pixels, 22 us for 1 - 2 MB.)
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
-                                                             float mul, int ct, int cl, float *__restrict__ dx)
+__device__ __forceinline__ void upsample2x_bwd_item(const float *__restrict__ dy, size_t idx, int H, int W, float mul, int ct, int cl,
+                                                     float *__restrict__ dx)
 {
     const int Ho = 2 * H, Wo = 2 * W, Wc = Wo - cl;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)planes * H * W) return;
     const int ix = (int)(idx % W);
     const size_t t = idx / W;
     const int iy = (int)(t % H), pl = (int)(t / H);
@@ -169,6 +182,21 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__rest
         acc += wx * col;
     }
     dx[idx] = mul * acc;
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float *__restrict__ dy, int planes, int H, int W,
+                                                             float mul, int ct, int cl, float *__restrict__ dx)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)planes * H * W) return;
+    upsample2x_bwd_item(dy, idx, H, W, mul, ct, cl, dx);
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_pair_kernel(const float *__restrict__ dya, int planes_a, float *__restrict__ dxa,
+                                                                  const float *__restrict__ dyb, int planes_b,
+                                                                  float *__restrict__ dxb, int H, int W)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, na = (size_t)planes_a * H * W;
+    if (idx < na) upsample2x_bwd_item(dya, idx, H, W, 1.0f, 0, 0, dxa);
+    else if (idx - na < (size_t)planes_b * H * W) upsample2x_bwd_item(dyb, idx - na, H, W, 1.0f, 0, 0, dxb);
 }
 
 }  // namespace
@@ -210,6 +238,28 @@ int tef_upsample_bilinear_crop_backward(const float *dy, int planes, int H, int 
     hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)((size_t)planes * H)), dim3(128), lds, (hipStream_t)stream, dy,
                        planes, H, W, scale_h, scale_w, mul, crop_top, crop_left, dx);
     return tef::check_launch("upsample_bwd_kernel");
+}
+
+int tef_upsample2x_pair(const float *xa, const float *xa2, int planes_a, float *ya, const float *xb, int planes_b, float *yb,
+                        int H, int W, void *stream)
+{
+    if (!xa || !ya || !xb || !yb || planes_a < 1 || planes_b < 1 || H < 1 || W < 2 || (W & 1))
+        return tef::fail("tef_upsample2x_pair: bad arguments (even width)"), TEF_ERR_INVALID;
+    const size_t n4 = (size_t)(planes_a + planes_b) * (2 * H) * (W >> 1);
+    hipLaunchKernelGGL(upsample2x_fwd4_pair_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, xa, xa2,
+                       planes_a, ya, xb, planes_b, yb, H, W);
+    return tef::check_launch("upsample2x_fwd4_pair_kernel");
+}
+
+int tef_upsample2x_pair_backward(const float *dya, int planes_a, float *dxa, const float *dyb, int planes_b, float *dxb, int H,
+                                 int W, void *stream)
+{
+    if (!dya || !dxa || !dyb || !dxb || planes_a < 1 || planes_b < 1 || H < 1 || W < 1)
+        return tef::fail("tef_upsample2x_pair_backward: bad arguments"), TEF_ERR_INVALID;
+    const size_t n = (size_t)(planes_a + planes_b) * H * W;
+    hipLaunchKernelGGL(upsample2x_bwd_pair_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dya,
+                       planes_a, dxa, dyb, planes_b, dxb, H, W);
+    return tef::check_launch("upsample2x_bwd_pair_kernel");
 }
 
 int tef_upsample_bilinear(const float *x, int planes, int H, int W, int scale_h, int scale_w, float mul, float *y,
