@@ -648,7 +648,10 @@ def main():
             # the eager launch path (what a drop-in caller of the loss module runs: Python + ctypes + 7 launches per step)
             "eager_ms": eager_probe,
             "kernel_event_steps": nprof,        # the last steps of the timed region, launched eagerly
-            "roofline": roofline,
+            # (round 6) `roofline` is SURVEY.md section 8d's headline: the WHOLE loss step on its compulsory bytes — filled in
+            # below; the kernel with the largest share of the step keeps its own line as `roofline_dominant_kernel`
+            "roofline": None,
+            "roofline_dominant_kernel": roofline,
             "kernels": kernels,
         }
         if "iwe_splat" in kernels and "GBps" in kernels["iwe_splat"]:
@@ -657,9 +660,16 @@ def main():
                 "unit": "GB/s", "frac": round(kernels["iwe_splat"]["GBps"] / HBM_PEAK_GBS, 4),
                 "traffic": traffic.get("iwe_splat"),
                 "splats_per_launch": splats,
-                "note": "kernel = IWE scatter fused with the image statistics; with its (A, R) write-out (8 B x 2 polarities "
-                        "x H x W per image) counted as well: %.1f GB/s" % (
-                            (alg["iwe_splat"] + (P + 1) * F * B * 2 * H * W * 8) / (kernels["iwe_splat"]["ms"] * 1e-3) / 1e9)}
+                "note": "kernel = IWE scatter fused with the image statistics; SURVEY.md section 8d's 16 B per event-splat "
+                        "(position 8 + time stamp 4 + flags 4); roofline_scatter_all_in also counts the (A, C + eps) write-out"}
+            # the same launch with the write-out of the materialised (A, C + eps) planes counted (8 B x 2 polarities x H x W per
+            # image: SURVEY.md section 8d's ~19.6 B per splat "all-in" reading)
+            all_in = alg["iwe_splat"] + (P + 1) * F * B * 2 * H * W * 8
+            gb = all_in / (kernels["iwe_splat"]["ms"] * 1e-3) / 1e9
+            out["roofline_scatter_all_in"] = {
+                "kernel": "iwe_splat", "bound": "hbm", "achieved": round(gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gb / HBM_PEAK_GBS, 4), "traffic": traffic.get("iwe_splat"),
+                "bytes_per_splat": round(all_in / max(1, splats), 2)}
         # whole loss against the HBM roofline by SURVEY.md section 8d's compulsory traffic: events and masks read once per
         # direction, flow maps read twice and their gradients written once, everything else on chip
         bpe = 48.0 + 24.0 * F * H * W / max(1, a.events + a.detached)
@@ -671,6 +681,11 @@ def main():
             whole["hbm_bytes_per_step_pmc"] = int(moved)
             whole["pmc_over_compulsory"] = round(moved / (bpe * events_per_step), 2)
         out["roofline_whole_loss"] = whole
+        out["roofline"] = {"kernel": "whole loss step (K1 warp, K2 scatter + statistics, count, reduce, K6 chain backward, K7 "
+                                     "flow-gradient scatter) on SURVEY.md section 8d's compulsory bytes",
+                           "bound": "hbm", "achieved": whole["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": whole["frac"], "traffic": whole.get("hbm_bytes_per_step_pmc"),
+                           "bytes_per_event": whole["bytes_per_event"]}
         if not a.no_cpu_baseline and a.warping == "Iterative" and world == 1:     # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a, host_windows[0])
             out["cpu_baseline_1thread"] = cpu_baseline(a, host_windows[0], threads=1, seconds=min(a.cpu_seconds, 6.0), batch=2)
@@ -682,7 +697,6 @@ def main():
                     out["extra"].update(dropin_extra(a, torch, dev, windows=10))      # the literal train_flow.py loop, no Trainer
                     # (10 windows: the loop ends with ~17 ms of backward still queued, which 3 timed windows showed as + 5.7 ms each)
                     out["extra"].update(dropin_fresh_process(a))
-                    out["extra"].update(train_window_other_math(a))
         elif dp_extra is not None:
             out["extra"] = dp_extra
         print(json.dumps(out), flush=True)
@@ -1022,26 +1036,6 @@ def train_extra(a, torch, dev):
                 "streams": tr_streams}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
-
-
-def train_window_other_math(a):
-    """The captured training window with the EXPERIMENTAL convolution math (TEF_CONV_MATH=bf16x3: forward and input gradients of
-    the 16 ... 128-pixel-row levels on error-compensated bf16 splits, 1e-5 per layer — not the arithmetic `train_window_ms` and
-    the parity statements are made with).  The switch is read once per process: a child process."""
-    import subprocess
-
-    if os.environ.get("TEF_CONV_MATH", "fp32") != "fp32":
-        return {}
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "train", "--graph", "--steps", "8", "--warmup", "2", "--batch",
-           str(a.batch), "--passes", str(a.passes), "--events", str(a.events), "--detached", str(a.detached), "--res",
-           str(a.res[0]), str(a.res[1]), "--no-cpu-baseline"]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, TEF_CONV_MATH="bf16x3"))
-        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-        return {"train_window_ms_experimental_bf16x3_convolutions": d.get("ms_per_step"),
-                "train_window_experimental_note": "TEF_CONV_MATH=bf16x3, off by default: 1e-5 per layer, 5e-4 on BPTT gradient norms"}
-    except Exception as e:                                    # noqa: BLE001
-        return {"train_window_experimental_error": repr(e)}
 
 
 def dropin_fresh_process(a):

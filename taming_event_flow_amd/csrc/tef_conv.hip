@@ -73,7 +73,6 @@ struct GemmArgs {
     // halo kernel: this launch covers rows [row_off, row_end) of the problem (row_end = 0: all of them) — a row count just
     // past a multiple of the tile height is worked as whole large tiles plus one launch of 32-row tiles (launch_halo_w)
     int row_off, row_end;
-    int dgrad;            // this launch is an input gradient (TEF_CONV_MATH=bf16x3_dgrad takes only those)
 };
 
 __device__ __forceinline__ void store_blend(const GemmArgs &g, size_t idx, float v)
@@ -864,285 +863,6 @@ __global__ __launch_bounds__(NT) void conv3x3_halo_kernel(GemmArgs g)
 }
 
 // =====================================================================================================================
-// The same contraction on ERROR-COMPENSATED bf16 SPLITS (opt-in: TEF_CONV_MATH=bf16x3; round 5, tools/bf16x3_conv_proto.hip).
-//   x = hi + lo, hi = bf16(x), lo = bf16(x - hi);   out += w_lo x_hi + w_hi x_lo + w_hi x_hi   on v_mfma_f32_32x32x16_bf16
-// (16x the fp32 MFMA rate; the dropped lo * lo term is 2^-16 of a product: 3e-6 of the largest output on the first ConvGRU's
-// gate convolution, where the fp32 MFMA kernel itself is at 1e-6 of a float64 sum — far inside the 1e-4 bar, but not the
-// exact-fp32 arithmetic the parity claims of this package rest on: hence a switch, off by default).
-// Forward and input gradient of the whole-row geometries with 32 / 64 / 128-pixel rows (EPI_FWD, one slab), the operands of
-// the halo kernel above: the SAME packed fp32 weights ([row][chunk of 8 channels][tap][8]; split when they are staged — a
-// k-step is one tap x 16 channels = two neighbouring chunks), the same two-source / gated gather, the same epilogue.
-//   Workgroup: TR (128 | 64) rows x 128 pixels, four wavefronts of (TR / 2) x 64; LDS: patch [hi|lo][channel half][(R + 2) x
-//   (W + 2) pixels][8 channels] (a lane's eight channels are one 16-byte read, consecutive lanes consecutive pixels), weights
-//   of three taps [hi|lo][tap][channel half][TR rows][8], double buffered; the next sub-stage's weights and the next chunk's
-//   patch are in flight under the matrix work.
-// =====================================================================================================================
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
-constexpr int XC = 16;           // channels per k-step
-
-template <int TR, int LOGW>
-constexpr size_t x3_lds_bytes()
-{
-    return sizeof(__bf16) * ((size_t)2 * 2 * ((128 >> LOGW) + 2) * ((1 << LOGW) + 2) * 8 + (size_t)2 * 2 * 3 * 2 * TR * 8);
-}
-
-template <int TR, int LOGW, bool GATED, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_x3_kernel(GemmArgs g)
-{
-    constexpr int W = 1 << LOGW, R = 128 >> LOGW, PW = W + 2, NPIX = (R + 2) * PW;
-    constexpr int MR = TR / 64;                      // 32-row MFMA tiles per wavefront (its tile: MR * 32 rows x 64 pixels)
-    extern __shared__ __attribute__((aligned(16))) unsigned char x3_lds[];
-    typedef __bf16 (*PatchT)[2][NPIX][8];
-    typedef __bf16 (*WeightT)[2][3][2][TR][8];
-    PatchT P = reinterpret_cast<PatchT>(x3_lds);
-    WeightT Ws = reinterpret_cast<WeightT>(x3_lds + sizeof(__bf16) * 2 * 2 * NPIX * 8);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5;
-    const int row0 = blockIdx.y * TR + g.row_off;
-    const int row_end = g.row_end ? g.row_end : g.rows;
-    const int H = g.G.SH, HW = H * W;
-    const int col0 = blockIdx.x * 128, img = col0 / HW, y0 = (col0 - img * HW) >> LOGW;
-    const int C0 = g.G.C0, Ct = g.G.C0 + g.G.C1;
-    const int nch8 = g.lda / HK, nch = (nch8 + 1) >> 1;
-    int c_begin = 0, c_end = nch;                    // chunks of 16 channels this workgroup reduces over
-    if (EPI == EPI_SLAB) {                           // (g.ksplit counts chunks of 8 and is even: the launcher checks)
-        c_begin = blockIdx.z * (g.ksplit >> 1);
-        c_end = min(nch, c_begin + (g.ksplit >> 1));
-        if (c_begin >= c_end) return;
-    }
-
-    // ---- patch staging: item = (pixel of the patch, group of 4 channels); scalar loads (coalesced along the pixels), then
-    //      4 hi + 4 lo as two 8-byte LDS writes ----
-    constexpr int PITEMS = NPIX * 4, PPT = (PITEMS + 255) / 256;
-    float pv[PPT][4];
-    // what does not depend on the chunk: the item's offset inside a channel plane (-1: outside the image / no item) and its
-    // first channel inside the chunk
-    int poff[PPT];
-#pragma unroll
-    for (int p = 0; p < PPT; ++p) {
-        const int item = tid + p * 256, it = min(item, PITEMS - 1), pix = it % NPIX;
-        const int pr = pix / PW, px = pix - pr * PW, yy = y0 - 1 + pr, xx = px - 1;
-        poff[p] = (item < PITEMS && yy >= 0 && yy < H && xx >= 0 && xx < W) ? yy * W + xx : -1;
-    }
-    // chunks that lie inside ONE source (both channel counts multiples of 16: every layer but the decoders, whose first source
-    // is the 2-channel prediction) take their base pointer as a scalar
-    const bool aligned = (C0 % XC) == 0 && (g.G.C1 % XC) == 0;
-    auto load_patch = [&](int chunk) {
-        if (aligned) {
-            const int c0 = chunk * XC;
-            const bool second = c0 >= C0, any = c0 < Ct;
-            const float *src = (second ? g.G.src1 + ((size_t)img * g.G.C1 + (c0 - C0)) * HW : g.G.src0 + ((size_t)img * C0 + c0) * HW);
-            const float *gt = GATED && second ? g.G.gate1 + ((size_t)img * g.G.C1 + (c0 - C0)) * HW : nullptr;
-#pragma unroll
-            for (int p = 0; p < PPT; ++p) {
-                const int cg = min(tid + p * 256, PITEMS - 1) / NPIX;
-                const bool ok = any && poff[p] >= 0;
-                const uint32_t o = ok ? (uint32_t)(cg * 4) * (uint32_t)HW + (uint32_t)poff[p] : 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = any ? src[o + (uint32_t)j * (uint32_t)HW * (ok ? 1u : 0u)] : 0.0f;
-                    if (GATED && gt) v *= gt[o + (uint32_t)j * (uint32_t)HW * (ok ? 1u : 0u)];
-                    pv[p][j] = ok ? v : 0.0f;
-                }
-            }
-            return;
-        }
-#pragma unroll
-        for (int p = 0; p < PPT; ++p) {
-            const int cg = min(tid + p * 256, PITEMS - 1) / NPIX;
-            const bool in = poff[p] >= 0;
-            const int off = in ? poff[p] : 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = chunk * XC + cg * 4 + j;
-                const bool ok = in && c < Ct, second = ok && c >= C0;
-                const float *src = second ? g.G.src1 : g.G.src0;
-                const int cs = second ? g.G.C1 : C0, cl = second ? c - C0 : c;
-                const size_t o = ok ? ((size_t)img * cs + cl) * HW + off : 0;
-                float v = src[o];
-                if (GATED) {
-                    const float q = g.G.gate1[second ? o : 0];
-                    v = second ? v * q : v;
-                }
-                pv[p][j] = ok ? v : 0.0f;
-            }
-        }
-    };
-    auto store_patch = [&]() {
-#pragma unroll
-        for (int p = 0; p < PPT; ++p) {
-            const int item = tid + p * 256;
-            if (PITEMS % 256 == 0 || item < PITEMS) {
-                const int pix = item % NPIX, cg = item / NPIX;
-                bf16x4_t hh = {(__bf16)pv[p][0], (__bf16)pv[p][1], (__bf16)pv[p][2], (__bf16)pv[p][3]};
-                bf16x4_t ll = {(__bf16)(pv[p][0] - (float)hh[0]), (__bf16)(pv[p][1] - (float)hh[1]), (__bf16)(pv[p][2] - (float)hh[2]),
-                               (__bf16)(pv[p][3] - (float)hh[3])};
-                *reinterpret_cast<bf16x4_t *>(&P[0][cg >> 1][pix][(cg & 1) * 4]) = hh;
-                *reinterpret_cast<bf16x4_t *>(&P[1][cg >> 1][pix][(cg & 1) * 4]) = ll;
-            }
-        }
-    };
-    // ---- weight staging: a sub-stage = 3 taps x 16 channels of TR rows, hi and lo planes: TR x 3 x 2 x 2 16-byte pieces of the
-    //      pre-split copy the packer leaves behind the fp32 halo layout ([plane][row][chunk of 16][tap][16] bf16) ----
-    constexpr int WPIECES = TR * 12, WPT = WPIECES / 256;
-    static_assert(WPIECES % 256 == 0, "whole pieces per thread");
-    const __bf16 *wsplit = reinterpret_cast<const __bf16 *>(g.A + (size_t)g.rows * g.lda);
-    const size_t wplane = (size_t)g.rows * nch * 9 * XC;
-    bf16x8_t wv[WPT];
-    auto load_w = [&](int chunk, int sub) {
-#pragma unroll
-        for (int p = 0; p < WPT; ++p) {
-            const int piece = tid + p * 256;                 // (plane, row, tap, half)
-            const int half = piece & 1, tap = (piece >> 1) % 3, row = (piece / 6) % TR, plane = piece / (6 * TR);
-            const int rc = min(row0 + row, g.rows - 1);
-            wv[p] = *reinterpret_cast<const bf16x8_t *>(wsplit + plane * wplane + (((size_t)rc * nch + chunk) * 9 + sub * 3 + tap) * XC + half * 8);
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < WPT; ++p) {
-            const int piece = tid + p * 256;
-            const int half = piece & 1, tap = (piece >> 1) % 3, row = (piece / 6) % TR, plane = piece / (6 * TR);
-            *reinterpret_cast<bf16x8_t *>(&Ws[buf][plane][tap][half][row][0]) = wv[p];
-        }
-    };
-
-    f32x16 acc[MR][2];
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    int pbase[2];                                    // the lane's two pixels: patch index of the pixel at tap (0, 0)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pl = wc * 64 + j * 32 + (lane & 31);
-        pbase[j] = (pl >> LOGW) * PW + (pl & (W - 1));
-    }
-    auto taps3 = [&](int buf, int sub) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int tap = sub * 3 + t, ky = tap / 3, kx = tap - ky * 3;
-            bf16x8_t ah[MR], al[MR], bh[2], bl[2];
-#pragma unroll
-            for (int i = 0; i < MR; ++i) {
-                const int r = wr * (MR * 32) + i * 32 + (lane & 31);
-                ah[i] = *reinterpret_cast<const bf16x8_t *>(&Ws[buf][0][t][h][r][0]);
-                al[i] = *reinterpret_cast<const bf16x8_t *>(&Ws[buf][1][t][h][r][0]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int pi = pbase[j] + ky * PW + kx;
-                bh[j] = *reinterpret_cast<const bf16x8_t *>(&P[0][h][pi][0]);
-                bl[j] = *reinterpret_cast<const bf16x8_t *>(&P[1][h][pi][0]);
-            }
-#pragma unroll
-            for (int i = 0; i < MR; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
-
-    load_patch(c_begin);
-    load_w(c_begin, 0);
-    store_patch();
-    store_w(0);
-    __syncthreads();
-    int wb = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-#pragma unroll
-        for (int sub = 0; sub < 3; ++sub) {
-            const bool last = c == c_end - 1 && sub == 2;
-            const int nc = sub == 2 ? c + 1 : c, ns = sub == 2 ? 0 : sub + 1;
-            if (!last) load_w(nc, ns);                       // the next sub-stage's weights in flight under the matrix work
-            if (sub == 2 && !last) load_patch(c + 1);
-            taps3(wb, sub);
-            if (sub == 2) __syncthreads();                   // everybody has read the patch: it may be replaced
-            if (!last) store_w(wb ^ 1);
-            if (sub == 2 && !last) store_patch();
-            __syncthreads();
-            wb ^= 1;
-        }
-    }
-    // epilogue as in the halo kernel (EPI_FWD).  C/D layout: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int pl = wc * 64 + j * 32 + (lane & 31);
-        const int px = (y0 + (pl >> LOGW)) * W + (pl & (W - 1));
-        if (col0 + pl >= g.cols) continue;
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int r = row0 + wr * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (r >= row_end) continue;
-                float v = acc[i][j][e];
-                if (EPI == EPI_SLAB) {               // this slab's partial sums, reduced with the epilogue by splitk_reduce_kernel
-                    g.C[((size_t)blockIdx.z * g.rows + r) * g.ldc + col0 + pl] = v;
-                    continue;
-                }
-                if (g.bias) v += g.bias[r];
-                v = apply_act(v, g.act);
-                if (r < g.split) {
-                    const size_t idx = ((size_t)img * g.split + r) * g.hw + px;
-                    g.C[idx] = v;
-                    store_blend(g, idx, v);
-                } else {
-                    g.C2[((size_t)img * (g.rows - g.split) + (r - g.split)) * g.hw + px] = v;
-                }
-            }
-    }
-}
-
-// The pre-split copy of a halo weight layout ([row][chunk of 8][tap][8] fp32, lda = nch8 * 72 floats) for the kernel above:
-// [hi | lo][row][chunk of 16][tap][16] bf16 right behind it (an odd number of 8-channel chunks: the last half chunk is zero).
-__global__ __launch_bounds__(256) void split_halo_weights_kernel(const float *__restrict__ w, int rows, int nch8, __bf16 *__restrict__ out)
-{
-    const int nch = (nch8 + 1) >> 1;
-    const size_t n = (size_t)rows * nch * 9 * XC, idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const int c16 = (int)(idx % XC), tap = (int)((idx / XC) % 9), chunk = (int)((idx / (XC * 9)) % nch), row = (int)(idx / ((size_t)XC * 9 * nch));
-    const int c8 = 2 * chunk + (c16 >> 3);
-    const float v = c8 < nch8 ? w[(size_t)row * nch8 * HK + (size_t)c8 * HK + tap * HC + (c16 & 7)] : 0.0f;
-    const __bf16 h = (__bf16)v;
-    out[idx] = h;
-    out[n + idx] = (__bf16)(v - (float)h);
-}
-
-// TEF_CONV_MATH (read once per process): bf16x3 = forward and input gradients, bf16x3_dgrad = input gradients only (the
-// forward — and with it every activation mask — stays on exact fp32 products)
-inline int conv_math_mode()
-{
-    static const int mode = [] {
-        const char *e = getenv("TEF_CONV_MATH");
-        if (e && strcmp(e, "bf16x3") == 0) return 2;
-        if (e && strcmp(e, "bf16x3_dgrad") == 0) return 1;
-        return 0;
-    }();
-    return mode;
-}
-inline bool conv_math_x3() { return conv_math_mode() != 0; }
-
-template <int TR, int LOGW, bool GATED, int EPI>
-int launch_x3(const GemmArgs &g, int z, hipStream_t st)
-{
-    constexpr size_t lds = x3_lds_bytes<TR, LOGW>();
-    static const hipError_t attr = hipFuncSetAttribute((const void *)conv3x3_x3_kernel<TR, LOGW, GATED, EPI>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return tef::fail_hip("hipFuncSetAttribute", attr), TEF_ERR_LAUNCH;
-    const int rows = (g.row_end ? g.row_end : g.rows) - g.row_off;
-    dim3 grid((g.cols + 127) / 128, (rows + TR - 1) / TR, EPI == EPI_SLAB ? z : 1);
-    hipLaunchKernelGGL((conv3x3_x3_kernel<TR, LOGW, GATED, EPI>), grid, dim3(256), lds, st, g);
-    return tef::check_launch("conv3x3_x3_kernel");
-}
-
-// =====================================================================================================================
 // Weight gradient of the same layers with the input patch in LDS:  dW[n][(ci, tap)] += sum_pixels g[n][m] x[ci][m + tap].
 // rows = output channels (A = g, NCHW, k = pixels, read as in the implicit GEMM), columns = (ci, tap) in the weight's own
 // order, reduction over pixels in stages of 32.  The 128 columns of a tile touch at most 16 input channels: their
@@ -1807,9 +1527,6 @@ inline int halo_logw(const tef_conv_desc *d)
     return d->W == 16 ? 4 : d->W == 32 ? 5 : d->W == 64 ? 6 : d->W == 128 ? 7 : 0;
 }
 
-// layers whose packed weights carry bf16 hi / lo copies for conv3x3_x3_kernel (TEF_CONV_MATH=bf16x3)
-inline bool x3_split_copies(const tef_conv_desc *d) { return conv_math_x3() && d->stride == 1 && halo_logw(d) >= 4; }
-
 // Any other 3x3 stride-1 layer whose rows are a multiple of 4 pixels runs on W x (128 / W) rectangles: returns
 // log2(tile width), the widest of 128 / 64 / 32 / 16 / 8 that wastes the least of the image's columns and rows
 // (30 x 40 at the deepest level of a 480 x 640 input: 8 x 16 tiles cover 94 %, 16 x 8 tiles 78 %).
@@ -1839,20 +1556,6 @@ template <int LOGW, int EPI, bool GATED, bool GEN, bool S2D = false>
 int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
 {
     constexpr int IPT = (LOGW == 3 && !GEN) ? 2 : 1;
-    // opt-in: error-compensated bf16 splits (conv3x3_x3_kernel) for launches of more than 32 rows: whole reductions, or slabs
-    // of an even number of 8-channel chunks (its k-step is 16 channels)
-    constexpr bool X3 = (EPI == EPI_FWD || EPI == EPI_SLAB) && !GEN && !S2D && LOGW >= 4;
-    bool x3 = false;
-    // (a slab of fewer than four 16-channel k-steps is all prologue: the fp32 kernel keeps those)
-    if constexpr (X3) x3 = (conv_math_mode() == 2 || (conv_math_mode() == 1 && g.dgrad)) && g.s2d_ct == 0 &&
-                           (EPI == EPI_FWD ? z == 1 : ((g.ksplit & 1) == 0 && g.ksplit >= 8));
-    auto launch_rows_x3 = [&](const GemmArgs &a) -> int {
-        if constexpr (X3) {
-            const int rows = (a.row_end ? a.row_end : a.rows) - a.row_off;
-            return rows > 64 ? launch_x3<128, LOGW, GATED, EPI>(a, z, st) : launch_x3<64, LOGW, GATED, EPI>(a, z, st);
-        }
-        return TEF_ERR_LAUNCH;
-    };
     unsigned tiles = (g.cols + 127) / 128;
     if (GEN) tiles = (unsigned)((g.G.SW + (1 << LOGW) - 1) >> LOGW) * ((g.G.SH + (128 >> LOGW) - 1) / (128 >> LOGW)) *
                      (g.G.npix / (g.G.SH * g.G.SW));
@@ -1866,9 +1569,7 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
         GemmArgs a = g, b = g;
         a.row_end = main_rows;
         b.row_off = main_rows; b.row_end = g.rows;
-        if (x3) {
-            if (int rc = launch_rows_x3(a)) return rc;
-        } else if (main_rows == 64) {
+        if (main_rows == 64) {
             hipLaunchKernelGGL((conv3x3_halo_kernel<512, 64, 32, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, a);
         } else {
             grid.y = main_rows / 128;
@@ -1883,7 +1584,6 @@ int launch_halo_w(const GemmArgs &g, int z, hipStream_t st)
         return tef::check_launch("conv3x3_halo_kernel (row remainder)");
     }
     const int tr = halo_row_tile(g.rows, g.cols);
-    if (x3 && (g.row_end ? g.row_end : g.rows) - g.row_off > 32) return launch_rows_x3(g);
     if (tr == 128) {
         grid.y = (g.rows + 127) / 128;
         hipLaunchKernelGGL((conv3x3_halo_kernel<512, 128, 64, LOGW, IPT, EPI, GATED, GEN, 1, S2D>), grid, dim3(512), 0, st, g);
@@ -2181,10 +1881,6 @@ size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, 
     if (d->ksize == 3) {           // + the halo-kernel layouts
         np_ += (size_t)d->N * ((q.Ct + HC - 1) / HC) * HK;
         n2 += (size_t)(s2d_mode(d, nullptr) ? 4 : 1) * q.Ct * ((d->N + HC - 1) / HC) * HK;      // S2D: four parity classes
-        if (x3_split_copies(d)) {      // + their bf16 hi / lo copies (TEF_CONV_MATH=bf16x3): 2 x 2 bytes per element of 16-channel chunks
-            np_ += (size_t)d->N * (((q.Ct + HC - 1) / HC + 1) / 2) * 9 * XC;
-            n2 += (size_t)q.Ct * (((d->N + HC - 1) / HC + 1) / 2) * 9 * XC;
-        }
     }
     if (wp_floats) *wp_floats = np_;
     if (w2_floats) *w2_floats = n2;
@@ -2210,16 +1906,6 @@ int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, 
         hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, rows,
                            row0, d->N, q.Ct, nch, nch2, wp + (size_t)d->N * q.Kp, w2 + (size_t)q.Ct * q.K2p);
         if (int rc = tef::check_launch("pack_halo_kernel")) return rc;
-        if (x3_split_copies(d)) {      // the whole matrices again after every part (the layers with >= 16-pixel rows)
-            hipStream_t st = (hipStream_t)stream;
-            const size_t n1 = (size_t)d->N * ((nch + 1) / 2) * 9 * XC, n2_ = (size_t)q.Ct * ((nch2 + 1) / 2) * 9 * XC;
-            float *h1 = wp + (size_t)d->N * q.Kp, *h2 = w2 + (size_t)q.Ct * q.K2p;
-            hipLaunchKernelGGL(split_halo_weights_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, h1, d->N, nch,
-                               reinterpret_cast<__bf16 *>(h1 + (size_t)d->N * nch * HK));
-            hipLaunchKernelGGL(split_halo_weights_kernel, dim3((unsigned)((n2_ + 255) / 256)), dim3(256), 0, st, h2, q.Ct, nch2,
-                               reinterpret_cast<__bf16 *>(h2 + (size_t)q.Ct * nch2 * HK));
-            if (int rc = tef::check_launch("split_halo_weights_kernel")) return rc;
-        }
         if (s2d_mode(d, nullptr)) {      // the stride-1 input-gradient layout is unused at stride 2: the region holds the S2D rows
             size_t ns = (size_t)4 * q.Ct * (n_hi - row0) * 9;
             hipLaunchKernelGGL(pack_s2d_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weight, rows,
@@ -2280,7 +1966,6 @@ int tef_conv_forward_blend(const tef_conv_desc *d, const float *x0, const float 
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
         g.ksplit = (nch + z - 1) / z;
-        if (conv_math_x3()) g.ksplit = (g.ksplit + 1) & ~1;      // (whole 16-channel k-steps per slab for conv3x3_x3_kernel)
         z = (nch + g.ksplit - 1) / g.ksplit;
         if (int rc = launch_halo_s2<EPI_SLAB>(g, logw, z, st)) return rc;
         size_t n = (size_t)d->N * q.M;
@@ -2296,7 +1981,6 @@ int tef_conv_forward_blend(const tef_conv_desc *d, const float *x0, const float 
         float *slab = (float *)(ws + L.slab);
         g.C = slab; g.ldc = q.M; g.valid_cols = q.M;
         g.ksplit = (nch + z - 1) / z;
-        if (conv_math_x3()) g.ksplit = (g.ksplit + 1) & ~1;      // (whole 16-channel k-steps per slab for conv3x3_x3_kernel)
         z = (nch + g.ksplit - 1) / g.ksplit;
         if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
         size_t n = (size_t)d->N * q.M;
@@ -2453,12 +2137,10 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
         if (int logw = halo_mode(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
-            g.dgrad = 1;
             int z = halo_splits(d, q.Ct, q.Min, nch2);
             if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
             g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
             g.ksplit = (nch2 + z - 1) / z;
-            if (conv_math_x3()) g.ksplit = (g.ksplit + 1) & ~1;
             z = (nch2 + g.ksplit - 1) / g.ksplit;
             if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
             size_t n = (size_t)q.Ct * q.Min;
