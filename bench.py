@@ -1220,11 +1220,13 @@ def dp_train_extra(a, torch, dist, dev, rank, world, windows=3):
         # all-reduce(MAX) on the host-side group, once per pass
         dist.barrier()
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(200):
             parallel.any_rank(False)
-        flag_ms = 1e3 * (time.perf_counter() - t0) / 20
+        flag_ms = 1e3 * (time.perf_counter() - t0) / 200
         out.update({
             "new_seq_exchange_ms_per_pass": round(flag_ms, 4),
+            # (round 6) ranks of one node exchange the flag over a shared-memory board; over the host-side gloo group otherwise
+            "new_seq_exchange_transport": "shared-memory flag board" if parallel._FLAG_BOARD else "gloo all-reduce",
             "dp_train_window_ms": round(ms, 3), "dp_train_events_per_s": round(ev / (ms * 1e-3), 1), "windows_timed": windows,
             "allreduce_ms": round(ar_ms, 3), "allreduce_exposed_ms": round(ex_ms, 3), "allreduce_bytes": nbytes,
             "allreduce_overlap": window.graph_mid is not None,

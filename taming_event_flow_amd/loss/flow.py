@@ -117,7 +117,8 @@ class _Window:
         self.workspace = None
         self.scratch = None
         self.pass_args = None      # ctypes argument arrays of tef_update_pass, refilled per pass
-        self.pending = []          # passes recorded by a deferred update() (BaseEventWarping.defer_update)
+        self.pending = []          # passes recorded by a deferred update() (BaseEventWarping.defer_update); None: this window packs pass by pass
+        self.pending_ptrs = set()  # storage of the event lists recorded so far (aliasing check of the deferred update)
         self.leases = []          # weak references to the tokens of evaluations whose autograd graph still reads the buffers
         self.cfg = None
 
@@ -198,7 +199,9 @@ class BaseEventWarping(torch.nn.Module):
         # is evaluated (tef_update_window) — for callers to whom ten launches and ten host calls per window matter (a
         # loss-only caller; inside a training window update() hides behind the network on a side stream anyway).  The
         # in-place shift of the callers' time stamps (loss/flow.py:457-458) then happens at the evaluation, and the lists
-        # must not be changed between update() and the evaluation.  Off by default: reference behaviour.
+        # must not be changed between update() and the evaluation (a list whose storage was already recorded in this window
+        # is detected: the recorded passes are then packed at once and the rest of the window goes pass by pass; a pass that
+        # takes the converting path, and reset(), pack the recorded passes first).  Off by default: reference behaviour.
         self.defer_update = bool(config["loss"].get("defer_update", False))
 
         # timescales for loss computation (loss/flow.py:42-44)
@@ -254,6 +257,10 @@ class BaseEventWarping(torch.nn.Module):
         win.flow_refs.append(refs)
 
     def reset_base(self):
+        if self._win is not None and self._win.pending:
+            # a window dropped with recorded passes (a new sequence in the middle of it): the reference has shifted the
+            # callers' time stamps in place at every update() (loss/flow.py:457-458) — pack them now, which applies the shift
+            self._flush_updates()
         if self._win is not None:      # the next window starts with stores of the size this one ended with
             self._hints = (max(self._win.grad.n, getattr(self, "_hints", (0, 0))[0]), max(self._win.det.n, getattr(self, "_hints", (0, 0))[1]))
         self._passes = 0
@@ -327,6 +334,7 @@ class BaseEventWarping(torch.nn.Module):
                     and not ((event_list.data_ptr() | pol_mask.data_ptr() | d_event_list.data_ptr() | d_pol_mask.data_ptr()) & 15)
                     and all(f.shape == fshape and f.dtype is f32 and f.is_cuda and f.stride()[2:] == ftail for f in flow_list))
         if not fast or (self._num_flows is not None and F != self._num_flows) or self._passes >= max(self.passes_loss):
+            self._flush_updates()                # (recorded passes first: the stores are filled in pass order)
             self.update_base(flow_list)          # (also where malformed calls get their error messages)
             self._update_events(event_list, pol_mask, d_event_list, d_pol_mask)
             return
@@ -349,9 +357,20 @@ class BaseEventWarping(torch.nn.Module):
                 d_ovr = ((d_event_list[:, :, 0].min() + float(t)) + 0.5).reshape(1).contiguous()
             win.keep = getattr(win, "keep", []) + [ovr, d_ovr]       # alive until the pack kernels have run
         slot0, dslot0 = win.grad.reserve(N), win.det.reserve(Nd)
-        if self.defer_update:
+        if self.defer_update and win.pending is not None:
             # the pass is only recorded (its tensors stay referenced, nothing is launched, the caller's time stamps are not
-            # shifted yet): _flush_updates() hands the whole window to the library in one call when the loss is evaluated
+            # shifted yet): _flush_updates() hands the whole window to the library in one call when the loss is evaluated.
+            # A caller that REUSES one device buffer for the event lists of successive passes (a common loader pattern) would
+            # have every recorded pass packed from the buffer's last contents: a list whose storage is already recorded is
+            # detected here, the recorded passes are packed now and this window goes on pass by pass.
+            ptrs_ = (event_list.data_ptr() if N else 0, d_event_list.data_ptr() if Nd else 0)
+            seen = win.pending_ptrs
+            if (ptrs_[0] and ptrs_[0] in seen) or (ptrs_[1] and ptrs_[1] in seen):
+                self._flush_updates()
+                win.pending = None               # (pass by pass from here to the end of the window)
+            else:
+                seen.update(p_ for p_ in ptrs_ if p_)
+        if self.defer_update and win.pending is not None:
             win.pending.append((list(flow_list), event_list, pol_mask, d_event_list, d_pol_mask, N, Nd, ovr, d_ovr, t, slot0, dslot0))
             win.grad.commit(N)
             win.det.commit(Nd)
@@ -386,6 +405,8 @@ class BaseEventWarping(torch.nn.Module):
         win = self._win
         if win is None or not win.pending:
             return
+        if self._side is not None:           # (recorded passes whose flows live on the network's side stream)
+            torch.cuda.current_stream().wait_stream(self._side)
         F, B = self._num_flows, self.batch_size
         H, W = self.res
         n = len(win.pending)
@@ -409,6 +430,7 @@ class BaseEventWarping(torch.nn.Module):
                                           win.grad.struct_ref(), win.det.struct_ref(), _lib.stream_ptr())
         _lib.check(rc, "tef_update_window")
         win.pending = []
+        win.pending_ptrs = set()
 
     def _smooth_weights(self, P):
         ws = -1.0 if self.flow_spat_smooth_weight is None else float(self.flow_spat_smooth_weight)

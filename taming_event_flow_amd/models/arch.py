@@ -167,16 +167,27 @@ class MultiResUNetRecurrent(nn.Module):
                 eng.side_stream = torch.cuda.Stream(device=params[0].device)
                 eng.lazy_flows = True
             return True
-        o, fresh = 0, False
+        # optimizer.zero_grad(set_to_none=True) — every gradient None at once — clears the whole buffer in one fill; when only
+        # SOME parameters lost their view (a param group zeroed, p.grad = None for a subset, gradient accumulation over
+        # several backward() calls with a partial zero_grad) only THEIR slices are cleared: the gradients already accumulated
+        # in the views that are still attached stay
+        if all(p.grad is None for p in params):
+            b.flat.zero_()
+            o = 0
+            for p in params:
+                p.grad = b.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            return True
+        o = 0
         for p in params:
             g = p.grad
             if g is None or g.data_ptr() != b.flat.data_ptr() + 4 * o or not g.is_contiguous():
-                if not fresh:                   # optimizer.zero_grad(set_to_none=True): the next backward starts from zero
-                    b.flat.zero_()
-                    fresh = True
-                if g is not None:
-                    b.flat[o:o + p.numel()].view_as(p).add_(g)
-                p.grad = b.flat[o:o + p.numel()].view_as(p)
+                view = b.flat[o:o + p.numel()].view_as(p)
+                if g is None:
+                    view.zero_()
+                else:
+                    view.copy_(g)
+                p.grad = view
             o += p.numel()
         return True
 

@@ -74,6 +74,8 @@ class PassEngine:
         self._zeros = {}
         self._layout = {}
         self._pending = []            # backward calls of the current window whose weight gradients are still deferred
+        self._callback_queued = False # an end-of-backward flush is queued with autograd (cleared by the callback itself)
+        self._own_packers = None      # ids of the PackedWeights of this engine's network (end-of-backward flush)
         self.last_pass_split = False  # whether the last run_pass left its flows on the side stream
 
     @property
@@ -342,10 +344,13 @@ class PassEngine:
         if direct and a.deferred_wgrad and not rec.queued:
             if self._pending and (self._pending[0].plan.B, self._pending[0].plan.H, self._pending[0].plan.W) != (pl.B, pl.H, pl.W):
                 self.flush_window()
-            if not self._pending and a.auto_grads and a._bucket is not None:
+            if a.auto_grads and a._bucket is not None and not self._callback_queued:
                 # nobody calls flush_window for the drop-in loop: at the end of this backward() (autograd runs the queued
-                # callbacks when every node is done)
+                # callbacks when every node is done).  The flag is the callback's own — not "the queue was empty": a
+                # backward() that raised after queueing records leaves them behind, and every later backward still gets its
+                # flush (the callback of a failed graph task never runs: the next forward drops the flag, run_pass)
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+                self._callback_queued = True
             self._pending.append(rec)       # (keeps the arenas alive until the flush)
             rec.queued = True
             sm._DEFERRED_ENGINES.add(self)
@@ -361,8 +366,16 @@ class PassEngine:
     def _end_of_backward(self):
         """arch.auto_grads: what train.Trainer does after loss.backward() — the window's remaining weight gradients, then wait
         for the reductions that ran beside BPTT on the weight-gradient stream."""
+        self._callback_queued = False
         self.join()          # (pre-activation gradients of the decoder halves were formed on the side stream)
-        sm.flush_deferred_wgrads()
+        self.flush_window()  # THIS engine's window; other models' engines and trainers flush their own
+        if sm._DEFERRED:                   # packers of THIS network's layer-by-layer modules (normally none queued)
+            if self._own_packers is None:
+                self._own_packers = {id(v_) for m_ in self.arch.modules() for v_ in vars(m_).values()
+                                     if isinstance(v_, sm.PackedWeights)}
+            for pk in list(sm._DEFERRED):
+                if id(pk) in self._own_packers:
+                    sm.flush_deferred_wgrads(pk)
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
@@ -485,6 +498,15 @@ def run_pass(engine, x, states):
                                          any(s is not None and s.requires_grad for s in states))
     side = engine.side_stream
     if needs:
+        if engine._callback_queued:
+            # a backward() that queued its end-of-backward flush never finished (it raised: autograd drops the callbacks of a
+            # failed graph task).  Its records are stale — their weight gradients belong to a window that was abandoned —
+            # and the next backward must queue a flush of its own
+            engine._callback_queued = False
+            for r_ in engine._pending:
+                r_.queued = False
+            engine._pending = []
+            sm._DEFERRED_ENGINES.discard(engine)
         engine.arch.own_gradients()          # (the drop-in loop: .grad views of the network's own flat buffer, see arch.py)
     if not needs:
         if side is None or not engine.defer_join:       # (without gradients the split only pays when the caller overlaps)

@@ -103,6 +103,7 @@ class FusedAdam:
         # or a load_state_dict without being captured again.
         self.hp = torch.zeros((5,), dtype=torch.float64, device=flat_g.device)
         self._hp_uploaded = None
+        self._hp_ring = None         # pinned staging buffers of refresh_hyperparams
         self._max_norm = -1.0
 
     @property
@@ -145,14 +146,31 @@ class FusedAdam:
             if k != "params":
                 self.param_groups[0][k] = tuple(v) if k == "betas" else v
 
-    def refresh_hyperparams(self):
+    def refresh_hyperparams(self, max_norm=None):
         """Upload (lr, betas, eps, max_norm) if any of them changed since the last upload.  Called by step() outside graph
-        capture and by CapturedWindow.replay() before the graph is launched; the copy is stream-ordered before whatever
-        is enqueued next and blocks the host only when something changed (a pageable source)."""
+        capture and by CapturedWindow.replay() before the graph is launched — there with the window's OWN capture-time
+        `max_norm`, so that an eager step with another clip between two replays cannot change the captured window's.  The
+        values go through a small ring of pinned host buffers with a non-blocking copy: stream-ordered before whatever is
+        enqueued next, and the host does not wait for the previous window to drain (a per-step learning-rate schedule would
+        otherwise serialise host and device at every replay)."""
         g = self.param_groups[0]
-        vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(self._max_norm))
+        mn = self._max_norm if max_norm is None else float(max_norm)
+        vals = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(mn))
         if vals != self._hp_uploaded:
-            self.hp.copy_(torch.tensor(vals, dtype=torch.float64))
+            if self.hp.is_cuda:
+                if self._hp_ring is None:
+                    self._hp_ring = [(torch.empty((5,), dtype=torch.float64).pin_memory(), torch.cuda.Event()) for _ in range(8)]
+                    self._hp_next = 0
+                buf, ev = self._hp_ring[self._hp_next % len(self._hp_ring)]
+                if self._hp_next >= len(self._hp_ring):
+                    ev.synchronize()          # (the copy that last used this slot, eight uploads ago)
+                self._hp_next += 1
+                for k_, v_ in enumerate(vals):
+                    buf[k_] = v_
+                self.hp.copy_(buf, non_blocking=True)
+                ev.record()
+            else:
+                self.hp.copy_(torch.tensor(vals, dtype=torch.float64))
             self._hp_uploaded = vals
 
     def step(self, max_norm=None):
@@ -189,6 +207,115 @@ def _flag_group():
     return _FLAG_GROUP
 
 
+class _FlagBoard:
+    """The lock-step exchange for ranks of ONE node (the only DP layout of this package: one process per GPU of a node) without
+    a collective: a shared-memory board of one (sequence number, mask) pair per rank and bank.  An exchange writes this
+    rank's mask, then its sequence number, into bank `seq % 2`, spins until every rank's number in that bank has reached
+    `seq`, and ORs the masks.  Nobody can be two exchanges ahead — exchange seq + 1 completes only when every rank has
+    written seq + 1, i.e. has finished reading seq — so the two banks never collide.  Aligned 8-byte stores and loads, store
+    order kept by the host's memory model (x86-64 TSO; the store of the number follows the store of the mask).  Measured
+    with 8 CPU processes (tools/lockstep_timing.py): ~2 ms per gloo all-reduce of one int in the build container against a few
+    microseconds here.  Falls back to the gloo group when the ranks are not on one host or shared memory is unavailable."""
+
+    def __init__(self):
+        import socket
+        import uuid
+        from multiprocessing import shared_memory
+
+        import numpy as np
+
+        grp = _flag_group()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        hosts = [None] * self.world
+        dist.all_gather_object(hosts, socket.gethostname(), group=grp)
+        if len(set(hosts)) != 1:
+            raise RuntimeError("ranks on several hosts")
+        name = [f"tef_flags_{uuid.uuid4().hex[:16]}" if self.rank == 0 else None]
+        nbytes = 2 * self.world * 2 * 8
+        shm, err = None, None
+        if self.rank == 0:
+            try:
+                shm = shared_memory.SharedMemory(name=name[0], create=True, size=nbytes)
+                shm.buf[:nbytes] = bytes(nbytes)
+            except Exception as e:          # noqa: BLE001
+                err, name[0] = repr(e), None
+        dist.broadcast_object_list(name, src=0, group=grp)
+        if name[0] is None:
+            raise RuntimeError(f"shared memory unavailable: {err}")
+        if self.rank != 0:
+            shm = shared_memory.SharedMemory(name=name[0])
+        self.shm = shm
+        self.words = np.ndarray((2, self.world, 2), dtype=np.uint64, buffer=shm.buf)      # [bank][rank][(seq, mask)]
+        self.seq = 0
+        dist.barrier(group=grp)            # everybody is attached before rank 0 may unlink the name
+        if self.rank == 0:
+            try:
+                shm.unlink()               # the mapping stays; the name goes away with the last process
+            except Exception:              # noqa: BLE001
+                pass
+
+    def exchange_or(self, mask, timeout=600.0):
+        import time
+
+        self.seq += 1
+        bank = self.words[self.seq & 1]
+        bank[self.rank, 1] = int(mask)
+        bank[self.rank, 0] = self.seq
+        seqs = bank[:, 0]
+        spins, t0 = 0, None
+        while int(seqs.min()) < self.seq:
+            spins += 1
+            if spins > 2000:
+                time.sleep(0)              # (oversubscribed hosts: let the rank we wait for run)
+                if t0 is None:
+                    t0 = time.monotonic()
+                elif spins % 4096 == 0 and time.monotonic() - t0 > timeout:
+                    raise RuntimeError("lock-step flag exchange timed out: a rank skipped an exchange or died")
+        out = 0
+        for v in bank[:, 1].tolist():
+            out |= v
+        return out
+
+    def close(self):
+        try:
+            self.words = None
+            self.shm.close()
+        except Exception:                  # noqa: BLE001
+            pass
+
+
+_FLAG_BOARD = None          # False: tried and unavailable (the gloo group is used)
+
+
+def _exchange_or(mask, nbits):
+    """OR over ranks of an integer mask: the shared-memory board when the ranks share a host (TEF_FLAG_BOARD=0: never),
+    one all-reduce(MAX) over the host-side gloo group otherwise."""
+    global _FLAG_BOARD, _EXCHANGES
+    import os
+
+    _EXCHANGES += 1
+    if _FLAG_BOARD is None:
+        _FLAG_BOARD = False
+        if os.environ.get("TEF_FLAG_BOARD", "1") != "0":
+            ok = [1]
+            try:
+                board = _FlagBoard()
+            except Exception:              # noqa: BLE001
+                board, ok = None, [0]
+            # (all ranks or none: a rank on its own would wait on the board for ranks that use the collective)
+            t = torch.tensor(ok, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_flag_group())
+            if int(t.item()) == 1:
+                _FLAG_BOARD = board
+            elif board is not None:
+                board.close()
+    if _FLAG_BOARD:
+        return _FLAG_BOARD.exchange_or(mask)
+    t = torch.tensor([(mask >> k) & 1 for k in range(nbits)], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_flag_group())
+    return sum(int(v) << k for k, v in enumerate(t.tolist()))
+
+
 def any_rank(flag, device=None):
     """True on every rank if `flag` is True on at least one (lock-step `new_seq`, reference train_flow.py:83-87 applied
     to the global batch).  EVERY rank must call this at the same point of every pass, whatever its own flag is: a rank
@@ -196,15 +323,31 @@ def any_rank(flag, device=None):
     all-reduce) and hang or corrupt it.  No collective (and no device sync) outside DP."""
     if not is_distributed():
         return bool(flag)
-    t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_flag_group())
-    return bool(t.item())
+    return bool(_exchange_or(1 if flag else 0, 1))
+
+
+_EXCHANGES = 0       # host-side flag exchanges this process took part in (tests / tools count them)
+
+
+def any_rank_mask(mask, nbits):
+    """The bitwise OR over ranks of an `nbits`-bit mask: ONE host-side exchange for a whole loss window (bit k = "a slot of
+    this rank starts a new sequence at pass k of the window").  For loaders that know their sequence boundaries ahead —
+    fixed-length sequences, e.g. the reference's dsec_train (200 passes per sequence, configs/train_flow.yml:6) — this
+    replaces the per-pass any_rank: `Trainer.declare_fixed_sequences`.  Same rule as any_rank: EVERY rank calls it at the
+    same point.  No collective outside DP."""
+    mask = int(mask) & ((1 << nbits) - 1)
+    if not is_distributed():
+        return mask
+    return _exchange_or(mask, nbits)
 
 
 def reset_groups():
     """Forget the cached flag group (after destroy_process_group)."""
-    global _FLAG_GROUP
+    global _FLAG_GROUP, _FLAG_BOARD
     _FLAG_GROUP = None
+    if _FLAG_BOARD:
+        _FLAG_BOARD.close()
+    _FLAG_BOARD = None
 
 
 def shard_range(global_batch, rank, world):

@@ -98,6 +98,9 @@ class CapturedWindow:
         self.trainer, self.graph, self.graph_tail, self.inputs, self.states = trainer, graph, graph_tail, inputs, states
         self.graph_mid = graph_mid        # DP with overlap: the encoder half of the last weight-gradient reduction
         self.signature, self.loss_out = signature, loss_out      # (what Trainer.capture_window parks a closed window under)
+        # the clip the window was captured with (None: no clipping): uploaded with the other hyper-parameters at every replay,
+        # whatever an eager step in between used
+        self.max_norm = trainer.cfg["loss"]["clip_grad"] if trainer is not None else None
         # buffers the graphs read and write that nothing else refers to (the per-pass working copies of the inputs, allocated
         # BEFORE the capture, i.e. outside the graphs' private pool): they must live as long as the graphs can run — until
         # round 5 they died with capture_window()'s frame and the next allocation of the caller landed in them
@@ -111,7 +114,8 @@ class CapturedWindow:
             for s in self.states:            # loss containers and gradients are already clear at a window boundary
                 s.zero_()
         if self.trainer.fused_opt is not None:
-            self.trainer.fused_opt.refresh_hyperparams()      # lr / betas / eps / clip as they are NOW (a schedule, a restored checkpoint)
+            # lr / betas / eps as they are NOW (a schedule, a restored checkpoint); the clip as it was captured
+            self.trainer.fused_opt.refresh_hyperparams(max_norm=-1.0 if self.max_norm is None else float(self.max_norm))
         if self.loss_out is not None:
             self.trainer.last_loss = self.loss_out            # (the graph's own output tensor: eager windows in between re-point it)
         self.graph.replay()
@@ -162,9 +166,11 @@ class CapturedWindow:
         # shapes hands it out again instead of capturing (a retired graph pins its private pool — a whole window's memory —
         # for the life of the process; with this, what is retained is one window per distinct shape and trainer, and it is
         # retired once, with the trainer).  Hyper-parameters are read from device memory at every replay, the inputs are
-        # static buffers the caller fills: a parked window is as good as a new capture.
+        # static buffers the caller fills: a parked window is as good as a new capture — ONLY with the fused optimiser: any
+        # torch.optim optimiser (TEF_TORCH_ADAM=1, or another name in the config) bakes lr / betas / eps into the captured
+        # kernels, and such a window is retired as before (a new capture_window() records the values of its own time).
         tr = self.trainer
-        if (tr is not None and self.signature is not None and getattr(tr, "_parked", None) is not None
+        if (tr is not None and tr.fused_opt is not None and self.signature is not None and getattr(tr, "_parked", None) is not None
                 and self.signature not in tr._parked and os.environ.get("TEF_DESTROY_GRAPHS", "0") != "1"):
             tr._parked[self.signature] = {"graph": self.graph, "graph_tail": self.graph_tail, "graph_mid": self.graph_mid,
                                           "inputs": self.inputs, "states": self.states, "loss_out": self.loss_out,
@@ -257,6 +263,7 @@ class Trainer:
             self.optimizer = getattr(torch.optim, config["optimizer"]["name"])(self.model.parameters(), **opt_kwargs)
         self.last_loss = None
         self.last_grad_norm = None
+        self._fixed_seq, self._seq_pos, self._win_mask, self._win_pos = 0, 0, None, 0      # declare_fixed_sequences
         self._parked = {}       # closed captured windows by batch-shape signature (CapturedWindow.close)
         # DP: the gradient bucket is reduced in two pieces — [encoders | residual blocks, decoders, heads], the order of
         # model.parameters() — so that the second piece's all-reduce overlaps the encoders' last weight-gradient reduction
@@ -334,7 +341,13 @@ class Trainer:
             raise ValueError("capture needs at least one eager window (allocations, recurrent state buffers)")
         if self.loss_function.num_passes != 0:
             raise RuntimeError("capture_window must start at a window boundary")
-        signature = (warmup >= 1, parallel.is_distributed(),
+        # everything else that is baked into the graphs at capture time: the optimiser object, the clip, how the DP
+        # reduction is split, the loss configuration (a parked window is handed out again only when all of it still holds)
+        lcfg = self.cfg["loss"]
+        signature = (warmup >= 1, parallel.is_distributed(), id(self.optimizer), lcfg.get("clip_grad"),
+                     self._dp_overlap() is not None, os.environ.get("TEF_DP_OVERLAP", "1"),
+                     tuple(sorted((k, repr(v)) for k, v in lcfg.items())), repr(self.cfg["data"].get("passes_loss")),
+                     repr(self.cfg["data"].get("scales_loss")),
                      tuple(tuple((k, tuple(v.shape), str(v.dtype)) for k, v in sorted(b.items())) for b in batches))
         rec = self._parked.pop(signature, None) if self._parked is not None else None
         if rec is not None:
@@ -418,9 +431,43 @@ class Trainer:
         cw.keep = work
         return cw
 
+    def declare_fixed_sequences(self, seq_len, first_pass=0):
+        """The loader's sequences are all `seq_len` passes long (the reference's dsec_train: 2 s = 200 passes,
+        configs/train_flow.yml:6) and the next pass handed to step() is pass `first_pass` of its sequence.  Under DP the
+        ranks then agree on the reset flags ONCE PER LOSS WINDOW instead of once per pass: at a window's first pass every
+        rank contributes the passes of the coming window at which ITS sequences restart (from its own pass counter) and
+        takes the OR over ranks (parallel.any_rank_mask); the host-side exchange — 10 blocking gloo all-reduces per window
+        otherwise, DESIGN section 7 — happens once every P passes.  A loader flag that the declared length does not predict
+        raises.  `seq_len` None / 0: back to the per-pass exchange."""
+        self._fixed_seq = int(seq_len) if seq_len else 0
+        self._seq_pos = int(first_pass)
+        self._win_mask, self._win_pos = None, 0
+
+    def _lockstep_flag(self, new_seq):
+        """The reset flag of this pass as every rank sees it (train_flow.py:83-87 applied to the global batch)."""
+        if not getattr(self, "_fixed_seq", 0):
+            return parallel.any_rank(new_seq)      # every rank exchanges its flag on every pass (no-op outside DP)
+        P = self.cfg["data"]["passes_loss"]
+        if self._win_mask is None:             # once every P passes, whatever the window boundaries are
+            mine = 0
+            for k in range(P):
+                if (self._seq_pos + k) % self._fixed_seq == 0:
+                    mine |= 1 << k
+            self._win_mask, self._win_pos = parallel.any_rank_mask(mine, P), 0
+        predicted = (self._seq_pos % self._fixed_seq) == 0
+        if bool(new_seq) != predicted:
+            raise RuntimeError(f"the loader's new_seq flag ({bool(new_seq)}) disagrees with the declared sequence length "
+                               f"{self._fixed_seq} at pass {self._seq_pos} of the sequence")
+        flag = bool((self._win_mask >> self._win_pos) & 1)
+        self._win_pos += 1
+        self._seq_pos += 1
+        if self._win_pos >= P:
+            self._win_mask = None              # the P passes the exchange covered are used up: the next pass exchanges again
+        return flag
+
     def step(self, inputs, new_seq=False):
         """One pass (train_flow.py:83-137).  Returns True when an optimiser step happened."""
-        if parallel.any_rank(new_seq):      # every rank exchanges its flag on every pass (no-op outside DP)
+        if self._lockstep_flag(new_seq):
             self.reset()
         return self._pass(inputs)
 

@@ -239,6 +239,65 @@ def test_graph_replay_matches_eager():
     assert np.isfinite(float(tr_g.last_loss.item()))
 
 
+def test_parked_windows_only_where_nothing_is_baked_in(monkeypatch):
+    """Round-5 advisory: a closed CapturedWindow is parked (and handed out again by the next capture_window of the same
+    shapes) only with the fused optimiser, whose hyper-parameters live in device memory; a torch.optim optimiser bakes lr into
+    the captured kernels, so its windows are retired and a new capture is a NEW capture.  The park's key holds the clip: a
+    trainer whose loss.clip_grad changed captures afresh; and a replay uses the clip of ITS capture whatever an eager step
+    in between used."""
+    import copy
+
+    import __graft_entry__ as g
+
+    g.build()
+    from taming_event_flow_amd import train
+
+    dev = torch.device("cuda:0")
+    cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    cfg["loader"].update(batch_size=2, resolution=[32, 32], max_num_grad_events=300)
+    cfg["data"]["passes_loss"] = 2
+    cfg["optimizer"].update(lr=1e-4, capturable=True)
+
+    def batches(tr):
+        src = train.SyntheticSequences(cfg, dev, 380, seq_len=10 ** 9, seed=3)
+        tr.reset()
+        return [src.next() for _ in range(2)]
+
+    torch.manual_seed(7)
+    tr = train.Trainer(cfg, dev)
+    assert tr.fused_opt is not None
+    win = batches(tr)
+    cw = tr.capture_window(win, warmup=1)
+    graph = cw.graph
+    cw.close()
+    assert len(tr._parked) == 1
+    cw2 = tr.capture_window(win, warmup=1)
+    assert cw2.graph is graph                       # handed out again
+    # the clip of the capture (100) stays the captured window's, whatever an eager step used in between
+    assert cw2.max_norm == cfg["loss"]["clip_grad"]
+    tr.fused_opt.step(max_norm=1e-9)                # an eager step with another clip (gradient is zero here: a no-op update)
+    cw2.replay()
+    torch.cuda.synchronize()
+    assert tr.fused_opt._hp_uploaded[4] == float(cfg["loss"]["clip_grad"])
+    cw2.close()
+    tr.cfg["loss"]["clip_grad"] = 50.0              # another clip: not the parked window's signature any more
+    cw3 = tr.capture_window(win, warmup=1)
+    assert cw3.graph is not graph and cw3.max_norm == 50.0
+    cw3.close()
+    tr.close()
+    # torch.optim.Adam: lr is a constant of the captured kernels -> never parked
+    monkeypatch.setenv("TEF_TORCH_ADAM", "1")
+    torch.manual_seed(7)
+    tr2 = train.Trainer(cfg, dev)
+    assert tr2.fused_opt is None
+    win2 = batches(tr2)
+    n0 = train.retired_graph_count()
+    cwt = tr2.capture_window(win2, warmup=1)
+    cwt.close()
+    assert len(tr2._parked) == 0 and train.retired_graph_count() > n0
+    tr2.close()
+
+
 @pytest.mark.parametrize("B,R,passes", [(2, 32, 3), (4, 64, 4)])
 def test_deferred_weight_gradients_match_immediate(B, R, passes):
     """Weight gradients of a BPTT window computed per layer in one long reduction (flush_deferred_wgrads) equal the per-pass
