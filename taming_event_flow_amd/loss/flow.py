@@ -117,7 +117,7 @@ class _Window:
         self.workspace = None
         self.scratch = None
         self.pass_args = None      # ctypes argument arrays of tef_update_pass, refilled per pass
-        self.pending = []          # passes recorded by a deferred update() (BaseEventWarping.defer_update); None: this window packs pass by pass
+        self.pending = []          # passes recorded by a deferred update() (BaseEventWarping.defer_update)
         self.pending_ptrs = set()  # storage of the event lists recorded so far (aliasing check of the deferred update)
         self.leases = []          # weak references to the tokens of evaluations whose autograd graph still reads the buffers
         self.cfg = None
@@ -200,8 +200,8 @@ class BaseEventWarping(torch.nn.Module):
         # loss-only caller; inside a training window update() hides behind the network on a side stream anyway).  The
         # in-place shift of the callers' time stamps (loss/flow.py:457-458) then happens at the evaluation, and the lists
         # must not be changed between update() and the evaluation (a list whose storage was already recorded in this window
-        # is detected: the recorded passes are then packed at once and the rest of the window goes pass by pass; a pass that
-        # takes the converting path, and reset(), pack the recorded passes first).  Off by default: reference behaviour.
+        # — one buffer reused for every pass — raises; a pass that takes the converting path, and reset(), pack the recorded
+        # passes first).  Off by default: reference behaviour.
         self.defer_update = bool(config["loss"].get("defer_update", False))
 
         # timescales for loss computation (loss/flow.py:42-44)
@@ -361,15 +361,16 @@ class BaseEventWarping(torch.nn.Module):
             # the pass is only recorded (its tensors stay referenced, nothing is launched, the caller's time stamps are not
             # shifted yet): _flush_updates() hands the whole window to the library in one call when the loss is evaluated.
             # A caller that REUSES one device buffer for the event lists of successive passes (a common loader pattern) would
-            # have every recorded pass packed from the buffer's last contents: a list whose storage is already recorded is
-            # detected here, the recorded passes are packed now and this window goes on pass by pass.
+            # have every recorded pass packed from the buffer's last contents — and by the time the second pass names the
+            # buffer the first one's data is gone: nothing to fall back to.  Detected and refused.
             ptrs_ = (event_list.data_ptr() if N else 0, d_event_list.data_ptr() if Nd else 0)
             seen = win.pending_ptrs
             if (ptrs_[0] and ptrs_[0] in seen) or (ptrs_[1] and ptrs_[1] in seen):
-                self._flush_updates()
-                win.pending = None               # (pass by pass from here to the end of the window)
-            else:
-                seen.update(p_ for p_ in ptrs_ if p_)
+                raise RuntimeError("defer_update: this pass's event list lives in storage that an earlier pass of the window "
+                                   "recorded and that has not been packed yet (one buffer reused for every pass?).  A "
+                                   "deferred update() needs the lists of all passes alive and unchanged until the loss is "
+                                   "evaluated: hand in a tensor per pass, or switch defer_update off")
+            seen.update(p_ for p_ in ptrs_ if p_)
         if self.defer_update and win.pending is not None:
             win.pending.append((list(flow_list), event_list, pol_mask, d_event_list, d_pol_mask, N, Nd, ovr, d_ovr, t, slot0, dslot0))
             win.grad.commit(N)
