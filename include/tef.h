@@ -340,6 +340,18 @@ int tef_convgru_cell_bwd(const tef_gru_desc *d, const float *x, const float *h, 
  * TEF_ACT_NONE on g).  dy: HOST array of device pointers.  out = the layer's activated output (unused for TEF_ACT_NONE). */
 int tef_grad_act(const float *const *dy, int ndy, const float *out, int act, int B, int C, int HW, float *g, float *dbias,
                  void *stream);
+/* The tail of a decoder level, backward, in ONE launch (round 6; models/arch.py:238-240: decoder convolution -> activation ->
+ * 1x1 prediction head -> activation).  `head` describes the 1x1 head (ksize 1, stride 1, C1 = 0, N <= 4, act = the head's
+ * activation); dec [B,C0,H,W] is the decoder convolution's ACTIVATED output (the head's input), pred [B,N,H,W] the head's.
+ *   gp      = (sum of the ndpred (1..4) tensors dpred[k]) * act'(pred)                  pre-activation gradient of the head
+ *   db_pred += per-channel sums of gp;   dw_pred [N,C0] += gp x dec over pixels         (either may be NULL)
+ *   gd      = dec_act'(dec) * (w2^T gp + dfeat)      dfeat: gradient reaching dec from its other consumer, or NULL
+ *   db_dec  += per-channel sums of gd                                                    (may be NULL)
+ * = tef_grad_act + tef_conv_backward_keep (1x1) + tef_grad_act, element for element the same operations in the same order.
+ * dpred: HOST array of device pointers; w2: the head's packed input-gradient operand (tef_conv_pack_weight). */
+int tef_dec_head_backward(const tef_conv_desc *head, const float *const *dpred, int ndpred, const float *pred, const float *w2,
+                          const float *dec, int dec_act, const float *dfeat, float *gp, float *gd, float *db_pred, float *dw_pred,
+                          float *db_dec, void *stream);
 /* out = act(a + b), n elements: the residual connection of ResidualBlock (models/submodules.py:219-226). */
 int tef_add_act(const float *a, const float *b, int act, size_t n, float *out, void *stream);
 

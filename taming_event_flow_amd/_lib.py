@@ -157,6 +157,8 @@ SIGNATURES = {
                              + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int] + [_fp] * 12 + [_fp, ctypes.c_size_t, _fp]),
     "tef_grad_act": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "tef_dec_head_backward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp, _fp, _fp,
+                                             ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "tef_add_act": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_size_t, _fp, _fp]),
     "tef_net_tape_floats": (ctypes.c_size_t, [ctypes.POINTER(NetPlan)]),
     "tef_net_gtape_floats": (ctypes.c_size_t, [ctypes.POINTER(NetPlan)]),

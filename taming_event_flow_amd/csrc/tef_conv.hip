@@ -1346,6 +1346,146 @@ __global__ __launch_bounds__(256) void pw_dw_kernel(const float *__restrict__ dy
     }
 }
 
+// ---- the tail of a decoder level, backward, in ONE launch (round 6) -----------------------------------------------------
+// models/arch.py:238-240 backward: prediction head (1x1, N <= 4 channels, tanh) and the decoder convolution's activation.
+//   gp[b][n][p]  = (sum_s dpred[s][b][n][p]) * act'(pred[b][n][p])
+//   db_pred[n]  += sum gp          dw_pred[n][c] += sum_{b, p} gp[b][n][p] * dec[b][c][p]
+//   gd[b][c][p]  = dec_act'(dec[b][c][p]) * (sum_n w2[c][n] gp[b][n][p] + dfeat[b][c][p])       (dfeat may be null)
+//   db_dec[c]   += sum gd
+// = grad_act_kernel (prediction) + pw_dx_kernel + pw_dw_kernel + grad_act_kernel (decoder) with the same operations in the
+// same order per element: four launches and a round trip of the [B, C, HW] input gradient (16.8 MB at the finest level)
+// become one sweep.  Thread = kDhPix pixels (256 apart) x a group of kDhCh channels; the per-channel sums are reduced per
+// wavefront through DPP, per workgroup through LDS, and leave as one atomic each.
+constexpr int kDhCh = 8;
+__device__ __forceinline__ float dh_wave_sum(float v)       // sum over the 64 lanes, valid in lane 63
+{
+#define TEF_DH_ADD(ctrl, rmask, bound) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, bound));
+    TEF_DH_ADD(0x111, 0xf, true) TEF_DH_ADD(0x112, 0xf, true) TEF_DH_ADD(0x114, 0xf, true) TEF_DH_ADD(0x118, 0xf, true)   // row_shr:1, 2, 4, 8
+    TEF_DH_ADD(0x142, 0xa, false)      // row_bcast:15 -> rows 1, 3
+    TEF_DH_ADD(0x143, 0xc, false)      // row_bcast:31 -> rows 2, 3
+#undef TEF_DH_ADD
+    return v;
+}
+__device__ __forceinline__ float dh_act_grad(float v, float y, int act)
+{
+    if (act == TEF_ACT_RELU) return y > 0.0f ? v : 0.0f;
+    if (act == TEF_ACT_TANH) return v * (1.0f - y * y);
+    if (act == TEF_ACT_SIGMOID) return v * (y * (1.0f - y));
+    return v;
+}
+struct DhSrc { const float *p[4]; int n; };
+// V = 4: a thread owns four consecutive pixels (16-byte loads and stores; HW % 4 == 0), V = 1: one pixel.  Every load of a
+// thread's channel group is issued before the first use.
+template <int V>
+__global__ __launch_bounds__(256) void dec_head_bwd_kernel(DhSrc dpred, const float *__restrict__ pred, int pred_act,
+                                                           const float *__restrict__ w2, int K2p, const float *__restrict__ dec,
+                                                           int dec_act, const float *__restrict__ dfeat, int B, int C, int N,
+                                                           int HW, float *__restrict__ gp, float *__restrict__ gd,
+                                                           float *__restrict__ db_pred, float *__restrict__ dw_pred,
+                                                           float *__restrict__ db_dec)
+{
+    __shared__ float red[4][kDhCh * (kPwMaxN + 1) + kPwMaxN];
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    const int M = B * HW, c0 = blockIdx.y * kDhCh, nc = min(kDhCh, C - c0);
+    float sgd[kDhCh], sw[kPwMaxN][kDhCh], sb[kPwMaxN];
+#pragma unroll
+    for (int j = 0; j < kDhCh; ++j) {
+        sgd[j] = 0.0f;
+#pragma unroll
+        for (int n = 0; n < kPwMaxN; ++n) sw[n][j] = 0.0f;
+    }
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) sb[n] = 0.0f;
+    const int m = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (m < M) {
+        const int b = m / HW, p = m - b * HW;
+        const size_t base = ((size_t)b * C + c0) * HW + p;
+        vec_t yv[kDhCh], fv[kDhCh];
+#pragma unroll
+        for (int j = 0; j < kDhCh; ++j) {
+            const size_t o = base + (size_t)(j < nc ? j : 0) * HW;
+            yv[j] = *reinterpret_cast<const vec_t *>(dec + o);
+            if (dfeat) fv[j] = *reinterpret_cast<const vec_t *>(dfeat + o);
+        }
+        vec_t g[kPwMaxN];
+#pragma unroll
+        for (int n = 0; n < kPwMaxN; ++n) {
+            if (n < N) {
+                const size_t o = ((size_t)b * N + n) * HW + p;
+                vec_t v = *reinterpret_cast<const vec_t *>(dpred.p[0] + o);
+                for (int s_ = 1; s_ < dpred.n; ++s_) v += *reinterpret_cast<const vec_t *>(dpred.p[s_] + o);
+                if (pred_act != TEF_ACT_NONE) {
+                    const vec_t y = *reinterpret_cast<const vec_t *>(pred + o);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) v[e] = dh_act_grad(v[e], y[e], pred_act);
+                }
+                g[n] = v;
+                if (blockIdx.y == 0) {
+                    *reinterpret_cast<vec_t *>(gp + o) = v;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) sb[n] += v[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kDhCh; ++j) {
+            if (j < nc) {
+                float wj[kPwMaxN];
+#pragma unroll
+                for (int n = 0; n < kPwMaxN; ++n) wj[n] = n < N ? w2[(size_t)(c0 + j) * K2p + n] : 0.0f;      // (wave-uniform)
+                vec_t out;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int n = 0; n < kPwMaxN; ++n)
+                        if (n < N) v += wj[n] * g[n][e];
+                    if (dfeat) v = v + fv[j][e];
+                    v = dh_act_grad(v, yv[j][e], dec_act);
+                    out[e] = v;
+                    sgd[j] += v;
+#pragma unroll
+                    for (int n = 0; n < kPwMaxN; ++n)
+                        if (n < N) sw[n][j] += g[n][e] * yv[j][e];
+                }
+                *reinterpret_cast<vec_t *>(gd + base + (size_t)j * HW) = out;
+            }
+        }
+    }
+    // per-channel sums: wavefront (DPP) -> workgroup (LDS) -> one atomic each
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < kDhCh; ++j) {
+        const float a = dh_wave_sum(sgd[j]);
+        if (lane == 63) red[wave][j] = a;
+#pragma unroll
+        for (int n = 0; n < kPwMaxN; ++n) {
+            if (n < N) {
+                const float w_ = dh_wave_sum(sw[n][j]);
+                if (lane == 63) red[wave][kDhCh * (1 + n) + j] = w_;
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < kPwMaxN; ++n) {
+        const float a = dh_wave_sum(sb[n]);
+        if (lane == 63) red[wave][kDhCh * (kPwMaxN + 1) + n] = a;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < kDhCh * (N + 1)) {
+        const int q = t / kDhCh, j = t - q * kDhCh;
+        if (j < nc) {
+            const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+            if (q == 0) { if (db_dec) atomicAdd(db_dec + c0 + j, v); }
+            else if (dw_pred) atomicAdd(dw_pred + (size_t)(q - 1) * C + c0 + j, v);
+        }
+    } else if (t >= 128 && t < 128 + N && blockIdx.y == 0 && db_pred) {
+        const int k = kDhCh * (kPwMaxN + 1) + (t - 128);
+        atomicAdd(db_pred + (t - 128), (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]));
+    }
+}
+
 // weight part [rows][Ct][ks][ks] -> rows [row0, row0 + rows) of
 //   wp [N][Kp]      k  = (ci, ky, kx)   forward A operand
 //   w2 [Ct][K2p]    k' = (n, ky, kx)    input-gradient A operand
@@ -2045,6 +2185,39 @@ int tef_conv_wgrad_parts(const tef_conv_desc *d, int nparts, const float *const 
         wp.A[p] = g[p]; wp.src0[p] = x0[p]; wp.src1[p] = d->C1 > 0 ? x1[p] : nullptr; wp.gate1[p] = gated ? gate1[p] : nullptr;
     }
     return conv_wgrad(d, q, wp.A[0], wp.src0[0], wp.src1[0], wp.gate1[0], wp, dweight, dweight2, split_rows, (hipStream_t)stream);
+}
+
+int tef_dec_head_backward(const tef_conv_desc *head, const float *const *dpred, int ndpred, const float *pred, const float *w2,
+                          const float *dec, int dec_act, const float *dfeat, float *gp, float *gd, float *db_pred, float *dw_pred,
+                          float *db_dec, void *stream)
+{
+    Geo q;
+    if (!make_geo(head, &q)) return TEF_ERR_INVALID;
+    if (!pointwise_small(head)) return tef::fail("tef_dec_head_backward: the head must be a 1x1 stride-1 convolution onto <= 4 channels"), TEF_ERR_INVALID;
+    if (!dpred || ndpred < 1 || ndpred > 4 || !w2 || !dec || !gp || !gd || (head->act != TEF_ACT_NONE && !pred))
+        return tef::fail("tef_dec_head_backward: null pointer / 1..4 gradient addends"), TEF_ERR_INVALID;
+    DhSrc src{};
+    src.n = ndpred;
+    for (int k = 0; k < ndpred; ++k) {
+        if (!dpred[k]) return tef::fail("tef_dec_head_backward: null gradient addend"), TEF_ERR_INVALID;
+        src.p[k] = dpred[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = q.Ho * q.Wo;
+    uintptr_t al = (uintptr_t)pred | (uintptr_t)dec | (uintptr_t)dfeat | (uintptr_t)gp | (uintptr_t)gd;
+    for (int k = 0; k < ndpred; ++k) al |= (uintptr_t)dpred[k];
+    const bool v4 = (HW & 3) == 0 && (al & 15) == 0;
+    dim3 grid((unsigned)((q.M + 256 * (v4 ? 4 : 1) - 1) / (256 * (v4 ? 4 : 1))), (unsigned)((head->C0 + kDhCh - 1) / kDhCh));
+    {
+        tef::ProfScope ps(tef::PROF_CONV_DGRAD, st);
+        if (v4)
+            hipLaunchKernelGGL(dec_head_bwd_kernel<4>, grid, dim3(256), 0, st, src, pred, head->act, w2, q.K2p, dec, dec_act, dfeat, head->B,
+                               head->C0, head->N, HW, gp, gd, db_pred, dw_pred, db_dec);
+        else
+            hipLaunchKernelGGL(dec_head_bwd_kernel<1>, grid, dim3(256), 0, st, src, pred, head->act, w2, q.K2p, dec, dec_act, dfeat, head->B,
+                               head->C0, head->N, HW, gp, gd, db_pred, dw_pred, db_dec);
+    }
+    return tef::check_launch("dec_head_bwd_kernel");
 }
 
 int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,

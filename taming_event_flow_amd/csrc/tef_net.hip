@@ -360,19 +360,30 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         if (d_prev_pred) srcs[ns++] = d_prev_pred;
         const float *feat[4];
         int nf = 0;
-        if (ns) {
-            TEF_TRY(tef_grad_act(srcs, ns, tape + t.p[k], p->final_act, g.B, p->nout, hw, gtape + q.gp[k], p->pred[k].db, stream));
-            TEF_TRY(conv_bwd(D.pred[k], p->pred[k], gtape + q.gp[k], tape + t.d[k], nullptr, gtape + q.dd[k], nullptr, ws, ws_bytes, stream));
+        // the 1x1 head (onto <= 4 channels) and the decoder's own activation gradient in ONE launch (round 6: four before —
+        // the head's pre-activation gradient, its input and weight gradients, the decoder's pre-activation gradient)
+        const bool fused = ns && D.pred[k].ksize == 1 && D.pred[k].stride == 1 && D.pred[k].C1 == 0 && D.pred[k].N <= 4;
+        if (fused) {
+            tef_conv_desc hd = D.pred[k];
+            hd.act = p->final_act;
+            TEF_TRY(tef_dec_head_backward(&hd, srcs, ns, tape + t.p[k], p->pred[k].w2, tape + t.d[k], TEF_ACT_RELU, d_feat, gtape + q.gp[k],
+                                          gtape + q.gd[k], p->pred[k].db, p->pred[k].dw, p->dec[k].db, stream));
             ran |= bit_pred(k);
-            feat[nf++] = gtape + q.dd[k];
+        } else {
+            if (ns) {
+                TEF_TRY(tef_grad_act(srcs, ns, tape + t.p[k], p->final_act, g.B, p->nout, hw, gtape + q.gp[k], p->pred[k].db, stream));
+                TEF_TRY(conv_bwd(D.pred[k], p->pred[k], gtape + q.gp[k], tape + t.d[k], nullptr, gtape + q.dd[k], nullptr, ws, ws_bytes, stream));
+                ran |= bit_pred(k);
+                feat[nf++] = gtape + q.dd[k];
+            }
+            if (d_feat) feat[nf++] = d_feat;
+            if (!nf) {          // nothing reaches this level (all its flow gradients absent): the chain is dead here
+                skip_grads[k] = nullptr;
+                d_prev_pred = d_feat = nullptr;
+                continue;
+            }
+            TEF_TRY(tef_grad_act(feat, nf, tape + t.d[k], TEF_ACT_RELU, g.B, g.out[k], hw, gtape + q.gd[k], p->dec[k].db, stream));
         }
-        if (d_feat) feat[nf++] = d_feat;
-        if (!nf) {          // nothing reaches this level (all its flow gradients absent): the chain is dead here
-            skip_grads[k] = nullptr;
-            d_prev_pred = d_feat = nullptr;
-            continue;
-        }
-        TEF_TRY(tef_grad_act(feat, nf, tape + t.d[k], TEF_ACT_RELU, g.B, g.out[k], hw, gtape + q.gd[k], p->dec[k].db, stream));
         const float *x0 = k ? tape + t.upp[k] : tape + t.upx[k], *x1 = k ? tape + t.upx[k] : nullptr;
         TEF_TRY(conv_bwd(D.dec[k], p->dec[k], gtape + q.gd[k], x0, x1, gtape + q.dx0[k], k ? gtape + q.dx1[k] : nullptr, ws, ws_bytes, stream));
         ran |= bit_dec(k);
