@@ -335,11 +335,38 @@ int tef_convgru_cell_bwd(const tef_gru_desc *d, const float *x, const float *h, 
                          const float *o, const float *const *dhn, int ndhn, const float *w2_ur, const float *w2_o,
                          float *g_ur, float *g_o, float *dx, float *dh, float *dw_u, float *dw_r, float *dw_o,
                          float *db_u, float *db_r, float *db_o, void *workspace, size_t workspace_bytes, void *stream);
+/* The same with the layer that PRODUCED x folded into the last sweep (round 6): when g_x is not NULL the call writes
+ * g_x [B,C,H,W] = x_act'(x) * (d loss / d x) — the pre-activation gradient of x's producer, e.g. the relu of a level's strided
+ * head convolution (models/submodules.py:95-101) — and db_x [C] += its per-channel sums (may be NULL) instead of dx (which may
+ * then be NULL): tef_grad_act's operations on the same values, one launch and one round trip of dx fewer. */
+int tef_convgru_cell_bwd_head(const tef_gru_desc *d, const float *x, const float *h, const float *u, const float *r,
+                              const float *o, const float *const *dhn, int ndhn, const float *w2_ur, const float *w2_o,
+                              float *g_ur, float *g_o, float *dx, float *dh, float *dw_u, float *dw_r, float *dw_o,
+                              float *db_u, float *db_r, float *db_o, int x_act, float *g_x, float *db_x, void *workspace,
+                              size_t workspace_bytes, void *stream);
 /* g [B,C,HW] = (sum of the ndy (1..4) tensors dy[k]) * act'(out), dbias [C] += per-channel sums of g (NULL to skip): the
  * pre-activation gradient of any conv layer whose output has several consumers (then tef_conv_backward* with
  * TEF_ACT_NONE on g).  dy: HOST array of device pointers.  out = the layer's activated output (unused for TEF_ACT_NONE). */
 int tef_grad_act(const float *const *dy, int ndy, const float *out, int act, int B, int C, int HW, float *g, float *dbias,
                  void *stream);
+/* Input gradient of a convolution whose input has ONE other role: it is the activated output of the layer before it
+ * (round 6: the residual blocks, models/submodules.py:207-227 — conv -> relu -> conv).  Instead of d loss / d x the call
+ * delivers that layer's pre-activation gradient
+ *     g_out [B,C0,H,W] = act'(mask) * (d loss / d x  +  addend)        dbias [C0] += per-channel sums of g_out
+ * (mask = the activated tensor x itself; addend [B,C0,H,W] = a gradient reaching x from another consumer, or NULL; dbias may
+ * be NULL) — tef_grad_act's operations on the same values.  Where the convolution is split over its reduction (the deep
+ * levels) this rides on the slabs' reduction launch; otherwise it costs one in-place sweep.  g [B,N,Ho,Wo]: the convolution's
+ * own pre-activation gradient (already formed: d->act must be TEF_ACT_NONE); dweight as in tef_conv_backward (NULL: skip /
+ * deferred).  One source (C1 = 0), not a 1x1 head. */
+typedef struct {
+    const float *mask;
+    int act;
+    const float *addend;
+    float *g_out;
+    float *dbias;
+} tef_conv_post;
+int tef_conv_backward_post(const tef_conv_desc *d, const float *x0, const float *w2, const float *g, float *dweight,
+                           const tef_conv_post *post, void *workspace, size_t workspace_bytes, void *stream);
 /* The tail of a decoder level, backward, in ONE launch (round 6; models/arch.py:238-240: decoder convolution -> activation ->
  * 1x1 prediction head -> activation).  `head` describes the 1x1 head (ksize 1, stride 1, C1 = 0, N <= 4, act = the head's
  * activation); dec [B,C0,H,W] is the decoder convolution's ACTIVATED output (the head's input), pred [B,N,H,W] the head's.

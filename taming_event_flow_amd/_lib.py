@@ -155,8 +155,12 @@ SIGNATURES = {
     "tef_convgru_cell_fwd": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 10 + [_fp, ctypes.c_size_t, _fp]),
     "tef_convgru_cell_bwd": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 5
                              + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int] + [_fp] * 12 + [_fp, ctypes.c_size_t, _fp]),
+    "tef_convgru_cell_bwd_head": (ctypes.c_int, [ctypes.POINTER(GruDesc)] + [_fp] * 5
+                                  + [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int] + [_fp] * 12 + [ctypes.c_int, _fp, _fp]
+                                  + [_fp, ctypes.c_size_t, _fp]),
     "tef_grad_act": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
                                     ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "tef_conv_backward_post": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, _fp, _fp, _fp, ctypes.c_void_p, _fp, ctypes.c_size_t, _fp]),
     "tef_dec_head_backward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp, _fp, _fp,
                                              ctypes.c_int, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "tef_add_act": (ctypes.c_int, [_fp, _fp, ctypes.c_int, ctypes.c_size_t, _fp, _fp]),

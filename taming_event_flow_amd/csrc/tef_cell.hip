@@ -197,6 +197,40 @@ __global__ __launch_bounds__(256) void cell_bwd_c_kernel(const float *__restrict
     }
 }
 
+// step C with the producer of x folded in (round 6): instead of dx = dx_a + dx_b, the pre-activation gradient of the layer that
+// made x — g_x = act'(x) * (dx_a + dx_b), db_x[n] += sum g_x (grad_act_kernel's operations on the same values) — and
+// dh += dh_c, in one channel-wise sweep.  In RecEVFlowNet x is the relu output of the level's strided head convolution.
+__global__ __launch_bounds__(256) void cell_bwd_c_head_kernel(const float *__restrict__ dx_a, const float *__restrict__ dx_b,
+                                                              const float *__restrict__ x, int x_act, float *__restrict__ g_x,
+                                                              float *__restrict__ db_x, const float *__restrict__ dh_c,
+                                                              float *__restrict__ dh, int B, int C, int HW)
+{
+    __shared__ float red[4];
+    const int n = blockIdx.y;
+    float local = 0.0f;
+    channel_loop(B, HW,
+        [&](int b, int p) {
+            const size_t i = ((size_t)b * C + n) * HW + p;
+            float4 v = add4(ld4(dx_a + i), ld4(dx_b + i));
+            if (x_act != TEF_ACT_NONE) {
+                const float4 y = ld4(x + i);
+                v = make_float4(act_grad(v.x, y.x, x_act), act_grad(v.y, y.y, x_act), act_grad(v.z, y.z, x_act), act_grad(v.w, y.w, x_act));
+            }
+            st4(g_x + i, v);
+            local += (v.x + v.y) + (v.z + v.w);
+            st4(dh + i, add4(ld4(dh + i), ld4(dh_c + i)));
+        },
+        [&](int b, int p) {
+            const size_t i = ((size_t)b * C + n) * HW + p;
+            float v = dx_a[i] + dx_b[i];
+            if (x_act != TEF_ACT_NONE) v = act_grad(v, x[i], x_act);
+            g_x[i] = v;
+            local += v;
+            dh[i] = dh[i] + dh_c[i];
+        });
+    if (db_x) block_add(local, db_x + n, red);
+}
+
 // out = act(a + b): the residual connection of ResidualBlock (models/submodules.py:219-226)
 __global__ __launch_bounds__(256) void add_act_kernel(const float *__restrict__ a, const float *__restrict__ b, int act,
                                                       size_t n, float *__restrict__ out)
@@ -271,8 +305,18 @@ int tef_convgru_cell_bwd(const tef_gru_desc *d, const float *x, const float *h, 
                          float *g_ur, float *g_o, float *dx, float *dh, float *dw_u, float *dw_r, float *dw_o,
                          float *db_u, float *db_r, float *db_o, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return tef_convgru_cell_bwd_head(d, x, h, u, r, o, dhn, ndhn, w2_ur, w2_o, g_ur, g_o, dx, dh, dw_u, dw_r, dw_o, db_u, db_r, db_o,
+                                     TEF_ACT_NONE, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+int tef_convgru_cell_bwd_head(const tef_gru_desc *d, const float *x, const float *h, const float *u, const float *r,
+                              const float *o, const float *const *dhn, int ndhn, const float *w2_ur, const float *w2_o,
+                              float *g_ur, float *g_o, float *dx, float *dh, float *dw_u, float *dw_r, float *dw_o,
+                              float *db_u, float *db_r, float *db_o, int x_act, float *g_x, float *db_x, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
     if (!gru_ok(d)) return TEF_ERR_INVALID;
-    if (!x || !h || !u || !r || !o || !w2_ur || !w2_o || !g_ur || !g_o || !dx || !dh || !workspace)
+    if (!x || !h || !u || !r || !o || !w2_ur || !w2_o || !g_ur || !g_o || (!dx && !g_x) || !dh || !workspace)
         return tef::fail("tef_convgru_cell_bwd: null pointer"), TEF_ERR_INVALID;
     if ((dw_u != nullptr) != (dw_r != nullptr)) return tef::fail("tef_convgru_cell_bwd: dw_u and dw_r go together"), TEF_ERR_INVALID;
     if (workspace_bytes < tef_convgru_workspace_bytes(d)) return tef::fail("tef_convgru_cell_bwd: workspace too small"), TEF_ERR_WORKSPACE;
@@ -296,6 +340,10 @@ int tef_convgru_cell_bwd(const tef_gru_desc *d, const float *x, const float *h, 
     if (int rc = tef::check_launch("cell_bwd_b_kernel")) return rc;
     if (int rc = tef_conv_backward_keep(&ur, x, h, nullptr, w2_ur, nullptr, nullptr, g_ur, nullptr, 2 * C, dx_b, dh_c, dw_u, dw_r,
                                         nullptr, nullptr, C, nullptr, cws, cws_bytes, stream)) return rc;
+    if (g_x) {      // the producer of x folded into the last sweep: its pre-activation gradient instead of dx
+        hipLaunchKernelGGL(cell_bwd_c_head_kernel, grid, dim3(256), 0, st, dx_a, dx_b, x, x_act, g_x, db_x, dh_c, dh, B, C, HW);
+        return tef::check_launch("cell_bwd_c_head_kernel");
+    }
     hipLaunchKernelGGL(cell_bwd_c_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1), 2), dim3(256), 0, st, dx_a, dx_b, dx, dh_c, dh, n);
     return tef::check_launch("cell_bwd_c_kernel");
 }

@@ -1156,6 +1156,54 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     }
 }
 
+// split-K epilogue of an INPUT GRADIENT whose only consumer is the pre-activation gradient of the layer that produced the
+// input (round 6: the residual blocks — dgrad -> relu' -> next dgrad):  g = act'(mask) * (sum_z slab[z][r][c] + addend),
+// dbias[r] += sum g, scattered to NCHW like splitk_reduce_kernel.  grad_act_kernel's operations on the same values; the
+// reduce launch and the activation-gradient launch become one.  z == 0: no slabs, g_out holds the input gradient already
+// (the convolution ran unsplit) and is rewritten in place.
+__global__ __launch_bounds__(256) void splitk_reduce_post_kernel(const float *__restrict__ slab, int z, int rows, int cols, int hw,
+                                                                 const float *__restrict__ mask, int act,
+                                                                 const float *__restrict__ addend, float *__restrict__ g_out,
+                                                                 float *__restrict__ dbias)
+{
+    const size_t plane = (size_t)rows * cols;
+    const bool vec = ((cols | hw) & 3) == 0;
+    const int per = vec ? 4 : 1, cq = cols / per;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = idx < (size_t)rows * cq;
+    const int r = in ? (int)(idx / cq) : 0, c = in ? (int)(idx - (size_t)r * cq) * per : 0;
+    const int img = c / hw, px = c - img * hw;
+    const size_t o = ((size_t)img * rows + r) * hw + px;
+    float local = 0.0f;
+    if (in) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (z == 0) {
+            for (int e = 0; e < per; ++e) v[e] = g_out[o + e];
+        } else {
+            const float *sp = slab + (size_t)r * cols + c;
+            for (int k = 0; k < z; ++k)
+                for (int e = 0; e < per; ++e) v[e] += sp[(size_t)k * plane + e];
+        }
+        for (int e = 0; e < per; ++e) {
+            float t = v[e];
+            if (addend) t = t + addend[o + e];
+            if (act != TEF_ACT_NONE) {
+                const float y = mask[o + e];
+                t = act == TEF_ACT_RELU ? (y > 0.0f ? t : 0.0f) : act == TEF_ACT_TANH ? t * (1.0f - y * y) : t * (y * (1.0f - y));
+            }
+            g_out[o + e] = t;
+            local += t;
+        }
+    }
+    if (!dbias) return;
+    if ((cq & 63) == 0) {          // a wavefront lies inside one row: one atomic per wavefront
+        for (int s_ = 32; s_ > 0; s_ >>= 1) local += __shfl_down(local, s_, 64);
+        if ((threadIdx.x & 63) == 0 && in) atomicAdd(dbias + r, local);
+    } else if (in) {
+        atomicAdd(dbias + r, local);
+    }
+}
+
 // split-K epilogue of the stride-2 input gradient (conv3x3_halo_kernel, S2D): slab rows = (parity class, channel), slab
 // columns = pixels (img, a, b) of the hg x wg output-gradient grid; dx[img][ci][2a + py][2b + px] = sum of the slabs.
 // One thread per pixel PAIR of the input row: it adds the px = 0 and px = 1 classes and stores 8 bytes.
@@ -2220,11 +2268,50 @@ int tef_dec_head_backward(const tef_conv_desc *head, const float *const *dpred, 
     return tef::check_launch("dec_head_bwd_kernel");
 }
 
+}  // extern "C"
+
+namespace {
+int conv_backward_impl(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                       const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
+                       int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
+                       float *dbias2, int split_rows, float *g_keep, void *workspace, size_t workspace_bytes,
+                       void *stream, const tef_conv_post *post);
+}
+
+extern "C" {
+
 int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
                            const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
                            int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
                            float *dbias2, int split_rows, float *g_keep, void *workspace, size_t workspace_bytes,
                            void *stream)
+{
+    return conv_backward_impl(d, x0, x1, gate1, w2, out, out2, dout, dout2, io_split, dx0, dx1, dweight, dweight2, dbias, dbias2,
+                              split_rows, g_keep, workspace, workspace_bytes, stream, nullptr);
+}
+
+int tef_conv_backward_post(const tef_conv_desc *d, const float *x0, const float *w2, const float *g, float *dweight,
+                           const tef_conv_post *post, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!d || !post || !post->g_out || (post->act != TEF_ACT_NONE && !post->mask))
+        return tef::fail("tef_conv_backward_post: null pointer"), TEF_ERR_INVALID;
+    if (d->C1 != 0 || d->act != TEF_ACT_NONE || pointwise_small(d))
+        return tef::fail("tef_conv_backward_post: one source, g already formed (TEF_ACT_NONE), not a 1x1 head"), TEF_ERR_INVALID;
+    return conv_backward_impl(d, x0, nullptr, nullptr, w2, nullptr, nullptr, g, nullptr, d->N, post->g_out, nullptr, dweight, nullptr,
+                              nullptr, nullptr, d->N, nullptr, workspace, workspace_bytes, stream, post);
+}
+
+}  // extern "C"
+
+namespace {
+// `post` (tef_conv_backward_post): the input gradient goes to post->g_out and is turned there into the pre-activation
+// gradient of the layer that produced the input — inside the split-K reduction when the convolution is split, by one
+// in-place sweep otherwise.
+int conv_backward_impl(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1,
+                       const float *w2, const float *out, const float *out2, const float *dout, const float *dout2,
+                       int io_split, float *dx0, float *dx1, float *dweight, float *dweight2, float *dbias,
+                       float *dbias2, int split_rows, float *g_keep, void *workspace, size_t workspace_bytes,
+                       void *stream, const tef_conv_post *post)
 {
     Geo q;
     if (!make_geo(d, &q)) return TEF_ERR_INVALID;
@@ -2273,6 +2360,17 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
         WgradParts none{};
         if (int rc = conv_wgrad(d, q, gsrc, x0, x1, gate1, none, dweight, dweight2, split_rows, st)) return rc;
     }
+    // post (tef_conv_backward_post): the reduction of z slabs — or, z == 0, one in-place sweep over the finished input
+    // gradient — forms act'(mask) * (dx + addend) and its per-channel sums
+    auto post_reduce = [&](int z) -> int {
+        const int hw_in = d->H * d->W;
+        const bool vec = ((q.Min | hw_in) & 3) == 0;
+        const size_t n = (size_t)q.Ct * (size_t)(vec ? q.Min / 4 : q.Min);
+        hipLaunchKernelGGL(splitk_reduce_post_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min, hw_in,
+                           post->mask, post->act, post->addend, post->g_out, post->dbias);
+        return tef::check_launch("splitk_reduce_post_kernel");
+    };
+    auto post_inplace = [&]() -> int { return (post && need_dx) ? post_reduce(0) : 0; };
     if (need_dx) {   // dx[ci][m'] = sum_{n,ky,kx} W[n][ci][ky][kx] * g[n][(m' + pad - k) / stride]
         GemmArgs g{};
         g.A = w2; g.lda = q.K2p; g.rows = q.Ct;
@@ -2297,7 +2395,10 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
             s.C = dx0; s.C2 = nullptr; s.split = 4 * q.Ct; s.bias = nullptr; s.act = TEF_ACT_NONE; s.hw = q.Ho * q.Wo;
             s.s2d_ct = q.Ct;
             int z = halo_splits(&gd, 4 * q.Ct, q.M, nch2);
-            if (z <= 1) return launch_halo_s2d<EPI_FWD>(s, logw, 1, st);
+            if (z <= 1) {
+                if (int rc = launch_halo_s2d<EPI_FWD>(s, logw, 1, st)) return rc;
+                return post_inplace();
+            }
             s.C = slab; s.ldc = q.M; s.valid_cols = q.M;
             s.ksplit = (nch2 + z - 1) / z;
             z = (nch2 + s.ksplit - 1) / s.ksplit;
@@ -2305,18 +2406,23 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
             size_t n = (size_t)2 * q.Ct * q.M;
             hipLaunchKernelGGL(splitk_reduce_s2d_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.M,
                                q.Ho, q.Wo, dx0);
-            return tef::check_launch("splitk_reduce_s2d_kernel");
+            if (int rc = tef::check_launch("splitk_reduce_s2d_kernel")) return rc;
+            return post_inplace();
         }
         if (int logw = halo_mode(d)) {      // stride 1: the gradient grid is the input grid; taps were flipped at pack time
             int nch2 = (N + HC - 1) / HC;
             g.A = w2 + (size_t)q.Ct * q.K2p; g.lda = nch2 * HK;
             int z = halo_splits(d, q.Ct, q.Min, nch2);
-            if (z <= 1) return launch_halo<EPI_FWD>(g, logw, 1, st);
+            if (z <= 1) {
+                if (int rc = launch_halo<EPI_FWD>(g, logw, 1, st)) return rc;
+                return post_inplace();
+            }
             g.C = slab; g.ldc = q.Min; g.valid_cols = q.Min;
             g.ksplit = (nch2 + z - 1) / z;
             z = (nch2 + g.ksplit - 1) / g.ksplit;
             if (int rc = launch_halo<EPI_SLAB>(g, logw, z, st)) return rc;
             size_t n = (size_t)q.Ct * q.Min;
+            if (post) return post_reduce(z);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min,
                                (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1, (const float *)nullptr, (const float *)nullptr,
                                (float *)nullptr);
@@ -2331,14 +2437,18 @@ int tef_conv_backward_keep(const tef_conv_desc *d, const float *x0, const float 
             z = (q.K2p + g.ksplit - 1) / g.ksplit;
             if (int rc = launch_gemm<A_PLAIN, B_GATHER, EPI_SLAB>(g, z, st)) return rc;
             size_t n = (size_t)q.Ct * q.Min;
+            if (post) return post_reduce(z);
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, slab, z, q.Ct, q.Min,
                                (const float *)nullptr, TEF_ACT_NONE, d->H * d->W, d->C0, dx0, dx1, (const float *)nullptr, (const float *)nullptr,
                                (float *)nullptr);
             if (int rc = tef::check_launch("splitk_reduce_kernel")) return rc;
         }
     }
-    return 0;
+    return post_inplace();
 }
+}  // namespace
+
+extern "C" {
 
 int tef_gru_blend(const float *h, const float *u, const float *o, size_t n, float *out, void *stream)
 {

@@ -214,6 +214,14 @@ int conv_bwd(const tef_conv_desc &d, const tef_net_conv &c, const float *g, cons
                                   defer ? nullptr : c.dw, nullptr, nullptr, nullptr, d.N, nullptr, ws, ws_bytes, stream);
 }
 
+// the same, delivering the pre-activation gradient of the layer that produced the input (tef_conv_backward_post)
+int conv_bwd_post(const tef_conv_desc &d, const tef_net_conv &c, const float *g, const float *x0, const tef_conv_post &post, void *ws,
+                  size_t ws_bytes, void *stream)
+{
+    const bool defer = c.defer && tef_conv_wgrad_parts_supported(&d);
+    return tef_conv_backward_post(&d, x0, c.w2, g, defer ? nullptr : c.dw, &post, ws, ws_bytes, stream);
+}
+
 }  // namespace
 
 extern "C" {
@@ -403,13 +411,25 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
     int ns = 0;
     if (skip_grads[0]) srcs[ns++] = skip_grads[0];
     const int hwt = g.h[g.top] * g.w[g.top], Ct = g.C[g.top];
+    // (round 6) conv -> relu -> conv chains: the input gradient of a convolution is turned into the pre-activation gradient of
+    // the layer before it by the convolution's own reduction launch (tef_conv_backward_post) — relu'(mid) * dmid inside a
+    // block, relu'(y[j-1]) * (dres[j] + gy[j]) between blocks — instead of a tef_grad_act launch each
+    bool gy_formed = false;               // gy[j] was formed by block j + 1's last input gradient
     for (int j = g.nres - 1; j >= 0 && ns && dec; --j) {
         const float *xin = j ? tape + t.y[j - 1] : tape + t.hn[g.top];
-        TEF_TRY(tef_grad_act(srcs, ns, tape + t.y[j], TEF_ACT_RELU, g.B, Ct, hwt, gtape + q.gy[j], p->res2[j].db, stream));
-        TEF_TRY(conv_bwd(D.res, p->res2[j], gtape + q.gy[j], tape + t.mid[j], nullptr, gtape + q.dmid[j], nullptr, ws, ws_bytes, stream));
-        const float *one[1] = {gtape + q.dmid[j]};
-        TEF_TRY(tef_grad_act(one, 1, tape + t.mid[j], TEF_ACT_RELU, g.B, Ct, hwt, gtape + q.gmid[j], p->res1[j].db, stream));
-        TEF_TRY(conv_bwd(D.res, p->res1[j], gtape + q.gmid[j], xin, nullptr, gtape + q.dres[j], nullptr, ws, ws_bytes, stream));
+        if (!gy_formed)
+            TEF_TRY(tef_grad_act(srcs, ns, tape + t.y[j], TEF_ACT_RELU, g.B, Ct, hwt, gtape + q.gy[j], p->res2[j].db, stream));
+        {
+            tef_conv_post post{tape + t.mid[j], TEF_ACT_RELU, nullptr, gtape + q.gmid[j], p->res1[j].db};
+            TEF_TRY(conv_bwd_post(D.res, p->res2[j], gtape + q.gy[j], tape + t.mid[j], post, ws, ws_bytes, stream));
+        }
+        if (j > 0) {
+            tef_conv_post post{tape + t.y[j - 1], TEF_ACT_RELU, gtape + q.gy[j], gtape + q.gy[j - 1], p->res2[j - 1].db};
+            TEF_TRY(conv_bwd_post(D.res, p->res1[j], gtape + q.gmid[j], xin, post, ws, ws_bytes, stream));
+            gy_formed = true;
+        } else {
+            TEF_TRY(conv_bwd(D.res, p->res1[j], gtape + q.gmid[j], xin, nullptr, gtape + q.dres[j], nullptr, ws, ws_bytes, stream));
+        }
         ran |= bit_res1(j) | bit_res2(j);
         srcs[0] = gtape + q.dres[j];      // through the two convolutions + the residual connection itself
         srcs[1] = gtape + q.gy[j];
@@ -447,14 +467,14 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         if (n > 4) return tef::fail("tef_net_pass_backward: more than four gradient addends at a state"), TEF_ERR_INVALID;
         const bool dur = p->gate_ur[i].defer && tef_conv_wgrad_parts_supported(&D.ur[i]);
         const bool dog = p->gate_o[i].defer && tef_conv_wgrad_parts_supported(&D.og[i]);
-        TEF_TRY(tef_convgru_cell_bwd(&D.gru[i], tape + t.e[i], states_in[i], tape + t.u[i], tape + t.r[i], tape + t.o[i], sources, n,
-                                     p->gate_ur[i].w2, p->gate_o[i].w2, gtape + q.g_ur[i], gtape + q.g_o[i], gtape + q.de[i], gtape + q.dh[i],
-                                     dur ? nullptr : p->gate_ur[i].dw, dur ? nullptr : p->gate_ur[i].dw2, dog ? nullptr : p->gate_o[i].dw,
-                                     p->gate_ur[i].db, p->gate_ur[i].db2, p->gate_o[i].db, ws, ws_bytes, stream));
+        // (the cell's last sweep also forms the head convolution's pre-activation gradient: relu'(e) * d loss / d e + its bias sums)
+        TEF_TRY(tef_convgru_cell_bwd_head(&D.gru[i], tape + t.e[i], states_in[i], tape + t.u[i], tape + t.r[i], tape + t.o[i], sources, n,
+                                          p->gate_ur[i].w2, p->gate_o[i].w2, gtape + q.g_ur[i], gtape + q.g_o[i], nullptr, gtape + q.dh[i],
+                                          dur ? nullptr : p->gate_ur[i].dw, dur ? nullptr : p->gate_ur[i].dw2, dog ? nullptr : p->gate_o[i].dw,
+                                          p->gate_ur[i].db, p->gate_ur[i].db2, p->gate_o[i].db, TEF_ACT_RELU, gtape + q.g_e[i], p->head[i].db,
+                                          ws, ws_bytes, stream));
         dstate_off[i] = (long long)q.dh[i];
         ran |= bit_ur(i) | bit_og(i);
-        const float *one[1] = {gtape + q.de[i]};
-        TEF_TRY(tef_grad_act(one, 1, tape + t.e[i], TEF_ACT_RELU, g.B, g.C[i], g.h[i] * g.w[i], gtape + q.g_e[i], p->head[i].db, stream));
         const bool want = i > 0 || want_dx;
         const float *xin = i ? tape + t.hn[i - 1] : x;
         TEF_TRY(conv_bwd(D.head[i], p->head[i], gtape + q.g_e[i], xin, nullptr, want ? gtape + q.dxin[i] : nullptr, nullptr, ws, ws_bytes, stream));
