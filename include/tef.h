@@ -237,6 +237,16 @@ size_t tef_conv_workspace_bytes(const tef_conv_desc *d);
 size_t tef_conv_packed_weight_floats(const tef_conv_desc *d, size_t *wp_floats, size_t *w2_floats);
 int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, int row0, float *wp, float *w2,
                          void *stream);
+/* The same for any number of weight parts (of any layers) in ONE launch: after an optimiser step a network re-packs every
+ * layer, and ~50 small launches one after the other kept the chip nearly empty for ~1 ms in front of the first convolution
+ * (round 6).  jobs: HOST array; a job = one tef_conv_pack_weight call's arguments. */
+typedef struct {
+    tef_conv_desc desc;
+    const float *weight;
+    int rows, row0;
+    float *wp, *w2;
+} tef_pack_job;
+int tef_conv_pack_weights(const tef_pack_job *jobs, int njobs, void *stream);
 /* out [B,N,Ho,Wo] = act(conv(cat[x0, x1 * gate1], weight) + bias), weight given as its packed form wp */
 int tef_conv_forward(const tef_conv_desc *d, const float *x0, const float *x1, const float *gate1, const float *wp,
                      const float *bias, float *out, void *workspace, size_t workspace_bytes, void *stream);

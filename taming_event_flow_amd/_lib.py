@@ -51,6 +51,13 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("B", "C0", "C1", "H", "W", "N", "ksize", "stride", "act")]
 
 
+class PackJob(ctypes.Structure):
+    """struct tef_pack_job (include/tef.h): one weight part of tef_conv_pack_weights"""
+
+    _fields_ = [("desc", ConvDesc), ("weight", ctypes.c_void_p), ("rows", ctypes.c_int), ("row0", ctypes.c_int),
+                ("wp", ctypes.c_void_p), ("w2", ctypes.c_void_p)]
+
+
 class GruDesc(ctypes.Structure):
     """struct tef_gru_desc (include/tef.h)"""
 
@@ -121,6 +128,7 @@ SIGNATURES = {
     "tef_conv_packed_weight_floats": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ctypes.c_size_t),
                                                         ctypes.POINTER(ctypes.c_size_t)]),
     "tef_conv_pack_weight": (ctypes.c_int, [ctypes.POINTER(ConvDesc), _fp, ctypes.c_int, ctypes.c_int, _fp, _fp, _fp]),
+    "tef_conv_pack_weights": (ctypes.c_int, [ctypes.POINTER(PackJob), ctypes.c_int, _fp]),
     "tef_upsample_bilinear": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_float, _fp, _fp]),
     "tef_upsample_bilinear_backward": (ctypes.c_int, [_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -1537,11 +1537,9 @@ __global__ __launch_bounds__(256) void dec_head_bwd_kernel(DhSrc dpred, const fl
 // weight part [rows][Ct][ks][ks] -> rows [row0, row0 + rows) of
 //   wp [N][Kp]      k  = (ci, ky, kx)   forward A operand
 //   w2 [Ct][K2p]    k' = (n, ky, kx)    input-gradient A operand
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int rows, int row0, int N,
-                                                          int Ct, int kk, int Kp, int K2p, float *__restrict__ wp,
-                                                          float *__restrict__ w2)
+__device__ __forceinline__ void pack_weight_item(size_t idx, const float *__restrict__ w, int rows, int row0, int N, int Ct, int kk,
+                                                 int Kp, int K2p, float *__restrict__ wp, float *__restrict__ w2)
 {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int K = Ct * kk;
     if (idx < (size_t)rows * Kp) {
         int n = (int)(idx / Kp), k = (int)(idx - (size_t)n * Kp);
@@ -1560,15 +1558,20 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restric
         w2[(size_t)ci * K2p + c] = v;
     }
 }
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *__restrict__ w, int rows, int row0, int N,
+                                                          int Ct, int kk, int Kp, int K2p, float *__restrict__ wp,
+                                                          float *__restrict__ w2)
+{
+    pack_weight_item((size_t)blockIdx.x * blockDim.x + threadIdx.x, w, rows, row0, N, Ct, kk, Kp, K2p, wp, w2);
+}
 
 // Halo-kernel operands of a 3x3 weight part [rows][Ct][3][3] (k-chunks of 8 channels, (tap, channel) inside a chunk):
 //   wh  [N][nch][9][8]     forward:        wh[n][chunk][tap][c]   = W[n][8 chunk + c][tap]
 //   w2h [Ct][nch2][9][8]   input gradient: w2h[ci][chunk][tap][c] = W[8 chunk + c][ci][8 - tap]   (taps flipped)
 // zero beyond Ct / N.  As pack_weight_kernel, a row part fills its own rows of wh and its own columns of w2h.
-__global__ __launch_bounds__(256) void pack_halo_kernel(const float *__restrict__ w, int rows, int row0, int N, int Ct,
-                                                        int nch, int nch2, float *__restrict__ wh, float *__restrict__ w2h)
+__device__ __forceinline__ void pack_halo_item(size_t idx, const float *__restrict__ w, int rows, int row0, int N, int Ct, int nch,
+                                               int nch2, float *__restrict__ wh, float *__restrict__ w2h)
 {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lda = nch * HK, lda2 = nch2 * HK;
     if (idx < (size_t)rows * lda) {
         int n = (int)(idx / lda), k = (int)(idx - (size_t)n * lda);
@@ -1584,14 +1587,18 @@ __global__ __launch_bounds__(256) void pack_halo_kernel(const float *__restrict_
         w2h[(size_t)ci * lda2 + (size_t)(n / HC) * HK + tap * HC + (n % HC)] = v;
     }
 }
+__global__ __launch_bounds__(256) void pack_halo_kernel(const float *__restrict__ w, int rows, int row0, int N, int Ct,
+                                                        int nch, int nch2, float *__restrict__ wh, float *__restrict__ w2h)
+{
+    pack_halo_item((size_t)blockIdx.x * blockDim.x + threadIdx.x, w, rows, row0, N, Ct, nch, nch2, wh, w2h);
+}
 
 // Stride-2 input gradient on the halo kernel (S2D): w2s [4 Ct][nch2][9][8], row = class (py, px) * Ct + ci, window tap
 // (ky', kx') reads g at (a + ky' - 1, b + kx' - 1).  Row 2a + py of the input meets output row a + dy through kernel row
 // ky = 1 (py = 0, dy = 0), ky = 2 (py = 1, dy = 0) or ky = 0 (py = 1, dy = 1); columns likewise; every other tap is zero.
-__global__ __launch_bounds__(256) void pack_s2d_kernel(const float *__restrict__ w, int rows, int row0, int N, int Ct,
-                                                       int nch2, float *__restrict__ w2s)
+__device__ __forceinline__ void pack_s2d_item(size_t idx, const float *__restrict__ w, int rows, int row0, int N, int Ct, int nch2,
+                                              float *__restrict__ w2s)
 {
-    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lda2 = nch2 * HK;
     int n_lo = row0, n_hi = (row0 + rows == N) ? nch2 * HC : row0 + rows;      // the last part also writes the padding
     int span = (n_hi - n_lo) * 9;
@@ -1603,6 +1610,44 @@ __global__ __launch_bounds__(256) void pack_s2d_kernel(const float *__restrict__
     int kx = px ? (kxw == 2 ? 0 : (kxw == 1 ? 2 : -1)) : (kxw == 1 ? 1 : -1);
     float v = (n < N && ky >= 0 && kx >= 0) ? w[((size_t)(n - row0) * Ct + ci) * 9 + ky * 3 + kx] : 0.0f;
     w2s[(size_t)row * lda2 + (size_t)(n / HC) * HK + tap * HC + (n % HC)] = v;
+}
+__global__ __launch_bounds__(256) void pack_s2d_kernel(const float *__restrict__ w, int rows, int row0, int N, int Ct,
+                                                       int nch2, float *__restrict__ w2s)
+{
+    pack_s2d_item((size_t)blockIdx.x * blockDim.x + threadIdx.x, w, rows, row0, N, Ct, nch2, w2s);
+}
+
+// Every weight part of a set of layers in ONE launch (round 6: tef_conv_pack_weights).  After an optimiser step the ~50 pack
+// launches of a window ran one after the other in front of the first convolutions — ~1 ms in which nothing but small pack
+// kernels was on the chip; as one launch the same 250 MB per half of the network move at the chip's rate.
+// A workgroup looks its job up in the block-offset table and works one chunk of kPackIter x 256 items of it.
+constexpr int kPackJobs = 40, kPackIter = 4;
+struct PackJob {
+    const float *w;
+    float *wp, *w2;
+    int rows, row0, N, Ct, kk, Kp, K2p, nch, nch2, halo, s2d;      // halo: 3x3 layouts too; s2d: the stride-2 input-gradient rows
+};
+struct PackJobs {
+    int n;
+    unsigned blk0[kPackJobs + 1];
+    PackJob job[kPackJobs];
+};
+__global__ __launch_bounds__(256) void pack_jobs_kernel(PackJobs J)
+{
+    int j = 0;
+    while (j + 1 < J.n && blockIdx.x >= J.blk0[j + 1]) ++j;
+    const PackJob &q = J.job[j];
+    const size_t first = (size_t)(blockIdx.x - J.blk0[j]) * (256 * kPackIter) + threadIdx.x;
+    float *wh = q.wp + (size_t)q.N * q.Kp, *w2h = q.w2 + (size_t)q.Ct * q.K2p;
+#pragma unroll
+    for (int it = 0; it < kPackIter; ++it) {
+        const size_t idx = first + (size_t)it * 256;
+        pack_weight_item(idx, q.w, q.rows, q.row0, q.N, q.Ct, q.kk, q.Kp, q.K2p, q.wp, q.w2);
+        if (q.halo) {
+            pack_halo_item(idx, q.w, q.rows, q.row0, q.N, q.Ct, q.nch, q.nch2, wh, w2h);
+            if (q.s2d) pack_s2d_item(idx, q.w, q.rows, q.row0, q.N, q.Ct, q.nch2, w2h);
+        }
+    }
 }
 
 // ConvGRU state update (models/submodules.py:150) and its backward.
@@ -2100,6 +2145,41 @@ int tef_conv_pack_weight(const tef_conv_desc *d, const float *weight, int rows, 
                                row0, d->N, q.Ct, nch2, w2 + (size_t)q.Ct * q.K2p);
             if (int rc = tef::check_launch("pack_s2d_kernel")) return rc;
         }
+    }
+    return 0;
+}
+
+int tef_conv_pack_weights(const tef_pack_job *jobs, int njobs, void *stream)
+{
+    if (njobs < 0 || (njobs && !jobs)) return tef::fail("tef_conv_pack_weights: bad arguments"), TEF_ERR_INVALID;
+    for (int j0 = 0; j0 < njobs; j0 += kPackJobs) {
+        PackJobs J{};
+        J.n = std::min(kPackJobs, njobs - j0);
+        unsigned blocks = 0;
+        for (int j = 0; j < J.n; ++j) {
+            const tef_pack_job &u = jobs[j0 + j];
+            const tef_conv_desc *d = &u.desc;
+            Geo q;
+            if (!make_geo(d, &q)) return TEF_ERR_INVALID;
+            if (!u.weight || !u.wp || !u.w2 || u.rows < 1 || u.row0 < 0 || u.row0 + u.rows > d->N)
+                return tef::fail("tef_conv_pack_weights: bad job"), TEF_ERR_INVALID;
+            PackJob &o = J.job[j];
+            o.w = u.weight; o.wp = u.wp; o.w2 = u.w2; o.rows = u.rows; o.row0 = u.row0; o.N = d->N; o.Ct = q.Ct; o.kk = q.kk;
+            o.Kp = q.Kp; o.K2p = q.K2p; o.nch = (q.Ct + HC - 1) / HC; o.nch2 = (d->N + HC - 1) / HC;
+            o.halo = d->ksize == 3; o.s2d = o.halo && s2d_mode(d, nullptr) ? 1 : 0;
+            const int c_lo = u.row0 * q.kk, c_hi = (u.row0 + u.rows == d->N) ? q.K2p : (u.row0 + u.rows) * q.kk;
+            size_t n = std::max((size_t)u.rows * q.Kp, (size_t)q.Ct * (c_hi - c_lo));
+            if (o.halo) {
+                const int n_hi = (u.row0 + u.rows == d->N) ? o.nch2 * HC : u.row0 + u.rows;
+                n = std::max(n, std::max((size_t)u.rows * o.nch * HK, (size_t)q.Ct * (n_hi - u.row0) * 9));
+                if (o.s2d) n = std::max(n, (size_t)4 * q.Ct * (n_hi - u.row0) * 9);
+            }
+            J.blk0[j] = blocks;
+            blocks += (unsigned)((n + 256 * kPackIter - 1) / (256 * kPackIter));
+        }
+        J.blk0[J.n] = blocks;
+        hipLaunchKernelGGL(pack_jobs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, J);
+        if (int rc = tef::check_launch("pack_jobs_kernel")) return rc;
     }
     return 0;
 }

@@ -29,6 +29,7 @@ The flows then live on the side stream: whoever consumes them either works on th
 """
 
 import ctypes
+import os
 import weakref
 
 import torch
@@ -121,8 +122,8 @@ class PassEngine:
         return z
 
     # ---- the plan ----------------------------------------------------------------------------------------------
-    def _conv_fields(self, nc, packer, weights, biases, desc):
-        wp, wt = packer.get(weights, desc)
+    def _conv_fields(self, nc, packer, weights, biases, desc, batch=None):
+        wp, wt = packer.get(weights, desc, batch)      # (stale operands: queued in `batch`, packed by make_plan in one launch)
         bias = packer.bias(biases)
         nc.wp, nc.w2, nc.bias = wp.data_ptr(), wt.data_ptr(), _p(bias)
 
@@ -144,36 +145,39 @@ class PassEngine:
                 pl.width[i] = c
                 pl.dec_out[i] = dec_rows[i].cout
         cin, h, w = np_.num_bins, Hp, Wp
+        batch = []      # weight parts to (re-)pack: all of a half of the network in ONE launch (after an optimiser step)
         for i, enc in enumerate(a.encoders):
             c = np_.width[i]
             if part & 1:
                 self._conv_fields(pl.head[i], enc.conv._packed, (enc.conv.conv2d.weight,), (enc.conv.conv2d.bias,),
-                                  _lib.ConvDesc(B, cin, 0, h, w, c, 3, np_.stride, ACT["relu"]))
+                                  _lib.ConvDesc(B, cin, 0, h, w, c, 3, np_.stride, ACT["relu"]), batch)
             h, w = h // 2, w // 2
             g = enc.recurrent_block
             if part & 1:
                 self._conv_fields(pl.gate_ur[i], g._packed_ur, (g.update_gate.weight, g.reset_gate.weight),
-                                  (g.update_gate.bias, g.reset_gate.bias), _lib.ConvDesc(B, c, c, h, w, 2 * c, 3, 1, ACT["sigmoid"]))
+                                  (g.update_gate.bias, g.reset_gate.bias), _lib.ConvDesc(B, c, c, h, w, 2 * c, 3, 1, ACT["sigmoid"]), batch)
                 self._conv_fields(pl.gate_o[i], g._packed_o, (g.out_gate.weight,), (g.out_gate.bias,),
-                                  _lib.ConvDesc(B, c, c, h, w, c, 3, 1, ACT["tanh"]))
+                                  _lib.ConvDesc(B, c, c, h, w, c, 3, 1, ACT["tanh"]), batch)
             cin = c
+        sm.run_pack_jobs(batch)
         if not (part & 2):
             return pl
         top = np_.width[-1]
         for j, rb in enumerate(a.resblocks):
             d = _lib.ConvDesc(B, top, 0, h, w, top, 3, 1, ACT["relu"])
-            self._conv_fields(pl.res1[j], rb._packed1, (rb.conv1.weight,), (rb.conv1.bias,), d)
-            self._conv_fields(pl.res2[j], rb._packed2, (rb.conv2.weight,), (rb.conv2.bias,), d)
+            self._conv_fields(pl.res1[j], rb._packed1, (rb.conv1.weight,), (rb.conv1.bias,), d, batch)
+            self._conv_fields(pl.res2[j], rb._packed2, (rb.conv2.weight,), (rb.conv2.bias,), d, batch)
         src = top
         for k, (dec, head) in enumerate(zip(a.decoders, a.preds)):
             h, w = h * 2, w * 2
             c0, c1 = (np_.nout, src) if k else (src, 0)
             out = dec_rows[k].cout
             self._conv_fields(pl.dec[k], dec._packed, (dec.conv2d.weight,), (dec.conv2d.bias,),
-                              _lib.ConvDesc(B, c0, c1, h, w, out, 3, 1, ACT["relu"]))
+                              _lib.ConvDesc(B, c0, c1, h, w, out, 3, 1, ACT["relu"]), batch)
             self._conv_fields(pl.pred[k], head._packed, (head.conv2d.weight,), (head.conv2d.bias,),
-                              _lib.ConvDesc(B, out, 0, h, w, np_.nout, 1, 1, ACT[np_.final_activation]))
+                              _lib.ConvDesc(B, out, 0, h, w, np_.nout, 1, 1, ACT[np_.final_activation]), batch)
             src = out
+        sm.run_pack_jobs(batch)
         return pl
 
     def layout(self, pl):

@@ -63,24 +63,42 @@ class PackedWeights:
             self.bias_key = key
         return self.bias_cat
 
-    def get(self, weights, desc):
+    def get(self, weights, desc, batch=None):
+        """-> (wp, w2).  `batch` (a list): a stale layer only queues its pack jobs there — the caller runs them all in ONE
+        launch with run_pack_jobs(batch) before anything reads the operands (models/engine.py: a network after an optimiser
+        step)."""
         key = tuple((w.data_ptr(), w._version) for w in weights) + (desc.C0 + desc.C1, desc.N, desc.ksize)
         if key != self.key:
             lib = _lib.lib()
             np_, nt = ctypes.c_size_t(), ctypes.c_size_t()
             lib.tef_conv_packed_weight_floats(ctypes.byref(desc), ctypes.byref(np_), ctypes.byref(nt))
             dev = weights[0].device
-            self.wp = torch.empty((np_.value,), dtype=torch.float32, device=dev)
-            self.wt = torch.empty((nt.value,), dtype=torch.float32, device=dev)
-            row0 = 0
+            if self.wp is None or self.wp.numel() != np_.value or self.wt.numel() != nt.value or self.wp.device != dev:
+                self.wp = torch.empty((np_.value,), dtype=torch.float32, device=dev)
+                self.wt = torch.empty((nt.value,), dtype=torch.float32, device=dev)
+            row0, jobs = 0, []
             for w in weights:
                 wc = w.detach().contiguous()
-                rc = lib.tef_conv_pack_weight(ctypes.byref(desc), wc.data_ptr(), wc.shape[0], row0, self.wp.data_ptr(),
-                                              self.wt.data_ptr(), _lib.stream_ptr())
-                _lib.check(rc, "tef_conv_pack_weight")
+                jobs.append((desc, wc, wc.shape[0], row0, self.wp, self.wt))
                 row0 += wc.shape[0]
+            if batch is None:
+                run_pack_jobs(jobs)
+            else:
+                batch.extend(jobs)
             self.key = key
         return self.wp, self.wt
+
+
+def run_pack_jobs(jobs):
+    """The queued weight parts (PackedWeights.get) in one launch on the current stream: include/tef.h tef_conv_pack_weights."""
+    if not jobs:
+        return
+    arr = (_lib.PackJob * len(jobs))()
+    for a, (desc, wc, rows, row0, wp, wt) in zip(arr, jobs):
+        a.desc = desc
+        a.weight, a.rows, a.row0, a.wp, a.w2 = wc.data_ptr(), rows, row0, wp.data_ptr(), wt.data_ptr()
+    _lib.check(_lib.lib().tef_conv_pack_weights(arr, len(jobs), _lib.stream_ptr()), "tef_conv_pack_weights")
+    del jobs[:]          # (the caller's list: a second call packs only what was queued since)
 
 
 class _ConvFn(torch.autograd.Function):
