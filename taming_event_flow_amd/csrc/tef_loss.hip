@@ -485,6 +485,20 @@ __device__ __forceinline__ void flag_bad_events(int *__restrict__ bad, int slot,
     if (threadIdx.x == 0) bad[slot] = any;
 }
 
+// Streaming accesses — trajectory planes out of K1 and into K6, per-map vectors out of K6 — carry the non-temporal hint so
+// that they do not push the gathered, re-used data (flow maps, (A, C + eps) images) out of the XCD's L2.  (Round 6: K1's
+// plane stores too: K2 -2 us, K6 -2 us, the step 0.626 -> 0.619 ms.)
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 NT_LD2(const float2 *p)
+{
+    f32x2_v v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_v *>(p));
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ void NT_ST2(float2 *p, float a, float b)
+{
+    f32x2_v v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x2_v *>(p));
+}
 // =============================================================================================
 // K1 (Iterative): iterative warping of every event to every reference time.
 // loss/flow.py:521-586 event_warping, :492-519 update_warping_indices, :599-654.
@@ -534,7 +548,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
         return quad_value(load_quad(map, q, H * W), q);
     };
     store_row_range(rng, w.nplanes, valid, y0, in_list);
-    if (in_list) tr[(size_t)w.nplanes * w.Mt] = make_float2(y0, x0);      // plane nplanes: where pass t sampled its own map (K7)
+    if (in_list) NT_ST2(&tr[(size_t)w.nplanes * w.Mt], y0, x0);      // plane nplanes: where pass t sampled its own map (K7)
     // flow at the original location, shared by the first forward and the first backward step
     float2 f0 = make_float2(0.0f, 0.0f);
     if (valid) f0 = lookup(y0, x0, t);
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
                 }
                 y = y + dt * f.x;
                 x = x + dt * f.y;
-                if (kept) tr[(size_t)(k + 1) * w.Mt] = make_float2(y, x);
+                if (kept) NT_ST2(&tr[(size_t)(k + 1) * w.Mt], y, x);
                 if (!inbounds(y, x, H, W)) { kf = k + 1; alive = false; }       // cumulative purge, loss/flow.py:575
             }
             store_row_range(rng, min(k + 1, P), alive, y, kept && in_list);
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256) void iter_warp_kernel(Win w, const float2 *__r
                 }
                 y = y + dt * f.x;
                 x = x + dt * f.y;
-                if (kept) tr[(size_t)k * w.Mt] = make_float2(y, x);
+                if (kept) NT_ST2(&tr[(size_t)k * w.Mt], y, x);
                 if (!inbounds(y, x, H, W)) { kb = k; alive = false; }
             }
             store_row_range(rng, max(k, 0), alive, y, kept && in_list);
@@ -1017,6 +1031,7 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
     const int nitems = w.nimg * FB, nsub = 2 * nbands;
     for (int k = threadIdx.x; k < (kSplat2Threads / 64) * kRing; k += blockDim.x) hit_ring[k] = 0;      // (stale entries are read, as rows)
     if (threadIdx.x == 0) s_item = atomicAdd(&queue[xcd], 1);
+    lds_plane_zero(lds_img, 2 * (min(H, rows_per_band) + 2) * WP);
     __syncthreads();
     for (;;) {
         const int q = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: everything derived from it is scalar
@@ -1031,7 +1046,8 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
         // planes: [C | T], each nrows + 2 rows (halo row, the band, halo row) of WP accumulators
         const size_t plane_sz = (size_t)(nrows + 2) * WP;
         double *img_c = lds_img, *img_t = lds_img + plane_sz;
-        lds_plane_zero(lds_img, 2 * (nrows + 2) * WP);         // all-zero bits: 0.0 and integer 0 alike
+        // (the planes are all zero here — cleared once before the first item, then by every item's statistics read-out: the
+        // thread that has read a pixel's accumulators clears them, halo rows included; all-zero bits are 0.0 and integer 0 alike)
         // run list of the integer path (the [pos-only] or [neg-only] slots of every pass / list) + accumulator choice
         const int nb = im.he - im.le, nlists = w.Md > 0 ? 2 : 1, nruns = nb * nlists;
         if (threadIdx.x < 2) s_flags[threadIdx.x] = 0;
@@ -1214,8 +1230,8 @@ __global__ __launch_bounds__(kSplat2Threads, 4) void splat_stats_kernel(Win w, E
         float acc = 0.0f;
         const size_t qpol = ((size_t)j * FB + ib) * 2 + c, o = qpol * HW + (size_t)r0 * W;
         unsigned long long *nzo = nzw + (qpol * nbands + band) * nz_cap;
-        if (fixed) band_stats<true, false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
-        else band_stats<false, false>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
+        if (fixed) band_stats<true, true>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
+        else band_stats<false, true>(lds_img + WP, plane_sz, nrows, W, WP, ar + o, nzo, acc);
         const double dacc = wave_sum_to_last((double)acc);
         if ((threadIdx.x & 63) == 63) part[(qpol * nbands + band) * kSplat2Waves + (threadIdx.x >> 6)] = dacc;      // (image_count_kernel adds the wavefronts' shares, fixed order)
         if (threadIdx.x == 0) s_item = next_item;
@@ -1485,17 +1501,6 @@ __global__ __launch_bounds__(256) void mag_reduce_kernel(const uint32_t *__restr
     if (threadIdx.x == 0) cmax[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
-typedef float f32x2_v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 NT_LD2(const float2 *p)
-{
-    f32x2_v v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_v *>(p));
-    return make_float2(v.x, v.y);
-}
-__device__ __forceinline__ void NT_ST2(float2 *p, float a, float b)
-{
-    f32x2_v v = {a, b};
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x2_v *>(p));
-}
 
 // ONE: a single temporal scale (scales_loss = 1, the headline configuration).  The kernel is VALU-bound (~450 vector
 // instructions per chain step, 2.9e7 steps per BASELINE window): the per-step scale loop with its integer division
