@@ -47,6 +47,11 @@ const char *tef_last_error(void);
 int tef_profile_enable(int on);
 int tef_profile_pause(int paused);      /* stop / resume recording without clearing what was recorded (sampled timing) */
 int tef_profile_collect(void);
+/* Per-layer attribution of the network passes (round 6): while profiling is on, tef_net_pass_forward / _backward /
+ * tef_net_window_wgrads bracket every layer and direction ("enc1.gru.ur fwd", "dec2 dgrad", "res0.conv1 wgrad" ...) with an
+ * event pair on the launch stream — meaningful when the window runs on ONE stream.  After tef_profile_collect: lines
+ * "label,scopes,ms" into buf (NUL-terminated, truncated to nbytes); returns the full length. */
+long tef_profile_layers(char *buf, size_t nbytes);
 int tef_profile_slots(void);
 const char *tef_profile_name(int slot);
 double tef_profile_ms(int slot);
@@ -423,6 +428,14 @@ typedef struct tef_net_plan {
     tef_net_conv head[TEF_NET_MAX_LEVELS], gate_ur[TEF_NET_MAX_LEVELS], gate_o[TEF_NET_MAX_LEVELS];
     tef_net_conv res1[TEF_NET_MAX_RES], res2[TEF_NET_MAX_RES];
     tef_net_conv dec[TEF_NET_MAX_LEVELS], pred[TEF_NET_MAX_LEVELS];
+    /* (round 6) the decoder half of SEVERAL passes as one batch.  Only the recurrent states cross passes (models/arch.py:
+     * 225-227), so the residual blocks, decoders and heads of the P passes of a loss window are independent of each other:
+     * with B = P x (samples) and hn_ext[i] = the passes' new states of level i stacked along the batch ([P*B, C_i, h_i, w_i]),
+     * tef_net_pass_forward_part / _backward_part / tef_net_window_wgrads_part with TEF_NET_DECODERS run that half ONCE per
+     * window — ten times fewer launches, and the deep levels' 512-pixel GEMMs (split over k 16..32 ways, 50 TFLOP/s) become
+     * 5120-pixel ones (110 TFLOP/s).  dec_only = 1: the arenas hold no encoder buffers (tef_net_tape_floats etc. follow). */
+    const float *hn_ext[TEF_NET_MAX_LEVELS];
+    int dec_only;
 } tef_net_plan;
 size_t tef_net_tape_floats(const tef_net_plan *p);
 size_t tef_net_gtape_floats(const tef_net_plan *p);

@@ -86,6 +86,7 @@ class NetPlan(ctypes.Structure):
         ("head", NetConv * TEF_NET_MAX_LEVELS), ("gate_ur", NetConv * TEF_NET_MAX_LEVELS),
         ("gate_o", NetConv * TEF_NET_MAX_LEVELS), ("res1", NetConv * TEF_NET_MAX_RES), ("res2", NetConv * TEF_NET_MAX_RES),
         ("dec", NetConv * TEF_NET_MAX_LEVELS), ("pred", NetConv * TEF_NET_MAX_LEVELS),
+        ("hn_ext", _fp * TEF_NET_MAX_LEVELS), ("dec_only", ctypes.c_int),
     ]
 
 # name -> (restype, argtypes); every symbol include/tef.h declares
@@ -95,6 +96,7 @@ SIGNATURES = {
     "tef_profile_enable": (ctypes.c_int, [ctypes.c_int]),
     "tef_profile_pause": (ctypes.c_int, [ctypes.c_int]),
     "tef_profile_collect": (ctypes.c_int, []),
+    "tef_profile_layers": (ctypes.c_long, [ctypes.c_char_p, ctypes.c_size_t]),
     "tef_profile_slots": (ctypes.c_int, []),
     "tef_profile_name": (ctypes.c_char_p, [ctypes.c_int]),
     "tef_profile_ms": (ctypes.c_double, [ctypes.c_int]),

@@ -33,6 +33,18 @@ struct ProfScope {
     ~ProfScope() { prof_end(slot, st); }
 };
 
+// Per-LAYER attribution (round 6): a named scope around everything a network layer enqueues in one direction (its
+// convolution launches AND the reduce / activation launches that belong to it); collected with the slots above and read
+// back as text through tef_profile_layers.  Only meaningful on ONE stream (an event pair measures what the stream did in
+// between).  `label` must outlive the collection (static storage).
+void layer_begin(const char *label, hipStream_t st);
+void layer_end(hipStream_t st);
+struct LayerScope {
+    hipStream_t st;
+    LayerScope(const char *label, hipStream_t stream) : st(stream) { layer_begin(label, st); }
+    ~LayerScope() { layer_end(st); }
+};
+
 }  // namespace tef
 
 #endif

@@ -4,6 +4,9 @@
 
 #include "tef_common.h"
 
+#include <algorithm>
+#include <map>
+#include <string>
 #include <vector>
 
 namespace {
@@ -21,6 +24,11 @@ long g_calls[tef::PROF_NSLOTS];
 std::vector<Pending> g_pending;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t g_open[tef::PROF_NSLOTS];
+struct LayerPending { const char *label; hipEvent_t a, b; };
+std::vector<LayerPending> g_layer_pending;
+const char *g_layer_open = nullptr;
+hipEvent_t g_layer_open_ev = nullptr;
+std::map<std::string, std::pair<long, double>> g_layers;      // label -> (scopes, ms)
 
 hipEvent_t get_event()
 {
@@ -82,6 +90,23 @@ void prof_end(int slot, hipStream_t st)
     g_pending.push_back(Pending{slot, g_open[slot], e});
 }
 
+void layer_begin(const char *label, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    g_layer_open = label;
+    g_layer_open_ev = get_event();
+    (void)hipEventRecord(g_layer_open_ev, st);
+}
+
+void layer_end(hipStream_t st)
+{
+    if (!g_prof_on || !g_layer_open) return;
+    hipEvent_t e = get_event();
+    (void)hipEventRecord(e, st);
+    g_layer_pending.push_back(LayerPending{g_layer_open, g_layer_open_ev, e});
+    g_layer_open = nullptr;
+}
+
 }  // namespace tef
 
 extern "C" {
@@ -89,6 +114,10 @@ extern "C" {
 int tef_profile_enable(int on)
 {
     g_prof_on = on != 0;
+    for (auto &p : g_layer_pending) { g_pool.push_back(p.a); g_pool.push_back(p.b); }
+    g_layer_pending.clear();
+    g_layers.clear();
+    g_layer_open = nullptr;
     for (int i = 0; i < tef::PROF_NSLOTS; ++i) { g_ms[i] = 0.0; g_calls[i] = 0; }
     for (auto &p : g_pending) { g_pool.push_back(p.a); g_pool.push_back(p.b); }
     g_pending.clear();
@@ -111,7 +140,35 @@ int tef_profile_collect(void)
         g_pool.push_back(p.b);
     }
     g_pending.clear();
+    for (auto &p : g_layer_pending) {
+        if (hipEventSynchronize(p.b) != hipSuccess) return tef::fail("tef_profile_collect: event sync failed"), TEF_ERR_LAUNCH;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            auto &e = g_layers[p.label];
+            e.first += 1;
+            e.second += ms;
+        }
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
+    }
+    g_layer_pending.clear();
     return 0;
+}
+
+long tef_profile_layers(char *buf, size_t nbytes)
+{
+    std::string out;
+    char line[160];
+    for (auto &kv : g_layers) {
+        snprintf(line, sizeof(line), "%s,%ld,%.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if (buf && nbytes) {
+        const size_t n = std::min(out.size(), nbytes - 1);
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (long)out.size();
 }
 
 int tef_profile_slots(void) { return tef::PROF_NSLOTS; }

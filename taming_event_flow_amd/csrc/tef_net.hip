@@ -19,7 +19,11 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdio.h>
+
 #include <algorithm>
+#include <map>
+#include <string>
 
 #include "tef.h"
 #include "tef_common.h"
@@ -96,7 +100,7 @@ Tape make_tape(const tef_net_plan *p, const Geo &g)
 {
     Tape t{};
     size_t o = 0;
-    for (int i = 0; i < g.lv; ++i) {
+    for (int i = 0; i < g.lv && !p->dec_only; ++i) {      // (a decoder-only arena reads the states through plan.hn_ext)
         t.e[i] = take(o, g.n[i]); t.u[i] = take(o, g.n[i]); t.r[i] = take(o, g.n[i]); t.o[i] = take(o, g.n[i]);
         t.hn[i] = take(o, g.n[i]);
     }
@@ -118,7 +122,7 @@ GTape make_gtape(const tef_net_plan *p, const Geo &g)
 {
     GTape t{};
     size_t o = 0;
-    for (int i = 0; i < g.lv; ++i) {
+    for (int i = 0; i < g.lv && !p->dec_only; ++i) {
         t.g_e[i] = take(o, g.n[i]); t.g_ur[i] = take(o, 2 * g.n[i]); t.g_o[i] = take(o, g.n[i]);
         t.de[i] = take(o, g.n[i]); t.dh[i] = take(o, g.n[i]);
         const size_t nin = i ? g.n[i - 1] : (size_t)p->B * p->bins * p->H * p->W;
@@ -179,14 +183,23 @@ size_t workspace_need(const tef_net_plan *p, const Geo &g)
     const Descs D = make_descs(p, g, 1);
     size_t m = tef_conv_workspace_bytes(&D.res);
     for (int i = 0; i < g.lv; ++i) {
-        m = std::max(m, tef_conv_workspace_bytes(&D.head[i]));
-        m = std::max(m, tef_conv_workspace_bytes(&D.ur[i]));
-        m = std::max(m, tef_conv_workspace_bytes(&D.og[i]));
-        m = std::max(m, tef_convgru_workspace_bytes(&D.gru[i]));
+        if (!p->dec_only) {
+            m = std::max(m, tef_conv_workspace_bytes(&D.head[i]));
+            m = std::max(m, tef_conv_workspace_bytes(&D.ur[i]));
+            m = std::max(m, tef_conv_workspace_bytes(&D.og[i]));
+            m = std::max(m, tef_convgru_workspace_bytes(&D.gru[i]));
+        }
         m = std::max(m, tef_conv_workspace_bytes(&D.dec[i]));
         m = std::max(m, tef_conv_workspace_bytes(&D.pred[i]));
     }
     return m;
+}
+
+// the new state of level i of the pass(es) a plan describes: in the pass's own arena, or (decoder half of a whole window as
+// one batch) the caller's stack of the passes' states
+inline const float *state_of(const tef_net_plan *p, const Tape &t, const float *tape, int i)
+{
+    return p->hn_ext[i] ? p->hn_ext[i] : tape + t.hn[i];
 }
 
 // layer bits of the "ran" mask a backward call reports (which pre-activation gradients of the arena are valid)
@@ -197,6 +210,16 @@ inline uint64_t bit_res1(int j) { return 1ull << (24 + j); }
 inline uint64_t bit_res2(int j) { return 1ull << (28 + j); }
 inline uint64_t bit_dec(int k) { return 1ull << (32 + k); }
 inline uint64_t bit_pred(int k) { return 1ull << (40 + k); }
+
+// static label strings of the per-layer profiling scopes (tef::LayerScope): "enc1.head fwd", "dec2 dgrad", ...
+const char *lbl(const char *fmt, int idx)
+{
+    static std::map<std::string, std::string> table;      // (node addresses are stable)
+    char buf[64];
+    snprintf(buf, sizeof(buf), fmt, idx);
+    return table.emplace(buf, buf).first->second.c_str();
+}
+#define TEF_LAYER(fmt, idx) tef::LayerScope layer_scope_(lbl(fmt, idx), (hipStream_t)stream)
 
 #define TEF_TRY(call)                 \
     do {                              \
@@ -283,19 +306,29 @@ int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, c
         const float *cur = x;
         for (int i = 0; i < g.lv; ++i) {
             if (!states_in[i]) return tef::fail("tef_net_pass_forward: null state (pass zeros for a fresh sequence)"), TEF_ERR_INVALID;
-            TEF_TRY(tef_conv_forward(&D.head[i], cur, nullptr, nullptr, p->head[i].wp, p->head[i].bias, tape + t.e[i], ws, ws_bytes, stream));
-            TEF_TRY(tef_convgru_cell_fwd(&D.gru[i], tape + t.e[i], states_in[i], p->gate_ur[i].wp, p->gate_o[i].wp, p->gate_ur[i].bias,
-                                         p->gate_o[i].bias, tape + t.u[i], tape + t.r[i], tape + t.o[i], tape + t.hn[i], ws, ws_bytes, stream));
+            {
+                TEF_LAYER("enc%d.head fwd", i);
+                TEF_TRY(tef_conv_forward(&D.head[i], cur, nullptr, nullptr, p->head[i].wp, p->head[i].bias, tape + t.e[i], ws, ws_bytes, stream));
+            }
+            {
+                TEF_LAYER("enc%d.gru fwd", i);
+                TEF_TRY(tef_convgru_cell_fwd(&D.gru[i], tape + t.e[i], states_in[i], p->gate_ur[i].wp, p->gate_o[i].wp, p->gate_ur[i].bias,
+                                             p->gate_o[i].bias, tape + t.u[i], tape + t.r[i], tape + t.o[i], tape + t.hn[i], ws, ws_bytes, stream));
+            }
             cur = tape + t.hn[i];
         }
     }
     if (!(part & TEF_NET_DECODERS)) return 0;
-    const float *cur = tape + t.hn[g.top];           // (the new states of this pass: written by the encoder half)
+    const float *cur = state_of(p, t, tape, g.top);  // (the new states of this pass: written by the encoder half)
     tef_conv_desc dres = D.res;
     for (int j = 0; j < g.nres; ++j) {
         dres.act = TEF_ACT_RELU;
-        TEF_TRY(tef_conv_forward(&dres, cur, nullptr, nullptr, p->res1[j].wp, p->res1[j].bias, tape + t.mid[j], ws, ws_bytes, stream));
+        {
+            TEF_LAYER("res%d.conv1 fwd", j);
+            TEF_TRY(tef_conv_forward(&dres, cur, nullptr, nullptr, p->res1[j].wp, p->res1[j].bias, tape + t.mid[j], ws, ws_bytes, stream));
+        }
         dres.act = TEF_ACT_NONE;
+        TEF_LAYER("res%d.conv2 fwd", j);
         TEF_TRY(tef_conv_forward(&dres, tape + t.mid[j], nullptr, nullptr, p->res2[j].wp, p->res2[j].bias, tape + t.lin, ws, ws_bytes, stream));
         TEF_TRY(tef_add_act(tape + t.lin, cur, TEF_ACT_RELU, g.n[g.top], tape + t.y[j], stream));      // submodules.py:219-226
         cur = tape + t.y[j];
@@ -304,15 +337,22 @@ int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, c
     for (int k = 0; k < g.lv; ++k) {
         const int lvl = g.lvl[k];
         // features + encoder skip, x2 (arch.py:236 "sum" skip + UpsampleConvLayer's interpolate), previous prediction x2
-        if (pred && !(g.w[lvl] & 1))      // both in one launch
-            TEF_TRY(tef_upsample2x_pair(cur, tape + t.hn[lvl], g.B * g.src[k], tape + t.upx[k], pred, g.B * p->nout, tape + t.upp[k], g.h[lvl],
-                                        g.w[lvl], stream));
-        else {
-            TEF_TRY(tef_upsample_bilinear_crop(cur, tape + t.hn[lvl], g.B * g.src[k], g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upx[k], stream));
-            if (pred) TEF_TRY(tef_upsample_bilinear_crop(pred, nullptr, g.B * p->nout, g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upp[k], stream));
+        {
+            TEF_LAYER("dec%d.up fwd", k);
+            if (pred && !(g.w[lvl] & 1))      // both in one launch
+                TEF_TRY(tef_upsample2x_pair(cur, state_of(p, t, tape, lvl), g.B * g.src[k], tape + t.upx[k], pred, g.B * p->nout, tape + t.upp[k],
+                                            g.h[lvl], g.w[lvl], stream));
+            else {
+                TEF_TRY(tef_upsample_bilinear_crop(cur, state_of(p, t, tape, lvl), g.B * g.src[k], g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upx[k], stream));
+                if (pred) TEF_TRY(tef_upsample_bilinear_crop(pred, nullptr, g.B * p->nout, g.h[lvl], g.w[lvl], 2, 2, 1.0f, 0, 0, tape + t.upp[k], stream));
+            }
         }
         const float *x0 = pred ? tape + t.upp[k] : tape + t.upx[k], *x1 = pred ? tape + t.upx[k] : nullptr;
-        TEF_TRY(tef_conv_forward(&D.dec[k], x0, x1, nullptr, p->dec[k].wp, p->dec[k].bias, tape + t.d[k], ws, ws_bytes, stream));
+        {
+            TEF_LAYER("dec%d fwd", k);
+            TEF_TRY(tef_conv_forward(&D.dec[k], x0, x1, nullptr, p->dec[k].wp, p->dec[k].bias, tape + t.d[k], ws, ws_bytes, stream));
+        }
+        TEF_LAYER("pred%d fwd", k);
         TEF_TRY(tef_conv_forward(&D.pred[k], tape + t.d[k], nullptr, nullptr, p->pred[k].wp, p->pred[k].bias, tape + t.p[k], ws, ws_bytes, stream));
         // to the input size, x 2^level (model.py:76-81) x the caller's flow scaling, top / left padding cropped (:83)
         TEF_TRY(tef_upsample_bilinear_crop(tape + t.p[k], nullptr, g.B * p->nout, g.hs[k], g.ws[k], g.s[k], g.s[k],
@@ -361,6 +401,7 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         const float *srcs[4];
         int ns = 0;
         if (dflows[k]) {
+            TEF_LAYER("pred%d.flow bwd", k);
             TEF_TRY(tef_upsample_bilinear_crop_backward(dflows[k], g.B * p->nout, g.hs[k], g.ws[k], g.s[k], g.s[k],
                                                         (float)g.s[k] * p->flow_scale, p->crop_top, p->crop_left, gtape + q.fup[k], stream));
             srcs[ns++] = gtape + q.fup[k];
@@ -372,6 +413,7 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         // the head's pre-activation gradient, its input and weight gradients, the decoder's pre-activation gradient)
         const bool fused = ns && D.pred[k].ksize == 1 && D.pred[k].stride == 1 && D.pred[k].C1 == 0 && D.pred[k].N <= 4;
         if (fused) {
+            TEF_LAYER("dec%d.tail bwd", k);
             tef_conv_desc hd = D.pred[k];
             hd.act = p->final_act;
             TEF_TRY(tef_dec_head_backward(&hd, srcs, ns, tape + t.p[k], p->pred[k].w2, tape + t.d[k], TEF_ACT_RELU, d_feat, gtape + q.gp[k],
@@ -393,8 +435,12 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
             TEF_TRY(tef_grad_act(feat, nf, tape + t.d[k], TEF_ACT_RELU, g.B, g.out[k], hw, gtape + q.gd[k], p->dec[k].db, stream));
         }
         const float *x0 = k ? tape + t.upp[k] : tape + t.upx[k], *x1 = k ? tape + t.upx[k] : nullptr;
-        TEF_TRY(conv_bwd(D.dec[k], p->dec[k], gtape + q.gd[k], x0, x1, gtape + q.dx0[k], k ? gtape + q.dx1[k] : nullptr, ws, ws_bytes, stream));
+        {
+            TEF_LAYER("dec%d dgrad", k);
+            TEF_TRY(conv_bwd(D.dec[k], p->dec[k], gtape + q.gd[k], x0, x1, gtape + q.dx0[k], k ? gtape + q.dx1[k] : nullptr, ws, ws_bytes, stream));
+        }
         ran |= bit_dec(k);
+        TEF_LAYER("dec%d.up bwd", k);
         const float *dupx = k ? gtape + q.dx1[k] : gtape + q.dx0[k], *dupp = k ? gtape + q.dx0[k] : nullptr;
         skip_grads[k] = d_feat = gtape + q.skip[k];
         d_prev_pred = nullptr;
@@ -416,13 +462,15 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
     // block, relu'(y[j-1]) * (dres[j] + gy[j]) between blocks — instead of a tef_grad_act launch each
     bool gy_formed = false;               // gy[j] was formed by block j + 1's last input gradient
     for (int j = g.nres - 1; j >= 0 && ns && dec; --j) {
-        const float *xin = j ? tape + t.y[j - 1] : tape + t.hn[g.top];
+        const float *xin = j ? tape + t.y[j - 1] : state_of(p, t, tape, g.top);
         if (!gy_formed)
             TEF_TRY(tef_grad_act(srcs, ns, tape + t.y[j], TEF_ACT_RELU, g.B, Ct, hwt, gtape + q.gy[j], p->res2[j].db, stream));
         {
+            TEF_LAYER("res%d.conv2 dgrad", j);
             tef_conv_post post{tape + t.mid[j], TEF_ACT_RELU, nullptr, gtape + q.gmid[j], p->res1[j].db};
             TEF_TRY(conv_bwd_post(D.res, p->res2[j], gtape + q.gy[j], tape + t.mid[j], post, ws, ws_bytes, stream));
         }
+        TEF_LAYER("res%d.conv1 dgrad", j);
         if (j > 0) {
             tef_conv_post post{tape + t.y[j - 1], TEF_ACT_RELU, gtape + q.gy[j], gtape + q.gy[j - 1], p->res2[j - 1].db};
             TEF_TRY(conv_bwd_post(D.res, p->res1[j], gtape + q.gmid[j], xin, post, ws, ws_bytes, stream));
@@ -468,13 +516,17 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         const bool dur = p->gate_ur[i].defer && tef_conv_wgrad_parts_supported(&D.ur[i]);
         const bool dog = p->gate_o[i].defer && tef_conv_wgrad_parts_supported(&D.og[i]);
         // (the cell's last sweep also forms the head convolution's pre-activation gradient: relu'(e) * d loss / d e + its bias sums)
+        {
+        TEF_LAYER("enc%d.gru bwd", i);
         TEF_TRY(tef_convgru_cell_bwd_head(&D.gru[i], tape + t.e[i], states_in[i], tape + t.u[i], tape + t.r[i], tape + t.o[i], sources, n,
                                           p->gate_ur[i].w2, p->gate_o[i].w2, gtape + q.g_ur[i], gtape + q.g_o[i], nullptr, gtape + q.dh[i],
                                           dur ? nullptr : p->gate_ur[i].dw, dur ? nullptr : p->gate_ur[i].dw2, dog ? nullptr : p->gate_o[i].dw,
                                           p->gate_ur[i].db, p->gate_ur[i].db2, p->gate_o[i].db, TEF_ACT_RELU, gtape + q.g_e[i], p->head[i].db,
                                           ws, ws_bytes, stream));
+        }
         dstate_off[i] = (long long)q.dh[i];
         ran |= bit_ur(i) | bit_og(i);
+        TEF_LAYER("enc%d.head dgrad", i);
         const bool want = i > 0 || want_dx;
         const float *xin = i ? tape + t.hn[i - 1] : x;
         TEF_TRY(conv_bwd(D.head[i], p->head[i], gtape + q.g_e[i], xin, nullptr, want ? gtape + q.dxin[i] : nullptr, nullptr, ws, ws_bytes, stream));
@@ -510,8 +562,9 @@ int tef_net_window_wgrads_part(const tef_net_plan *p, int part, int npass, const
     const Descs D = make_descs(p, g, 0);
     const float *gs[TEF_CONV_MAX_PARTS], *x0s[TEF_CONV_MAX_PARTS], *x1s[TEF_CONV_MAX_PARTS], *gts[TEF_CONV_MAX_PARTS];
     // one layer: collect the passes in which it ran, reduce them in groups
-    auto layer = [&](const tef_conv_desc &d, const tef_net_conv &c, uint64_t bit, auto part) -> int {
+    auto layer = [&](const char *label, const tef_conv_desc &d, const tef_net_conv &c, uint64_t bit, auto part) -> int {
         if (!c.defer || !tef_conv_wgrad_parts_supported(&d)) return 0;
+        tef::LayerScope layer_scope_(label, (hipStream_t)stream);
         int n = 0;
         for (int s = 0; s <= npass; ++s) {
             if (s < npass && (ran[s] & bit)) {
@@ -526,24 +579,24 @@ int tef_net_window_wgrads_part(const tef_net_plan *p, int part, int npass, const
         return 0;
     };
     for (int i = 0; i < g.lv && (part & TEF_NET_ENCODERS); ++i) {
-        TEF_TRY(layer(D.head[i], p->head[i], bit_head(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+        TEF_TRY(layer(lbl("enc%d.head wgrad", i), D.head[i], p->head[i], bit_head(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.g_e[i]; a = i ? tape[s] + t.hn[i - 1] : x[s]; b = nullptr; c_ = nullptr; }));
-        TEF_TRY(layer(D.ur[i], p->gate_ur[i], bit_ur(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+        TEF_TRY(layer(lbl("enc%d.gru.ur wgrad", i), D.ur[i], p->gate_ur[i], bit_ur(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.g_ur[i]; a = tape[s] + t.e[i]; b = states_in[s][i]; c_ = nullptr; }));
-        TEF_TRY(layer(D.og[i], p->gate_o[i], bit_og(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+        TEF_TRY(layer(lbl("enc%d.gru.og wgrad", i), D.og[i], p->gate_o[i], bit_og(i), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.g_o[i]; a = tape[s] + t.e[i]; b = states_in[s][i]; c_ = tape[s] + t.r[i]; }));
     }
     if (!(part & TEF_NET_DECODERS)) return 0;
     for (int j = 0; j < g.nres; ++j) {
-        TEF_TRY(layer(D.res, p->res1[j], bit_res1(j), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
-            gg = gtape[s] + q.gmid[j]; a = j ? tape[s] + t.y[j - 1] : tape[s] + t.hn[g.top]; b = nullptr; c_ = nullptr; }));
-        TEF_TRY(layer(D.res, p->res2[j], bit_res2(j), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+        TEF_TRY(layer(lbl("res%d.conv1 wgrad", j), D.res, p->res1[j], bit_res1(j), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+            gg = gtape[s] + q.gmid[j]; a = j ? tape[s] + t.y[j - 1] : state_of(p, t, tape[s], g.top); b = nullptr; c_ = nullptr; }));
+        TEF_TRY(layer(lbl("res%d.conv2 wgrad", j), D.res, p->res2[j], bit_res2(j), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.gy[j]; a = tape[s] + t.mid[j]; b = nullptr; c_ = nullptr; }));
     }
     for (int k = 0; k < g.lv; ++k) {
-        TEF_TRY(layer(D.dec[k], p->dec[k], bit_dec(k), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+        TEF_TRY(layer(lbl("dec%d wgrad", k), D.dec[k], p->dec[k], bit_dec(k), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.gd[k]; a = k ? tape[s] + t.upp[k] : tape[s] + t.upx[k]; b = k ? tape[s] + t.upx[k] : nullptr; c_ = nullptr; }));
-        TEF_TRY(layer(D.pred[k], p->pred[k], bit_pred(k), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
+        TEF_TRY(layer(lbl("pred%d wgrad", k), D.pred[k], p->pred[k], bit_pred(k), [&](int s, const float *&gg, const float *&a, const float *&b, const float *&c_) {
             gg = gtape[s] + q.gp[k]; a = tape[s] + t.d[k]; b = nullptr; c_ = nullptr; }));
     }
     return 0;

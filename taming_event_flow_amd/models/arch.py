@@ -18,7 +18,7 @@ from collections import namedtuple
 
 import torch.nn as nn
 
-from .engine import PassEngine, run_pass
+from .engine import PassEngine, decode_passes, encode_pass, run_pass
 from .submodules import ConvLayer, RecurrentConvLayer, ResidualBlock, UpsampleConvLayer, upsample_bilinear
 
 Row = namedtuple("Row", "kind level cin cout ksize stride act")
@@ -106,6 +106,7 @@ class MultiResUNetRecurrent(nn.Module):
         # extra factor on the full-resolution flows of the fused pass: a training loop that multiplies the network's
         # output by loss.flow_scaling (reference train_flow.py:107-108) can have the pass do it in its last kernel
         self.flow_scale = 1.0
+        self._window = []        # (record, new states) of the encoder halves queued by encode()
 
     # -- switches train.Trainer flips on every PackedWeights of the tree (submodules.enable_*): read them where they live
     @property
@@ -196,7 +197,26 @@ class MultiResUNetRecurrent(nn.Module):
         state["_engine"] = None                 # workspaces are not part of a checkpoint
         state["_bucket"] = None
         state["states"] = [None] * self.num_states
+        state["_window"] = []
         return state
+
+    # ---- window mode (train.Trainer): encoder halves pass by pass, the decoder halves of the whole window as one batch ----
+    def encode(self, x):
+        """The encoder half of one pass: updates `states` and queues the pass for decode_window().  Needs the training
+        loop's in-place gradient buffers (direct_grads) like every split pass."""
+        new_states, rec = encode_pass(self.engine, x, self.states)
+        self.states = new_states
+        self._window.append((rec, new_states))
+
+    def decode_window(self):
+        """-> flows[t][k] of every pass queued by encode() since the last call: residual blocks, decoders and heads of all of
+        them as ONE batch (only the recurrent states cross passes: reference models/arch.py:225-227)."""
+        recs, states = [r for r, _ in self._window], [s for _, s in self._window]
+        self._window = []
+        return decode_passes(self.engine, recs, states)
+
+    def drop_window(self):
+        self._window = []
 
     def step(self, x):
         """One fused pass on an input of any size: -> 4 flows at the input resolution, coarse to fine; updates `states`."""

@@ -53,7 +53,7 @@ class _Tape:
     """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
     __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape", "gtape", "ran", "targets_set", "queued",
-                 "stream")
+                 "stream", "hn", "new_states")
 
 
 class PassEngine:
@@ -127,7 +127,7 @@ class PassEngine:
         bias = packer.bias(biases)
         nc.wp, nc.w2, nc.bias = wp.data_ptr(), wt.data_ptr(), _p(bias)
 
-    def make_plan(self, B, Hp, Wp, ph, pw, part=3, pl=None):
+    def make_plan(self, B, Hp, Wp, ph, pw, part=3, pl=None, dec_only=False):
         """struct tef_net_plan for a (padded) input of B x bins x Hp x Wp: geometry + the packed weights / biases of
         every convolution (re-packed by PackedWeights only when a parameter changed).  part 1: geometry and the encoders'
         layers only; part 2 completes the plan `pl` with the residual blocks, decoders and heads — on the stream of the
@@ -135,8 +135,9 @@ class PassEngine:
         instead of in front of them."""
         a, np_ = self.arch, self.plan
         dec_rows = np_.of("dec")
-        if part & 1:
+        if (part & 1) or pl is None:
             pl = _lib.NetPlan()
+            pl.dec_only = 1 if dec_only else 0
             pl.B, pl.H, pl.W = B, Hp, Wp
             pl.bins, pl.levels, pl.nres, pl.nout = np_.num_bins, np_.levels, np_.nres, np_.nout
             pl.final_act = ACT[np_.final_activation]
@@ -182,7 +183,7 @@ class PassEngine:
 
     def layout(self, pl):
         """(tape floats, gradient-arena floats, workspace bytes, flow / state / dstate offsets, dx offset) of a geometry."""
-        key = (pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left)
+        key = (pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left, pl.dec_only)
         lay = self._layout.get(key)
         if lay is None:
             lib = _lib.lib()
@@ -259,6 +260,7 @@ class PassEngine:
             rec.states_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
             rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
+            rec.hn = rec.new_states = None
         pl = rec.plan
         if part == 2:
             self.make_plan(pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left, 2, pl)
@@ -279,6 +281,38 @@ class PassEngine:
         if part & 1:
             new_states = [rec.tape[so[i]:so[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) for i in range(n)]
         return flows, new_states, (rec if (keep or part != 3) else None)
+
+    # ---- the decoder half of a whole loss window as ONE batch (round 6) --------------------------------------------------
+    def decode_window(self, recs, states):
+        """recs: the records of P encoder halves (forward(part=1)) of one geometry; states[t][i]: the new state of level i
+        of pass t.  -> (flows[t][k] as views of one arena, the window's record).  Only the recurrent states cross passes
+        (reference models/arch.py:225-227): the residual blocks, decoders and heads of the P passes are independent, and as
+        one batch of P x B samples they are ten times fewer launches on GEMMs ten times larger (the 8 x 8 level: 512 pixels,
+        split 16..32 ways over k at 50 TFLOP/s, become 5120 at 110)."""
+        plan, n, P = self.plan, self.plan.levels, len(recs)
+        p0 = recs[0].plan
+        B = p0.B
+        dev = recs[0].tape.device
+        # the passes' states stacked along the batch: [P * B, C_i, h_i, w_i] (4 copies per window, 16 MB per pass)
+        hn = [torch.cat([states[t][i].detach() for t in range(P)], 0) for i in range(n)]
+        pl = self.make_plan(P * B, p0.H, p0.W, p0.crop_top, p0.crop_left, 2, None, dec_only=True)
+        for i in range(n):
+            pl.hn_ext[i] = hn[i].data_ptr()
+        ntape, _, wsb, fo, _, _, _ = self.layout(pl)
+        rec = _Tape()
+        rec.plan, rec.xp, rec.states_in, rec.states_arr = pl, None, None, None
+        rec.tape = torch.empty((ntape,), dtype=torch.float32, device=dev)
+        rec.geom, rec.x_shape = recs[0].geom, (P * B,) + tuple(recs[0].x_shape[1:])
+        rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
+        rec.hn, rec.new_states = hn, None
+        ws = self.workspace(wsb, dev)
+        rc = _lib.lib().tef_net_pass_forward_part(ctypes.byref(pl), 2, None, None, rec.tape.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  _lib.stream_ptr())
+        _lib.check(rc, "tef_net_pass_forward (window decoders)")
+        H, W = recs[0].x_shape[2], recs[0].x_shape[3]
+        per = B * plan.nout * H * W
+        flows = [[rec.tape[fo[k] + t * per:fo[k] + (t + 1) * per].view(B, plan.nout, H, W) for k in range(n)] for t in range(P)]
+        return flows, rec
 
     def backward(self, rec, dflows, dstates, params, want_dx, part=3):
         """-> (gradients w.r.t. the incoming states, gradient w.r.t. the network input or None, parameter gradients for
@@ -331,13 +365,13 @@ class PassEngine:
         off = (ctypes.c_longlong * n)()
         dxv = ctypes.c_int(0)
         ws = self.workspace(wsb, dev)
-        rc = _lib.lib().tef_net_pass_backward_part(ctypes.byref(pl), part, rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(),
+        rc = _lib.lib().tef_net_pass_backward_part(ctypes.byref(pl), part, _p(rec.xp), rec.states_arr, rec.tape.data_ptr(),
                                                    a_dfl, a_dst, 1 if want_dx else 0, gtape.data_ptr(), ctypes.byref(ran), off,
                                                    ctypes.byref(dxv), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "tef_net_pass_backward")
         rec.ran |= ran.value
-        dh = [gtape[off[i]:off[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) if off[i] >= 0 else None
-              for i in range(n)]
+        shapes = [t_.shape for t_ in (rec.hn if rec.hn is not None else rec.states_in)]      # (a window's decoders: the stacked states)
+        dh = [gtape[off[i]:off[i] + shapes[i].numel()].view(shapes[i]) if off[i] >= 0 else None for i in range(n)]
         dx = None
         if want_dx and (part & 1):
             ph, pw = rec.geom
@@ -346,7 +380,8 @@ class PassEngine:
             else:       # no gradient reached the first encoder: zeros, like autograd's own
                 dx = torch.zeros(rec.x_shape, dtype=torch.float32, device=dev)
         if direct and a.deferred_wgrad and not rec.queued:
-            if self._pending and (self._pending[0].plan.B, self._pending[0].plan.H, self._pending[0].plan.W) != (pl.B, pl.H, pl.W):
+            same = [r_ for r_ in self._pending if r_.plan.dec_only == pl.dec_only]      # (a window's batched decoders sit beside its passes)
+            if same and (same[0].plan.B, same[0].plan.H, same[0].plan.W) != (pl.B, pl.H, pl.W):
                 self.flush_window()
             if a.auto_grads and a._bucket is not None and not self._callback_queued:
                 # nobody calls flush_window for the drop-in loop: at the end of this backward() (autograd runs the queued
@@ -358,6 +393,11 @@ class PassEngine:
             self._pending.append(rec)       # (keeps the arenas alive until the flush)
             rec.queued = True
             sm._DEFERRED_ENGINES.add(self)
+        if rec.queued and rec.hn is not None and self.wgrad_stream is not None and self.wgrad_group:
+            # the batched decoder half of a window: its weight gradients (a third of the window's) run beside the encoders' BPTT.
+            # ONLY this record: this backward runs on the decoders' stream, and the reduction stream waits for the stream the
+            # flush is issued from — encoder records still queued belong to the caller's stream
+            self.flush_window(self.wgrad_stream, only=[rec])
         if rec.queued and part == 1 and self.wgrad_stream is not None and self.wgrad_group:
             # (backward walks the passes last to first and a pass's encoder half is its last piece: when this record is
             # the newest one queued, every queued pass is complete)
@@ -383,7 +423,7 @@ class PassEngine:
         if self.wgrad_stream is not None:
             torch.cuda.current_stream().wait_stream(self.wgrad_stream)
 
-    def flush_window(self, stream=None, parts=(3,), between=None, keep=False):
+    def flush_window(self, stream=None, parts=(3,), between=None, keep=False, only=None):
         """The deferred weight gradients of every backward call since the last flush: one reduction per layer over all
         passes (tef_net_window_wgrads) — on the current stream, or on `stream` once it has caught up with the current
         one (the caller makes its stream wait for `stream` before the gradients are read).  `parts`: the layer halves in
@@ -391,7 +431,14 @@ class PassEngine:
         every half but the last — a data-parallel caller starts the all-reduce of the finished half's gradients there.
         keep: leave the backward calls queued (the caller reduces the other half with a second call)."""
         pend = self._pending
-        if not keep:
+        if only is not None:               # these records alone; whatever else is queued stays queued
+            pend = [r for r in pend if any(r is o_ for o_ in only)]
+            self._pending = [r for r in self._pending if not any(r is o_ for o_ in only)]
+            for r in pend:
+                r.queued = False
+            if not self._pending:
+                sm._DEFERRED_ENGINES.discard(self)
+        elif not keep:
             self._pending = []
             sm._DEFERRED_ENGINES.discard(self)
             for r in pend:
@@ -407,23 +454,41 @@ class PassEngine:
                 if self.debug_delay and len(self.debug_delay) > 2 and self.debug_delay[2]:
                     torch.cuda._sleep(int(self.debug_delay[2]))
                 for r in pend:          # the arenas are released right after this call: not before `stream` has read them
-                    for t in [r.tape, r.gtape, r.xp] + list(r.states_in):
-                        t.record_stream(stream)
+                    for t in [r.tape, r.gtape, r.xp] + list(r.states_in or []) + list(r.hn or []):
+                        if t is not None:
+                            t.record_stream(stream)
                 self._launch_wgrads(pend, parts, between)
             return
         self._launch_wgrads(pend, parts, between)
 
     def _launch_wgrads(self, pend, parts=(3,), between=None):
-        npass = len(pend)
-        xs = (ctypes.c_void_p * npass)(*[r.xp.data_ptr() for r in pend])
-        sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p)) for r in pend])
-        tapes = (ctypes.c_void_p * npass)(*[r.tape.data_ptr() for r in pend])
-        gtapes = (ctypes.c_void_p * npass)(*[r.gtape.data_ptr() for r in pend])
-        rans = (ctypes.c_ulonglong * npass)(*[r.ran for r in pend])
+        # the passes' own records (encoder halves, or whole passes) and the records of windows' batched decoder halves: the
+        # two kinds have different batch sizes, each goes through tef_net_window_wgrads with its own plan (a layer that did
+        # not run in a record is skipped there by the record's `ran` bits)
+        groups = [[r for r in pend if r.hn is None], [r for r in pend if r.hn is not None]]
+        null = ctypes.POINTER(ctypes.c_void_p)()
         for k, part in enumerate(parts):
-            rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(pend[-1].plan), int(part), npass, xs, sts, tapes, gtapes, rans,
-                                                       _lib.stream_ptr())
-            _lib.check(rc, "tef_net_window_wgrads")
+            for grp in groups:
+                if not grp or (grp[0].hn is not None and not (int(part) & 2)):
+                    continue
+                npass = len(grp)
+                xs = (ctypes.c_void_p * npass)(*[_p(r.xp) for r in grp])
+                sts = (ctypes.POINTER(ctypes.c_void_p) * npass)(*[
+                    ctypes.cast(r.states_arr, ctypes.POINTER(ctypes.c_void_p)) if r.states_arr is not None else null for r in grp])
+                tapes = (ctypes.c_void_p * npass)(*[r.tape.data_ptr() for r in grp])
+                gtapes = (ctypes.c_void_p * npass)(*[r.gtape.data_ptr() for r in grp])
+                rans = (ctypes.c_ulonglong * npass)(*[r.ran for r in grp])
+                if grp[0].hn is not None:        # one launch set per window record (each has its own stack of states in its plan)
+                    for q in range(npass):
+                        rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(grp[q].plan), 2, 1, (ctypes.c_void_p * 1)(xs[q]),
+                                                                   (ctypes.POINTER(ctypes.c_void_p) * 1)(sts[q]), (ctypes.c_void_p * 1)(tapes[q]),
+                                                                   (ctypes.c_void_p * 1)(gtapes[q]), (ctypes.c_ulonglong * 1)(rans[q]),
+                                                                   _lib.stream_ptr())
+                        _lib.check(rc, "tef_net_window_wgrads")
+                else:
+                    rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(grp[-1].plan), int(part), npass, xs, sts, tapes, gtapes, rans,
+                                                               _lib.stream_ptr())
+                    _lib.check(rc, "tef_net_window_wgrads")
             if between is not None and k + 1 < len(parts):
                 between()
 
@@ -492,6 +557,53 @@ class _DecFn(torch.autograd.Function):
         ds, _, pg = ctx.engine.backward(ctx.rec, list(dflows), None, ctx.params, False, part=2)
         ctx.rec = None
         return (None, None, None) + tuple(ds) + tuple(pg)
+
+
+class _DecWinFn(torch.autograd.Function):
+    """The decoder halves of the P passes of a loss window as ONE batch (PassEngine.decode_window):
+    (P x 4 new states, parameters...) -> P x 4 flows.  Its backward runs once, before any encoder half's."""
+
+    @staticmethod
+    def forward(ctx, engine, recs, nstates, *rest):
+        P = len(recs)
+        states = [list(rest[t * nstates:(t + 1) * nstates]) for t in range(P)]
+        flows, rec = engine.decode_window(recs, states)
+        ctx.engine, ctx.rec, ctx.P, ctx.nstates = engine, rec, P, nstates
+        ctx.params = rest[P * nstates:]
+        return tuple(f for t in range(P) for f in flows[t])
+
+    @staticmethod
+    def backward(ctx, *dflows):
+        engine, rec, P, n = ctx.engine, ctx.rec, ctx.P, ctx.nstates
+        B = rec.plan.B // P
+        dfl = []
+        for k in range(n):          # per head: the passes' gradients stacked along the batch (one copy per head)
+            gs = [dflows[t * n + k] for t in range(P)]
+            have = [g for g in gs if g is not None]
+            if not have:
+                dfl.append(None)
+            else:
+                dfl.append(torch.cat([g if g is not None else torch.zeros_like(have[0]) for g in gs], 0))
+        ds, _, pg = engine.backward(rec, dfl, None, ctx.params, False, part=2)
+        ctx.rec = None
+        out = [None if ds[i] is None else ds[i][t * B:(t + 1) * B] for t in range(P) for i in range(n)]
+        return (None, None, None) + tuple(out) + tuple(pg)
+
+
+def encode_pass(engine, x, states):
+    """The encoder half of one pass as an autograd node of its own -> (new states, the pass's record for decode_passes)."""
+    params = [p for p in engine.arch.parameters()]
+    holder = []
+    new_states = _EncFn.apply(engine, len(states), holder, x, *states, *params)
+    return list(new_states), holder[0]
+
+
+def decode_passes(engine, recs, states):
+    """-> flows[t][k]: the decoder halves of the passes `recs` (encode_pass) as one batch."""
+    params = [p for p in engine.arch.parameters()]
+    n = len(states[0])
+    out = _DecWinFn.apply(engine, list(recs), n, *[s for st in states for s in st], *params)
+    return [list(out[t * n:(t + 1) * n]) for t in range(len(recs))]
 
 
 def run_pass(engine, x, states):

@@ -230,7 +230,7 @@ class WindowRunner:
 class Trainer:
     """model + loss + optimiser wired like reference train_flow.py:60-70, plus the DP gradient bucket."""
 
-    def __init__(self, config, device, model=None, loss_function=None, streams=None):
+    def __init__(self, config, device, model=None, loss_function=None, streams=None, window_decode=None):
         self.cfg, self.device = config, device
         num_bins = 2 if config["data"]["voxel"] is None else config["data"]["voxel"]
         if model is None:
@@ -284,9 +284,17 @@ class Trainer:
         eng = getattr(getattr(self.model, "arch", None), "engine", None)
         if streams is None:      # (an explicit argument wins over the environment switch)
             streams = os.environ.get("TEF_TWO_STREAMS", "1") != "0"
+        # Window mode (round 6; TEF_WINDOW_DECODE=0 opts out): the encoder halves run pass by pass, the decoder halves of the
+        # whole window — independent of each other: only the recurrent states cross passes — as ONE batch of P x B samples
+        # when the window is complete (models/engine.py decode_window): ten times fewer launches on GEMMs ten times
+        # larger.  The loss container's update() calls follow it, the batches of the window stay referenced until then.
+        self.window_decode = (eng is not None and torch.device(device).type == "cuda" and hasattr(self.model.arch, "encode")
+                              and os.environ.get("TEF_WINDOW_DECODE", "1") != "0") if window_decode is None else bool(window_decode)
+        self._win_inputs = []
         if eng is not None and torch.device(device).type == "cuda" and streams:
-            self.dec_stream = torch.cuda.Stream(device=device)
-            eng.side_stream = self.dec_stream
+            if not self.window_decode:       # (pass-by-pass decoders: on a side stream beside the next pass's encoders)
+                self.dec_stream = torch.cuda.Stream(device=device)
+                eng.side_stream = self.dec_stream
             # ... and a third one for the deferred weight gradients: every TEF_WGRAD_GROUP (default 3) finished backward
             # passes are reduced beside the rest of BPTT instead of all of them after it (0: after it)
             group = int(os.environ.get("TEF_WGRAD_GROUP", "3"))
@@ -323,6 +331,9 @@ class Trainer:
         """train_flow.py:83-87"""
         if self.dec_stream is not None:      # (a window cut short: its decoder halves / updates may still be running)
             torch.cuda.current_stream().wait_stream(self.dec_stream)
+        if self._win_inputs:                 # window mode: the passes collected so far are dropped with the window
+            self._win_inputs = []
+            self.model.arch.drop_window()
         self.loss_function.reset()
         self.model.reset_states()
         self.bucket.zero()
@@ -339,7 +350,7 @@ class Trainer:
         assert len(batches) == P
         if warmup < 1:
             raise ValueError("capture needs at least one eager window (allocations, recurrent state buffers)")
-        if self.loss_function.num_passes != 0:
+        if self.loss_function.num_passes != 0 or self._win_inputs:
             raise RuntimeError("capture_window must start at a window boundary")
         # everything else that is baked into the graphs at capture time: the optimiser object, the clip, how the DP
         # reduction is split, the loss configuration (a parked window is handed out again only when all of it still holds)
@@ -484,6 +495,26 @@ class Trainer:
         cfg = self.cfg
         # flow_scaling (train_flow.py:107-108) rides on the pass's final up-sampling kernel when the model offers it
         arch = getattr(self.model, "arch", None)
+        if self.window_decode and torch.is_grad_enabled() and arch.direct_grads:
+            P = cfg["data"]["passes_loss"]
+            arch.encode(inputs["net_input"])
+            self._win_inputs.append(inputs)
+            if len(self._win_inputs) < P:
+                return False
+            # the window is complete: the decoder halves of all its passes as ONE batch, then their update() calls, on the
+            # caller's stream.  (Measured, round 6: in chunks of 5 passes on a side stream beside the later passes' encoders the
+            # window is 0.2-0.6 ms SLOWER than as one batch here — the window is bound by the sum of its kernels now, and
+            # two half-size batches are less efficient than one.)
+            arch.flow_scale = float(cfg["loss"]["flow_scaling"])
+            try:
+                flows_all = arch.decode_window()
+            finally:
+                arch.flow_scale = 1.0
+            batches, self._win_inputs = self._win_inputs, []
+            for flows, b in zip(flows_all, batches):
+                self.loss_function.update(flows, b["event_list"], b["event_list_pol_mask"], b["d_event_list"],
+                                          b["d_event_list_pol_mask"])
+            return self.loss_function.num_passes >= P
         if hasattr(arch, "flow_scale"):
             arch.flow_scale = float(cfg["loss"]["flow_scaling"])
             if self.dec_stream is not None:

@@ -87,14 +87,17 @@ if "--self-test" in sys.argv:
     sys.exit(0)
 
 
-def window(cfg, passes, wgrad_group, streams, new_seq_at=None, events=600, windows=2):
+def window(cfg, passes, wgrad_group, streams, new_seq_at=None, events=600, windows=2, window_decode=False):
     os.environ["TEF_WGRAD_GROUP"] = str(wgrad_group)
     torch.manual_seed(0)
-    tr = train.Trainer(cfg, dev, streams=streams)
+    tr = train.Trainer(cfg, dev, streams=streams, window_decode=window_decode)
     if streams:       # the side streams are dummies: the control flow (split passes, grouped flushes) is the real one
         e = tr.model.arch.engine
-        e.side_stream, e.wgrad_stream, e.wgrad_group = _Stream(), _Stream(), wgrad_group
-        tr.dec_stream, tr.wgrad_stream = e.side_stream, e.wgrad_stream
+        e.wgrad_stream, e.wgrad_group = _Stream(), wgrad_group
+        tr.wgrad_stream = e.wgrad_stream
+        if not window_decode:
+            e.side_stream = _Stream()
+            tr.dec_stream = e.side_stream
     src = train.SyntheticSequences(cfg, dev, events, seq_len=10 ** 9, seed=3, jitter=50)
     tr.reset()
     steps = 0
@@ -128,6 +131,10 @@ cases = [
 for name, cfg, P, group, streams, ns in cases:
     window(cfg, P, group, streams, ns, windows=1 if P == 64 else 2)
     print("ok:", name, flush=True)
+# window mode (round 6): encoder halves pass by pass, the decoder halves of the window as one batch
+for name, cfg, P, group, streams, ns in cases:
+    window(cfg, P, group, streams, ns, windows=1 if P == 64 else 2, window_decode=True)
+    print("ok (window decode):", name, flush=True)
 
 # loss module on its own: ragged / empty lists, general masks, detached events
 rng = np.random.default_rng(0)

@@ -333,7 +333,7 @@ def test_deferred_weight_gradients_match_immediate(B, R, passes):
         assert float((a - b).abs().max()) <= 2e-5 * max(scale, 1e-12)
 
 
-def _trace_run(two_streams, delay):
+def _trace_run(two_streams, delay, window_decode=False):
     """Two eager windows of the golden trace's inputs (fresh input tensors every pass, dropped right after the call — what
     a data loader does) -> [loss, pre-clip gradient norm] per window + a parameter checksum."""
     from taming_event_flow_amd import synth, train
@@ -352,8 +352,8 @@ def _trace_run(two_streams, delay):
     }
     # (the switch is a constructor argument here: changing os.environ under a process whose HIP runtime threads are alive
     # is a setenv / getenv race)
-    tr = train.Trainer(cfg, dev, streams=two_streams)
-    assert (tr.dec_stream is not None) == two_streams and (tr.wgrad_stream is not None) == two_streams
+    tr = train.Trainer(cfg, dev, streams=two_streams, window_decode=window_decode)
+    assert (tr.dec_stream is not None) == (two_streams and not window_decode) and (tr.wgrad_stream is not None) == two_streams
     tr.model.arch.engine.debug_delay = delay
     sd = tr.model.state_dict()
     w = synth.make_model_weights([(k, v.shape) for k, v in sd.items()], int(z["seed"]))
@@ -392,6 +392,13 @@ def test_two_stream_window_has_no_race():
         # test was written against gave a 40 % different loss)
         tol = np.array([1e-5, 1e-5, 1e-5, 5e-4, 1e-6])
         assert np.isfinite(got).all() and (err <= tol).all(), (delay, got, ref)
+    # window mode (round 6, the Trainer's default): encoder halves pass by pass, the decoder halves of the whole window as
+    # one batch, its weight gradients on the reduction stream beside the encoders' BPTT — on one stream, on its streams, and
+    # with the reduction stream / the main stream held back
+    for streams, delay in ((False, None), (True, None), (True, (0, 0, 4 * spin)), (True, (spin, spin, 0))):
+        got = _trace_run(streams, delay, window_decode=True)
+        err = np.abs(got - ref) / np.abs(ref)
+        assert np.isfinite(got).all() and (err <= tol).all(), ("window", streams, delay, got, ref)
 
 
 @pytest.mark.parametrize("warping,scales,smooth,graph", [("Linear", 2, True, False), ("Iterative", 2, True, False),
