@@ -1021,6 +1021,7 @@ def train_extra(a, torch, dev):
         flops = 3 * conv_flops_per_pass(a.batch, a.res[0], a.res[1]) * a.passes
         ev = a.batch * a.passes * (a.events + a.detached)
         tr_streams = 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)
+        win_mode = bool(getattr(tr, "window_decode", False))
         del tr, window
         release_now(torch)
         return {"workload": "training window as one hipGraph (bench.py --mode train --graph): RecEVFlowNet fwd + loss + BPTT "
@@ -1033,7 +1034,10 @@ def train_extra(a, torch, dev):
                 # the same flops over the WHOLE window (two streams, every other launch included)
                 "window_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                 "window_frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-                "streams": tr_streams}
+                "streams": tr_streams,
+                # (round 6) encoder halves pass by pass, the decoder halves of the window as one batch (train.Trainer.window_decode);
+                # the captured window keeps its weight-gradient reductions on the capture stream, the eager one on a second stream
+                "window_decode": win_mode}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
 

@@ -191,14 +191,17 @@ def test_checkpoint_resume_continues_the_run(dev, tmp_path):
         tr.close()
         return out
 
-    a, b, c = run(False), run(False), run(True)
-    noise = (a[2] - b[2]).abs().max().item()
+    # three uninterrupted runs give the run-to-run noise (float atomics in the weight-gradient epilogues add in arrival order;
+    # ONE pair underestimates it often enough to fail one run in four: round 6), then the interrupted one
+    a, b, b2, c = run(False), run(False), run(False), run(True)
+    noise = max((a[2] - b[2]).abs().max().item(), (a[2] - b2[2]).abs().max().item(), (b[2] - b2[2]).abs().max().item())
+    lnoise = max(abs(a[1] - b[1]), abs(a[1] - b2[1]), abs(b[1] - b2[1]))
     assert a[0] == c[0] or abs(a[0] - c[0]) <= 1e-6 * abs(a[0])
-    if noise == 0.0 and a[1] == b[1]:
+    if noise == 0.0 and lnoise == 0.0:
         assert c[1] == a[1] and torch.equal(c[2], a[2]), "the resumed run differs from the uninterrupted one"
     else:
-        assert abs(c[1] - a[1]) <= max(10 * abs(a[1] - b[1]), 1e-6 * abs(a[1]))
-        assert (c[2] - a[2]).abs().max().item() <= 10 * noise
+        assert abs(c[1] - a[1]) <= max(10 * lnoise, 1e-6 * abs(a[1]))
+        assert (c[2] - a[2]).abs().max().item() <= max(10 * noise, 1e-6 * a[2].abs().max().item())
 
 
 def test_reference_format_state_dict_loads_through_load_model(dev, tmp_path):

@@ -7,8 +7,9 @@ export TMPDIR=/tmp
 O=$1
 mkdir -p $O
 hipcc --offload-arch=gfx950 -O3 -o $O/mfma_f32_peak tools/mfma_f32_peak.hip 2> $O/build.err
-for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32; do
-  TEF_TWO_STREAMS=0 timeout -k 5 300 rocprofv3 --pmc $C --kernel-include-regex "halo_kernel|gemm_nt_kernel" --output-format csv -d $O/conv_$C -- python3 bench.py --mode train --steps 1 --warmup 1 --no-cpu-baseline > $O/conv_$C.json 2> $O/conv_$C.err
+# (round 6: + what the wavefronts wait for — LDS, any memory — and what they issue besides MFMA)
+for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT; do
+  TEF_TWO_STREAMS=0 TEF_WGRAD_GROUP=0 timeout -k 5 300 rocprofv3 --pmc $C --kernel-include-regex "halo_kernel|gemm_nt_kernel" --output-format csv -d $O/conv_$C -- python3 bench.py --mode train --steps 1 --warmup 1 --no-cpu-baseline > $O/conv_$C.json 2> $O/conv_$C.err
   timeout -k 5 100 rocprofv3 --pmc $C --output-format csv -d $O/peak_$C -- $O/mfma_f32_peak > $O/peak_$C.out 2> $O/peak_$C.err
 done
 python3 - <<PY
