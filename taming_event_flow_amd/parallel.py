@@ -244,6 +244,12 @@ class _FlagBoard:
             raise RuntimeError(f"shared memory unavailable: {err}")
         if self.rank != 0:
             shm = shared_memory.SharedMemory(name=name[0])
+            try:      # (attaching registers the segment with this process's resource tracker, which would unlink it — again — at exit)
+                from multiprocessing import resource_tracker
+
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:              # noqa: BLE001
+                pass
         self.shm = shm
         self.words = np.ndarray((2, self.world, 2), dtype=np.uint64, buffer=shm.buf)      # [bank][rank][(seq, mask)]
         self.seq = 0
