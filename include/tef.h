@@ -436,6 +436,13 @@ typedef struct tef_net_plan {
      * 5120-pixel ones (110 TFLOP/s).  dec_only = 1: the arenas hold no encoder buffers (tef_net_tape_floats etc. follow). */
     const float *hn_ext[TEF_NET_MAX_LEVELS];
     int dec_only;
+    /* (round 6) 3x3 layers whose weight gradient the multi-part kernels cannot run (the deepest stride-2 head: 8 x 8 outputs)
+     * used to reduce per pass, 45 us each for 1.2 GFLOP.  copy_batch = 1: the caller promises to hand tef_net_window_wgrads a
+     * workspace (wgrad_ws / wgrad_ws_bytes >= tef_net_window_wgrads_workspace) — such a layer is then deferred too: the
+     * passes' pre-activation gradients and inputs (a few MB) are copied side by side and reduced as ONE batch. */
+    int copy_batch;
+    void *wgrad_ws;
+    size_t wgrad_ws_bytes;
 } tef_net_plan;
 size_t tef_net_tape_floats(const tef_net_plan *p);
 size_t tef_net_gtape_floats(const tef_net_plan *p);
@@ -481,6 +488,8 @@ int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *
 /* the same for one half of the layers: part = TEF_NET_ENCODERS (heads + ConvGRU gates), TEF_NET_DECODERS (residual blocks,
  * decoders, prediction heads) or both.  A data-parallel caller reduces the decoder half first and all-reduces its slice
  * of the gradient bucket while the encoder half is still being reduced (train.Trainer). */
+/* workspace bytes tef_net_window_wgrads needs in plan->wgrad_ws for `npass` passes when plan->copy_batch is set (0: none) */
+size_t tef_net_window_wgrads_workspace(const tef_net_plan *p, int npass);
 int tef_net_window_wgrads_part(const tef_net_plan *p, int part, int npass, const float *const *x,
                                const float *const *const *states_in, const float *const *tape, const float *const *gtape,
                                const unsigned long long *ran, void *stream);

@@ -87,6 +87,7 @@ class NetPlan(ctypes.Structure):
         ("gate_o", NetConv * TEF_NET_MAX_LEVELS), ("res1", NetConv * TEF_NET_MAX_RES), ("res2", NetConv * TEF_NET_MAX_RES),
         ("dec", NetConv * TEF_NET_MAX_LEVELS), ("pred", NetConv * TEF_NET_MAX_LEVELS),
         ("hn_ext", _fp * TEF_NET_MAX_LEVELS), ("dec_only", ctypes.c_int),
+        ("copy_batch", ctypes.c_int), ("wgrad_ws", _fp), ("wgrad_ws_bytes", ctypes.c_size_t),
     ]
 
 # name -> (restype, argtypes); every symbol include/tef.h declares
@@ -193,6 +194,7 @@ SIGNATURES = {
     "tef_net_window_wgrads": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.POINTER(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ulonglong), _fp]),
+    "tef_net_window_wgrads_workspace": (ctypes.c_size_t, [ctypes.POINTER(NetPlan), ctypes.c_int]),
     "tef_net_window_wgrads_part": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                                   ctypes.POINTER(ctypes.POINTER(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p),
                                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ulonglong), _fp]),

@@ -229,19 +229,26 @@ const char *lbl(const char *fmt, int idx)
 
 // input gradients of a convolution whose pre-activation gradient g is formed; the weight gradient is accumulated now
 // unless the layer defers it (then g stays in the arena for tef_net_window_wgrads)
-int conv_bwd(const tef_conv_desc &d, const tef_net_conv &c, const float *g, const float *x0, const float *x1, float *dx0,
+// 3x3 single-source layers outside the multi-part weight-gradient kernels: deferred all the same when the caller has promised
+// a workspace for tef_net_window_wgrads (plan.copy_batch): their passes are copied side by side and reduced as one batch
+inline bool copy_batch_ok(const tef_net_plan *p, const tef_conv_desc &d)
+{
+    return p->copy_batch && d.ksize == 3 && d.C1 == 0 && !tef_conv_wgrad_parts_supported(&d);
+}
+
+int conv_bwd(const tef_net_plan *p, const tef_conv_desc &d, const tef_net_conv &c, const float *g, const float *x0, const float *x1, float *dx0,
              float *dx1, void *ws, size_t ws_bytes, void *stream)
 {
-    const bool defer = c.defer && tef_conv_wgrad_parts_supported(&d);
+    const bool defer = c.defer && (tef_conv_wgrad_parts_supported(&d) || copy_batch_ok(p, d));
     return tef_conv_backward_keep(&d, x0, x1, nullptr, c.w2, nullptr, nullptr, g, nullptr, d.N, dx0, dx1,
                                   defer ? nullptr : c.dw, nullptr, nullptr, nullptr, d.N, nullptr, ws, ws_bytes, stream);
 }
 
 // the same, delivering the pre-activation gradient of the layer that produced the input (tef_conv_backward_post)
-int conv_bwd_post(const tef_conv_desc &d, const tef_net_conv &c, const float *g, const float *x0, const tef_conv_post &post, void *ws,
+int conv_bwd_post(const tef_net_plan *p, const tef_conv_desc &d, const tef_net_conv &c, const float *g, const float *x0, const tef_conv_post &post, void *ws,
                   size_t ws_bytes, void *stream)
 {
-    const bool defer = c.defer && tef_conv_wgrad_parts_supported(&d);
+    const bool defer = c.defer && (tef_conv_wgrad_parts_supported(&d) || copy_batch_ok(p, d));
     return tef_conv_backward_post(&d, x0, c.w2, g, defer ? nullptr : c.dw, &post, ws, ws_bytes, stream);
 }
 
@@ -422,7 +429,7 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         } else {
             if (ns) {
                 TEF_TRY(tef_grad_act(srcs, ns, tape + t.p[k], p->final_act, g.B, p->nout, hw, gtape + q.gp[k], p->pred[k].db, stream));
-                TEF_TRY(conv_bwd(D.pred[k], p->pred[k], gtape + q.gp[k], tape + t.d[k], nullptr, gtape + q.dd[k], nullptr, ws, ws_bytes, stream));
+                TEF_TRY(conv_bwd(p, D.pred[k], p->pred[k], gtape + q.gp[k], tape + t.d[k], nullptr, gtape + q.dd[k], nullptr, ws, ws_bytes, stream));
                 ran |= bit_pred(k);
                 feat[nf++] = gtape + q.dd[k];
             }
@@ -437,7 +444,7 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         const float *x0 = k ? tape + t.upp[k] : tape + t.upx[k], *x1 = k ? tape + t.upx[k] : nullptr;
         {
             TEF_LAYER("dec%d dgrad", k);
-            TEF_TRY(conv_bwd(D.dec[k], p->dec[k], gtape + q.gd[k], x0, x1, gtape + q.dx0[k], k ? gtape + q.dx1[k] : nullptr, ws, ws_bytes, stream));
+            TEF_TRY(conv_bwd(p, D.dec[k], p->dec[k], gtape + q.gd[k], x0, x1, gtape + q.dx0[k], k ? gtape + q.dx1[k] : nullptr, ws, ws_bytes, stream));
         }
         ran |= bit_dec(k);
         TEF_LAYER("dec%d.up bwd", k);
@@ -468,15 +475,15 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         {
             TEF_LAYER("res%d.conv2 dgrad", j);
             tef_conv_post post{tape + t.mid[j], TEF_ACT_RELU, nullptr, gtape + q.gmid[j], p->res1[j].db};
-            TEF_TRY(conv_bwd_post(D.res, p->res2[j], gtape + q.gy[j], tape + t.mid[j], post, ws, ws_bytes, stream));
+            TEF_TRY(conv_bwd_post(p, D.res, p->res2[j], gtape + q.gy[j], tape + t.mid[j], post, ws, ws_bytes, stream));
         }
         TEF_LAYER("res%d.conv1 dgrad", j);
         if (j > 0) {
             tef_conv_post post{tape + t.y[j - 1], TEF_ACT_RELU, gtape + q.gy[j], gtape + q.gy[j - 1], p->res2[j - 1].db};
-            TEF_TRY(conv_bwd_post(D.res, p->res1[j], gtape + q.gmid[j], xin, post, ws, ws_bytes, stream));
+            TEF_TRY(conv_bwd_post(p, D.res, p->res1[j], gtape + q.gmid[j], xin, post, ws, ws_bytes, stream));
             gy_formed = true;
         } else {
-            TEF_TRY(conv_bwd(D.res, p->res1[j], gtape + q.gmid[j], xin, nullptr, gtape + q.dres[j], nullptr, ws, ws_bytes, stream));
+            TEF_TRY(conv_bwd(p, D.res, p->res1[j], gtape + q.gmid[j], xin, nullptr, gtape + q.dres[j], nullptr, ws, ws_bytes, stream));
         }
         ran |= bit_res1(j) | bit_res2(j);
         srcs[0] = gtape + q.dres[j];      // through the two convolutions + the residual connection itself
@@ -529,7 +536,7 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         TEF_LAYER("enc%d.head dgrad", i);
         const bool want = i > 0 || want_dx;
         const float *xin = i ? tape + t.hn[i - 1] : x;
-        TEF_TRY(conv_bwd(D.head[i], p->head[i], gtape + q.g_e[i], xin, nullptr, want ? gtape + q.dxin[i] : nullptr, nullptr, ws, ws_bytes, stream));
+        TEF_TRY(conv_bwd(p, D.head[i], p->head[i], gtape + q.g_e[i], xin, nullptr, want ? gtape + q.dxin[i] : nullptr, nullptr, ws, ws_bytes, stream));
         ran |= bit_head(i);
         if (want) {
             if (i > 0) { srcs[0] = gtape + q.dxin[i]; ns = 1; }
@@ -543,6 +550,26 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
 // The window's deferred weight gradients: per layer ONE reduction over the pixels of all passes (tef_conv_wgrad_parts, up to
 // TEF_CONV_MAX_PARTS passes per launch) instead of one short, atomics-heavy reduction per pass.  x / states_in / tape /
 // gtape / ran: the arguments and results of the npass backward calls since the last flush (any order).
+size_t tef_net_window_wgrads_workspace(const tef_net_plan *p, int npass)
+{
+    Geo g;
+    if (!make_geo(p, &g) || !p->copy_batch || npass < 1) return 0;
+    const Descs D = make_descs(p, g, 0);
+    size_t need = 0;
+    auto one = [&](const tef_conv_desc &d) {
+        if (!copy_batch_ok(p, d)) return;
+        const int pad = d.ksize / 2, Ho = (d.H + 2 * pad - d.ksize) / d.stride + 1, Wo = (d.W + 2 * pad - d.ksize) / d.stride + 1;
+        const size_t gsz = (size_t)d.B * d.N * Ho * Wo, xsz = (size_t)d.B * d.C0 * d.H * d.W;
+        tef_conv_desc db = d;
+        db.B = d.B * npass;
+        need = std::max(need, ((((size_t)npass * (gsz + xsz) * sizeof(float)) + 255) & ~(size_t)255) + tef_conv_workspace_bytes(&db));
+    };
+    for (int i = 0; i < g.lv && !p->dec_only; ++i) one(D.head[i]);
+    one(D.res);
+    for (int k = 0; k < g.lv; ++k) one(D.dec[k]);
+    return need;
+}
+
 int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran, void *stream)
 {
@@ -563,7 +590,35 @@ int tef_net_window_wgrads_part(const tef_net_plan *p, int part, int npass, const
     const float *gs[TEF_CONV_MAX_PARTS], *x0s[TEF_CONV_MAX_PARTS], *x1s[TEF_CONV_MAX_PARTS], *gts[TEF_CONV_MAX_PARTS];
     // one layer: collect the passes in which it ran, reduce them in groups
     auto layer = [&](const char *label, const tef_conv_desc &d, const tef_net_conv &c, uint64_t bit, auto part) -> int {
-        if (!c.defer || !tef_conv_wgrad_parts_supported(&d)) return 0;
+        if (!c.defer) return 0;
+        if (!tef_conv_wgrad_parts_supported(&d)) {
+            if (!copy_batch_ok(p, d)) return 0;
+            // the passes in which the layer ran, side by side in the workspace: one reduction over a batch of n x B samples
+            tef::LayerScope layer_scope_(label, (hipStream_t)stream);
+            int n = 0;
+            for (int s = 0; s < npass; ++s) n += (ran[s] & bit) ? 1 : 0;
+            if (!n) return 0;
+            const int pad = d.ksize / 2, Ho = (d.H + 2 * pad - d.ksize) / d.stride + 1, Wo = (d.W + 2 * pad - d.ksize) / d.stride + 1;
+            const size_t gsz = (size_t)d.B * d.N * Ho * Wo, xsz = (size_t)d.B * d.C0 * d.H * d.W;
+            tef_conv_desc db = d;
+            db.B = d.B * n;
+            const size_t head = (((size_t)n * (gsz + xsz) * sizeof(float)) + 255) & ~(size_t)255, cws = tef_conv_workspace_bytes(&db);
+            if (!p->wgrad_ws || p->wgrad_ws_bytes < head + cws)
+                return tef::fail("tef_net_window_wgrads: plan.copy_batch needs plan.wgrad_ws (tef_net_window_wgrads_workspace)"), TEF_ERR_WORKSPACE;
+            float *G = (float *)p->wgrad_ws, *X = G + (size_t)n * gsz;
+            int k = 0;
+            for (int s = 0; s < npass; ++s) {
+                if (!(ran[s] & bit)) continue;
+                const float *gg, *a, *b, *c_;
+                part(s, gg, a, b, c_);
+                if (hipMemcpyAsync(G + (size_t)k * gsz, gg, gsz * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess ||
+                    hipMemcpyAsync(X + (size_t)k * xsz, a, xsz * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+                    return tef::fail("tef_net_window_wgrads: hipMemcpyAsync"), TEF_ERR_LAUNCH;
+                ++k;
+            }
+            return tef_conv_backward_keep(&db, X, nullptr, nullptr, nullptr, nullptr, nullptr, G, nullptr, db.N, nullptr, nullptr, c.dw, c.dw2,
+                                          nullptr, nullptr, c.dw2 ? db.N / 2 : db.N, nullptr, (char *)p->wgrad_ws + head, p->wgrad_ws_bytes - head, stream);
+        }
         tef::LayerScope layer_scope_(label, (hipStream_t)stream);
         int n = 0;
         for (int s = 0; s <= npass; ++s) {

@@ -138,6 +138,7 @@ class PassEngine:
         if (part & 1) or pl is None:
             pl = _lib.NetPlan()
             pl.dec_only = 1 if dec_only else 0
+            pl.copy_batch = 1        # (flush_window hands tef_net_window_wgrads its workspace: _launch_wgrads)
             pl.B, pl.H, pl.W = B, Hp, Wp
             pl.bins, pl.levels, pl.nres, pl.nout = np_.num_bins, np_.levels, np_.nres, np_.nout
             pl.final_act = ACT[np_.final_activation]
@@ -480,13 +481,22 @@ class PassEngine:
                 rans = (ctypes.c_ulonglong * npass)(*[r.ran for r in grp])
                 if grp[0].hn is not None:        # one launch set per window record (each has its own stack of states in its plan)
                     for q in range(npass):
+                        nws = _lib.lib().tef_net_window_wgrads_workspace(ctypes.byref(grp[q].plan), 1)
+                        if nws:
+                            ws_ = self.workspace(nws, grp[q].tape.device)
+                            grp[q].plan.wgrad_ws, grp[q].plan.wgrad_ws_bytes = ws_.data_ptr(), ws_.numel()
                         rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(grp[q].plan), 2, 1, (ctypes.c_void_p * 1)(xs[q]),
                                                                    (ctypes.POINTER(ctypes.c_void_p) * 1)(sts[q]), (ctypes.c_void_p * 1)(tapes[q]),
                                                                    (ctypes.c_void_p * 1)(gtapes[q]), (ctypes.c_ulonglong * 1)(rans[q]),
                                                                    _lib.stream_ptr())
                         _lib.check(rc, "tef_net_window_wgrads")
                 else:
-                    rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(grp[-1].plan), int(part), npass, xs, sts, tapes, gtapes, rans,
+                    pl_ = grp[-1].plan
+                    nws = _lib.lib().tef_net_window_wgrads_workspace(ctypes.byref(pl_), npass)
+                    if nws:              # layers reduced as one copied batch (plan.copy_batch: the deepest stride-2 head)
+                        ws_ = self.workspace(nws, grp[-1].tape.device)
+                        pl_.wgrad_ws, pl_.wgrad_ws_bytes = ws_.data_ptr(), ws_.numel()
+                    rc = _lib.lib().tef_net_window_wgrads_part(ctypes.byref(pl_), int(part), npass, xs, sts, tapes, gtapes, rans,
                                                                _lib.stream_ptr())
                     _lib.check(rc, "tef_net_window_wgrads")
             if between is not None and k + 1 < len(parts):

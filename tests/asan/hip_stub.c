@@ -1,6 +1,6 @@
 /* Dry-run HIP runtime for the host-side sanitizer run of libtef_hip.so (tests/asan/run_host_asan.sh; test build only, never
  * part of the product): every entry point the library imports, as a no-op that reports success.  Kernel launches do nothing;
- * hipMemsetAsync really writes — the "device" buffers of the dry run are host tensors, so a memset past the end of one is an
+ * hipMemsetAsync and hipMemcpyAsync really write — the "device" buffers of the dry run are host tensors, so a memset past the end of one is an
  * AddressSanitizer report.  Preloaded in front of libamdhip64.so, whose versioned symbols these unversioned ones satisfy. */
 #include <stddef.h>
 #include <string.h>
@@ -31,6 +31,8 @@ int hipFuncSetAttribute(const void *f, int attr, int v) { (void)f; (void)attr; (
 int hipGetDevice(int *d) { if (d) *d = 0; return 0; }
 int hipDeviceGetAttribute(int *v, int attr, int dev) { (void)attr; (void)dev; if (v) *v = 256; return 0; }
 int hipMemsetAsync(void *p, int value, size_t n, void *stream) { (void)stream; memset(p, value, n); return 0; }
+/* (a real copy too: the window's copied weight-gradient batches, tef_net_window_wgrads with plan.copy_batch) */
+int hipMemcpyAsync(void *dst, const void *src, size_t n, int kind, void *stream) { (void)kind; (void)stream; memcpy(dst, src, n); return 0; }
 int hipEventCreate(void **e) { static int dummy; if (e) *e = &dummy; return 0; }
 int hipEventRecord(void *e, void *s) { (void)e; (void)s; return 0; }
 int hipEventSynchronize(void *e) { (void)e; return 0; }
