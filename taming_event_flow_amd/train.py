@@ -291,6 +291,10 @@ class Trainer:
         self.window_decode = (eng is not None and torch.device(device).type == "cuda" and hasattr(self.model.arch, "encode")
                               and os.environ.get("TEF_WINDOW_DECODE", "1") != "0") if window_decode is None else bool(window_decode)
         self._win_inputs = []
+        if self.window_decode and hasattr(self.loss_function, "defer_update"):
+            # the P update() calls of a window follow its batched decoders back to back: packed in ONE launch when the loss is
+            # evaluated (tef_update_window) instead of ten (the module refuses a list buffer it has already recorded: below)
+            self.loss_function.defer_update = True
         if eng is not None and torch.device(device).type == "cuda" and streams:
             if not self.window_decode:       # (pass-by-pass decoders: on a side stream beside the next pass's encoders)
                 self.dec_stream = torch.cuda.Stream(device=device)
@@ -515,6 +519,15 @@ class Trainer:
         if self.window_decode and torch.is_grad_enabled() and arch.direct_grads:
             P = cfg["data"]["passes_loss"]
             arch.encode(inputs["net_input"])
+            # the event lists are read when the window is complete: a loader that writes every pass into ONE buffer would have
+            # them all read that buffer's last contents
+            for k in ("event_list", "d_event_list"):
+                t_ = inputs[k]
+                if isinstance(t_, torch.Tensor) and t_.numel() and any(b_[k].data_ptr() == t_.data_ptr() for b_ in self._win_inputs
+                                                                        if isinstance(b_[k], torch.Tensor) and b_[k].numel()):
+                    raise RuntimeError(f"train.Trainer (window mode): the {k} of this pass lives in the storage of an earlier pass of "
+                                       "the window; the batches of a window must stay alive and unchanged until its last pass — hand "
+                                       "in a tensor per pass, or Trainer(..., window_decode=False)")
             self._win_inputs.append(inputs)
             if len(self._win_inputs) < P:
                 return False
