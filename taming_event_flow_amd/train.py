@@ -387,7 +387,10 @@ class Trainer:
                 self.warmup_losses.append(float(self.last_loss.item()))
             return cw
         inputs = [{k: v.clone() for k, v in b.items()} for b in batches]          # public static input buffers
-        work = [{k: torch.empty_like(v) for k, v in b.items()} for b in batches]   # update() shifts timestamps in place
+        # update() shifts the time stamps of the two event lists in place (loss/flow.py:457-458): those two get a working copy
+        # per replay, everything else is read from the static buffers directly (round 6: 70 -> 20 copy launches per window)
+        inplace = ("event_list", "d_event_list")
+        work = [{k: (torch.empty_like(v) if k in inplace else inputs[t][k]) for k, v in b.items()} for t, b in enumerate(batches)]
         # In window mode a CAPTURED window keeps its weight-gradient reductions on the capture stream (round 6, measured: the
         # window is bound by the sum of its kernels, and a replayed graph gains nothing from the third stream — 31.9 ms
         # against 32.4 with groups of three passes on it; the eager window, whose launches the host feeds, keeps the stream)
@@ -413,7 +416,8 @@ class Trainer:
         def run_head(stage=0):   # everything up to the local gradient (stage 1: without the encoder half's last reduction)
             for src, dst in zip(inputs, work):
                 for k in src:
-                    dst[k].copy_(src[k])
+                    if dst[k] is not src[k]:
+                        dst[k].copy_(src[k])
                 complete = self._forward_update(dst)
             assert complete
             loss = self.loss_function()
