@@ -15,8 +15,12 @@ stream (36.7 instead of 33 ms).  `LazyFlow` lets that caller keep the overlap wi
     ``__torch_function__`` — first makes the current stream wait for the side stream and then works on the plain tensor:
     to any other consumer the flows behave like joined flows.
 
-What does not go through ``__torch_function__`` (``data_ptr()`` handed to foreign code right away, the DLPack / CUDA array
-interfaces) would see memory that is still being written: `TEF_LAZY_FLOWS=0` switches the mechanism off.
+That includes the interfaces that hand the memory to code torch does not see — ``data_ptr()``, DLPack
+(``torch.utils.dlpack.to_dlpack`` / ``__dlpack__``), ``__cuda_array_interface__``: on this torch they are dispatched through
+``__torch_function__`` like any other method, so the caller's stream has been made to wait before the pointer leaves
+(tests/test_lazy_flow_gpu.py::test_raw_pointer_interfaces_join_first, with the decoder half held back).  What the mechanism
+cannot cover is foreign code that then uses the pointer on a stream of ITS OWN without ordering it behind the caller's — the
+same contract as for any torch tensor.  `TEF_LAZY_FLOWS=0` switches the mechanism off.
 """
 import torch
 
