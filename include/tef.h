@@ -481,6 +481,14 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
                                const float *const *dflows, const float *const *dstates, int want_dx, float *gtape,
                                unsigned long long *ran, long long *dstate_off, int *dx_valid, void *workspace,
                                size_t workspace_bytes, void *stream);
+/* tef_net_pass_backward_part with a SECOND set of gradients w.r.t. the new states (dstates2, NULL or one pointer or NULL per
+ * level), added where dstates are: the batched decoder half of a loss window hands its share to the encoder halves directly
+ * (train.Trainer's window mode), the gradients arriving from the next pass come through autograd as before — no sum of the
+ * two as a launch of its own. */
+int tef_net_pass_backward_part2(const tef_net_plan *p, int part, const float *x, const float *const *states_in, const float *tape,
+                                const float *const *dflows, const float *const *dstates, const float *const *dstates2,
+                                int want_dx, float *gtape, unsigned long long *ran, long long *dstate_off, int *dx_valid,
+                                void *workspace, size_t workspace_bytes, void *stream);
 /* the deferred weight gradients of a BPTT window: per layer one reduction over the pixels of all npass backward calls */
 int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran,

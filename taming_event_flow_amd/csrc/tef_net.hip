@@ -389,6 +389,15 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
                                unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws, size_t ws_bytes,
                                void *stream)
 {
+    return tef_net_pass_backward_part2(p, part, x, states_in, tape, dflows, dstates, nullptr, want_dx, gtape, ran_out, dstate_off,
+                                       dx_valid, ws, ws_bytes, stream);
+}
+
+int tef_net_pass_backward_part2(const tef_net_plan *p, int part, const float *x, const float *const *states_in, const float *tape,
+                                const float *const *dflows, const float *const *dstates, const float *const *dstates2, int want_dx,
+                                float *gtape, unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws,
+                                size_t ws_bytes, void *stream)
+{
     Geo g;
     if (!make_geo(p, &g)) return TEF_ERR_INVALID;
     const bool enc = part & TEF_NET_ENCODERS, dec = part & TEF_NET_DECODERS;
@@ -517,6 +526,7 @@ int tef_net_pass_backward_part(const tef_net_plan *p, int part, const float *x, 
         const float *sg = skip_grads[g.lv - 1 - i];
         if (sg) sources[n++] = sg;
         if (dstates[i]) sources[n++] = dstates[i];
+        if (dstates2 && dstates2[i]) sources[n++] = dstates2[i];
         ns = 0;
         if (!n) continue;
         if (n > 4) return tef::fail("tef_net_pass_backward: more than four gradient addends at a state"), TEF_ERR_INVALID;

@@ -53,7 +53,7 @@ class _Tape:
     """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
     __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape", "gtape", "ran", "targets_set", "queued",
-                 "stream", "hn", "new_states")
+                 "stream", "hn", "new_states", "dec_dstates")
 
 
 class PassEngine:
@@ -261,7 +261,7 @@ class PassEngine:
             rec.states_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
             rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-            rec.hn = rec.new_states = None
+            rec.hn = rec.new_states = rec.dec_dstates = None
         pl = rec.plan
         if part == 2:
             self.make_plan(pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left, 2, pl)
@@ -305,7 +305,7 @@ class PassEngine:
         rec.tape = torch.empty((ntape,), dtype=torch.float32, device=dev)
         rec.geom, rec.x_shape = recs[0].geom, (P * B,) + tuple(recs[0].x_shape[1:])
         rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-        rec.hn, rec.new_states = hn, None
+        rec.hn, rec.new_states, rec.dec_dstates = hn, None, None
         ws = self.workspace(wsb, dev)
         rc = _lib.lib().tef_net_pass_forward_part(ctypes.byref(pl), 2, None, None, rec.tape.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   _lib.stream_ptr())
@@ -315,7 +315,7 @@ class PassEngine:
         flows = [[rec.tape[fo[k] + t * per:fo[k] + (t + 1) * per].view(B, plan.nout, H, W) for k in range(n)] for t in range(P)]
         return flows, rec
 
-    def backward(self, rec, dflows, dstates, params, want_dx, part=3):
+    def backward(self, rec, dflows, dstates, params, want_dx, part=3, dstates2=None):
         """-> (gradients w.r.t. the incoming states, gradient w.r.t. the network input or None, parameter gradients for
         autograd).  Parameter gradients are added into the parameters' own .grad buffers when the training loop owns them
         (`direct_grads`: nothing is handed to autograd), otherwise into one fresh zero buffer whose views are returned.
@@ -366,9 +366,18 @@ class PassEngine:
         off = (ctypes.c_longlong * n)()
         dxv = ctypes.c_int(0)
         ws = self.workspace(wsb, dev)
-        rc = _lib.lib().tef_net_pass_backward_part(ctypes.byref(pl), part, _p(rec.xp), rec.states_arr, rec.tape.data_ptr(),
-                                                   a_dfl, a_dst, 1 if want_dx else 0, gtape.data_ptr(), ctypes.byref(ran), off,
-                                                   ctypes.byref(dxv), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        if dstates2 is not None and any(g is not None for g in dstates2):
+            # a second addend per new state (window mode: the batched decoders' share, handed over beside autograd)
+            dst2 = [None if g is None else g.to(torch.float32).contiguous() for g in dstates2]
+            a_dst2 = (ctypes.c_void_p * n)(*[_p(g) for g in dst2])
+            rc = _lib.lib().tef_net_pass_backward_part2(ctypes.byref(pl), part, _p(rec.xp), rec.states_arr, rec.tape.data_ptr(),
+                                                        a_dfl, a_dst, a_dst2, 1 if want_dx else 0, gtape.data_ptr(),
+                                                        ctypes.byref(ran), off, ctypes.byref(dxv), ws.data_ptr(), ws.numel(),
+                                                        _lib.stream_ptr())
+        else:
+            rc = _lib.lib().tef_net_pass_backward_part(ctypes.byref(pl), part, _p(rec.xp), rec.states_arr, rec.tape.data_ptr(),
+                                                       a_dfl, a_dst, 1 if want_dx else 0, gtape.data_ptr(), ctypes.byref(ran), off,
+                                                       ctypes.byref(dxv), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "tef_net_pass_backward")
         rec.ran |= ran.value
         shapes = [t_.shape for t_ in (rec.hn if rec.hn is not None else rec.states_in)]      # (a window's decoders: the stacked states)
@@ -539,11 +548,16 @@ class _EncFn(torch.autograd.Function):
         ctx.params = rest[nstates:]
         ctx.state_given = [s is not None for s in states]
         ctx.want_dx = bool(x.requires_grad)
+        ctx.set_materialize_grads(False)      # (a state nobody differentiated arrives as None, not as a tensor of zeros)
         return tuple(new_states)
 
     @staticmethod
     def backward(ctx, *dstates):
-        dh, dx, pg = ctx.engine.backward(ctx.rec, None, list(dstates), ctx.params, ctx.want_dx, part=1)
+        # window mode: the batched decoder half has left its share of the new states' gradients at the record (_DecWinFn);
+        # `dstates` are then what the NEXT pass's encoder half sends (nothing at the window's last pass)
+        dec = ctx.rec.dec_dstates
+        ctx.rec.dec_dstates = None
+        dh, dx, pg = ctx.engine.backward(ctx.rec, None, list(dstates), ctx.params, ctx.want_dx, part=1, dstates2=dec)
         ctx.rec = None
         dh = [g if given else None for g, given in zip(dh, ctx.state_given)]
         return (None, None, None, dx) + tuple(dh) + tuple(pg)
@@ -579,6 +593,7 @@ class _DecWinFn(torch.autograd.Function):
         states = [list(rest[t * nstates:(t + 1) * nstates]) for t in range(P)]
         flows, rec = engine.decode_window(recs, states)
         ctx.engine, ctx.rec, ctx.P, ctx.nstates = engine, rec, P, nstates
+        ctx.recs = list(recs)
         ctx.params = rest[P * nstates:]
         return tuple(f for t in range(P) for f in flows[t])
 
@@ -596,8 +611,14 @@ class _DecWinFn(torch.autograd.Function):
                 dfl.append(torch.cat([g if g is not None else torch.zeros_like(have[0]) for g in gs], 0))
         ds, _, pg = engine.backward(rec, dfl, None, ctx.params, False, part=2)
         ctx.rec = None
-        out = [None if ds[i] is None else ds[i][t * B:(t + 1) * B] for t in range(P) for i in range(n)]
-        return (None, None, None) + tuple(out) + tuple(pg)
+        # What this half sends to the new states goes to the passes' encoder halves DIRECTLY (their records), not through
+        # autograd: there it would be added to the next pass's gradient by a launch per state and pass (36 per window);
+        # the encoder half's first kernel sums its addends anyway.  The encoder nodes still run — each is reached through
+        # the states it produced, with None where nothing else arrives.
+        for t, r in enumerate(ctx.recs):
+            r.dec_dstates = [None if ds[i] is None else ds[i][t * B:(t + 1) * B] for i in range(n)]
+        ctx.recs = None
+        return (None, None, None) + (None,) * (P * n) + tuple(pg)
 
 
 def encode_pass(engine, x, states):
