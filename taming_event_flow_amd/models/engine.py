@@ -555,8 +555,9 @@ class _EncFn(torch.autograd.Function):
     def backward(ctx, *dstates):
         # window mode: the batched decoder half has left its share of the new states' gradients at the record (_DecWinFn);
         # `dstates` are then what the NEXT pass's encoder half sends (nothing at the window's last pass)
-        dec = ctx.rec.dec_dstates
-        ctx.rec.dec_dstates = None
+        dec = None
+        if ctx.rec is not None:      # (None: a second backward through the pass — engine.backward says so)
+            dec, ctx.rec.dec_dstates = ctx.rec.dec_dstates, None
         dh, dx, pg = ctx.engine.backward(ctx.rec, None, list(dstates), ctx.params, ctx.want_dx, part=1, dstates2=dec)
         ctx.rec = None
         dh = [g if given else None for g, given in zip(dh, ctx.state_given)]

@@ -413,11 +413,13 @@ class Trainer:
 
         overlap = split and self._dp_overlap() is not None
 
+        # the working copies of the whole window in one multi-tensor copy (the static buffers hold every pass before the replay)
+        pairs = [(dst[k], src[k]) for src, dst in zip(inputs, work) for k in src if dst[k] is not src[k]]
+
         def run_head(stage=0):   # everything up to the local gradient (stage 1: without the encoder half's last reduction)
-            for src, dst in zip(inputs, work):
-                for k in src:
-                    if dst[k] is not src[k]:
-                        dst[k].copy_(src[k])
+            if pairs:
+                torch._foreach_copy_([d_ for d_, _ in pairs], [s_ for _, s_ in pairs])
+            for dst in work:
                 complete = self._forward_update(dst)
             assert complete
             loss = self.loss_function()
@@ -446,8 +448,7 @@ class Trainer:
         self.model.arch.states = static_states
         def tail():
             self._apply_update()
-            for dst, src in zip(static_states, self.model.arch.states):
-                dst.copy_(src.detach())
+            torch._foreach_copy_(list(static_states), [src.detach() for src in self.model.arch.states])
 
         graph, graph_tail, graph_mid = torch.cuda.CUDAGraph(), None, None
         with torch.cuda.graph(graph):
