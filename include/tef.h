@@ -489,6 +489,19 @@ int tef_net_pass_backward_part2(const tef_net_plan *p, int part, const float *x,
                                 const float *const *dflows, const float *const *dstates, const float *const *dstates2,
                                 int want_dx, float *gtape, unsigned long long *ran, long long *dstate_off, int *dx_valid,
                                 void *workspace, size_t workspace_bytes, void *stream);
+/* The encoder half of a pass by LEVEL RANGE [lo, hi) — for a caller that pipelines the levels of consecutive passes over
+ * streams: level i of pass t + 1 needs only level i - 1 of pass t + 1 and level i of pass t (models/arch.py:217-227), so the
+ * lower levels of pass t + 1 can run beside the upper levels of pass t.  All ranges of a pass share its tape and gradient
+ * arena; forward: ranges in ascending order (level lo reads state lo - 1 from the tape; lo = 0 reads x); backward: descending.
+ * Backward: above_valid = the dx_valid the call for [hi, ...) returned (ignored when hi is the top): the gradient w.r.t.
+ * state hi - 1 it left in the arena is added at level hi - 1.  *dx_valid: lo = 0: as tef_net_pass_backward; lo > 0: whether
+ * such a gradient was left for the levels below.  dstates / dstates2 / dstate_off are indexed by level as in _part2. */
+int tef_net_pass_forward_levels(const tef_net_plan *p, int lo, int hi, const float *x, const float *const *states_in, float *tape,
+                                void *workspace, size_t workspace_bytes, void *stream);
+int tef_net_pass_backward_levels(const tef_net_plan *p, int lo, int hi, int above_valid, const float *x,
+                                 const float *const *states_in, const float *tape, const float *const *dstates,
+                                 const float *const *dstates2, int want_dx, float *gtape, unsigned long long *ran,
+                                 long long *dstate_off, int *dx_valid, void *workspace, size_t workspace_bytes, void *stream);
 /* the deferred weight gradients of a BPTT window: per layer one reduction over the pixels of all npass backward calls */
 int tef_net_window_wgrads(const tef_net_plan *p, int npass, const float *const *x, const float *const *const *states_in,
                           const float *const *tape, const float *const *gtape, const unsigned long long *ran,

@@ -196,6 +196,13 @@ SIGNATURES = {
                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_int,
                                                    _fp, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_longlong),
                                                    ctypes.POINTER(ctypes.c_int), _fp, ctypes.c_size_t, _fp]),
+    "tef_net_pass_forward_levels": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.c_int, _fp,
+                                                   ctypes.POINTER(ctypes.c_void_p), _fp, _fp, ctypes.c_size_t, _fp]),
+    "tef_net_pass_backward_levels": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp,
+                                                    ctypes.POINTER(ctypes.c_void_p), _fp, ctypes.POINTER(ctypes.c_void_p),
+                                                    ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _fp,
+                                                    ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_longlong),
+                                                    ctypes.POINTER(ctypes.c_int), _fp, ctypes.c_size_t, _fp]),
     "tef_net_window_wgrads": (ctypes.c_int, [ctypes.POINTER(NetPlan), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.POINTER(ctypes.c_void_p)), ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_ulonglong), _fp]),

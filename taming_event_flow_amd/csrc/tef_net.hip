@@ -298,20 +298,45 @@ int tef_net_pass_forward(const tef_net_plan *p, const float *x, const float *con
     return tef_net_pass_forward_part(p, TEF_NET_ENCODERS | TEF_NET_DECODERS, x, states_in, tape, ws, ws_bytes, stream);
 }
 
+namespace {
+int pass_forward_impl(const tef_net_plan *p, int part, int lo, int hi, const float *x, const float *const *states_in, float *tape,
+                      void *ws, size_t ws_bytes, void *stream);
+int pass_backward_impl(const tef_net_plan *p, int part, int lo, int hi, int above_valid, const float *x, const float *const *states_in,
+                       const float *tape, const float *const *dflows, const float *const *dstates, const float *const *dstates2,
+                       int want_dx, float *gtape, unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws,
+                       size_t ws_bytes, void *stream);
+}  // namespace
+
 int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, const float *const *states_in, float *tape,
                               void *ws, size_t ws_bytes, void *stream)
 {
+    return pass_forward_impl(p, part, 0, TEF_NET_MAX_LEVELS, x, states_in, tape, ws, ws_bytes, stream);
+}
+
+int tef_net_pass_forward_levels(const tef_net_plan *p, int lo, int hi, const float *x, const float *const *states_in, float *tape,
+                                void *ws, size_t ws_bytes, void *stream)
+{
+    if (lo < 0 || hi <= lo) return tef::fail("tef_net_pass_forward_levels: empty level range"), TEF_ERR_INVALID;
+    return pass_forward_impl(p, TEF_NET_ENCODERS, lo, hi, x, states_in, tape, ws, ws_bytes, stream);
+}
+
+namespace {
+int pass_forward_impl(const tef_net_plan *p, int part, int lo, int hi, const float *x, const float *const *states_in, float *tape,
+                      void *ws, size_t ws_bytes, void *stream)
+{
     Geo g;
     if (!make_geo(p, &g)) return TEF_ERR_INVALID;
+    hi = std::min(hi, g.lv);
+    if (lo >= hi && (part & TEF_NET_ENCODERS)) return tef::fail("tef_net_pass_forward: level range outside the network"), TEF_ERR_INVALID;
     if (!(part & (TEF_NET_ENCODERS | TEF_NET_DECODERS))) return tef::fail("tef_net_pass_forward: no part selected"), TEF_ERR_INVALID;
-    if (!tape || !ws || ((part & TEF_NET_ENCODERS) && (!x || !states_in)))
+    if (!tape || !ws || ((part & TEF_NET_ENCODERS) && ((lo == 0 && !x) || !states_in)))
         return tef::fail("tef_net_pass_forward: null pointer"), TEF_ERR_INVALID;
     if (ws_bytes < workspace_need(p, g)) return tef::fail("tef_net_pass_forward: workspace too small"), TEF_ERR_WORKSPACE;
     const Tape t = make_tape(p, g);
     const Descs D = make_descs(p, g, 1);
     if (part & TEF_NET_ENCODERS) {
-        const float *cur = x;
-        for (int i = 0; i < g.lv; ++i) {
+        const float *cur = lo ? tape + t.hn[lo - 1] : x;      // (levels from lo on: the state below was written by an earlier call)
+        for (int i = lo; i < hi; ++i) {
             if (!states_in[i]) return tef::fail("tef_net_pass_forward: null state (pass zeros for a fresh sequence)"), TEF_ERR_INVALID;
             {
                 TEF_LAYER("enc%d.head fwd", i);
@@ -369,6 +394,7 @@ int tef_net_pass_forward_part(const tef_net_plan *p, int part, const float *x, c
     }
     return 0;
 }
+}  // namespace
 
 int tef_net_pass_backward(const tef_net_plan *p, const float *x, const float *const *states_in, const float *tape,
                           const float *const *dflows, const float *const *dstates, int want_dx, float *gtape,
@@ -398,11 +424,33 @@ int tef_net_pass_backward_part2(const tef_net_plan *p, int part, const float *x,
                                 float *gtape, unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws,
                                 size_t ws_bytes, void *stream)
 {
+    return pass_backward_impl(p, part, 0, TEF_NET_MAX_LEVELS, 0, x, states_in, tape, dflows, dstates, dstates2, want_dx, gtape, ran_out,
+                              dstate_off, dx_valid, ws, ws_bytes, stream);
+}
+
+int tef_net_pass_backward_levels(const tef_net_plan *p, int lo, int hi, int above_valid, const float *x, const float *const *states_in,
+                                 const float *tape, const float *const *dstates, const float *const *dstates2, int want_dx,
+                                 float *gtape, unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws,
+                                 size_t ws_bytes, void *stream)
+{
+    if (lo < 0 || hi <= lo) return tef::fail("tef_net_pass_backward_levels: empty level range"), TEF_ERR_INVALID;
+    return pass_backward_impl(p, TEF_NET_ENCODERS, lo, hi, above_valid, x, states_in, tape, nullptr, dstates, dstates2, want_dx, gtape,
+                              ran_out, dstate_off, dx_valid, ws, ws_bytes, stream);
+}
+
+namespace {
+int pass_backward_impl(const tef_net_plan *p, int part, int lo, int hi, int above_valid, const float *x, const float *const *states_in,
+                       const float *tape, const float *const *dflows, const float *const *dstates, const float *const *dstates2,
+                       int want_dx, float *gtape, unsigned long long *ran_out, long long *dstate_off, int *dx_valid, void *ws,
+                       size_t ws_bytes, void *stream)
+{
     Geo g;
     if (!make_geo(p, &g)) return TEF_ERR_INVALID;
     const bool enc = part & TEF_NET_ENCODERS, dec = part & TEF_NET_DECODERS;
     if (!enc && !dec) return tef::fail("tef_net_pass_backward: no part selected"), TEF_ERR_INVALID;
-    if (!tape || !gtape || !ws || !dstate_off || (dec && !dflows) || (enc && (!x || !states_in || !dstates || !dx_valid)))
+    hi = std::min(hi, g.lv);
+    if (enc && lo >= hi) return tef::fail("tef_net_pass_backward: level range outside the network"), TEF_ERR_INVALID;
+    if (!tape || !gtape || !ws || !dstate_off || (dec && !dflows) || (enc && ((lo == 0 && !x) || !states_in || !dstates || !dx_valid)))
         return tef::fail("tef_net_pass_backward: null pointer"), TEF_ERR_INVALID;
     if (ws_bytes < workspace_need(p, g)) return tef::fail("tef_net_pass_backward: workspace too small"), TEF_ERR_WORKSPACE;
     const Tape t = make_tape(p, g);
@@ -519,7 +567,11 @@ int tef_net_pass_backward_part2(const tef_net_plan *p, int part, const float *x,
         return 0;
     }
     *dx_valid = 0;
-    for (int i = g.lv - 1; i >= 0; --i) {
+    if (!dec && hi < g.lv) {      // a level range: what the call for the levels above left for the state below them
+        ns = 0;
+        if (above_valid) { srcs[0] = gtape + q.dxin[hi]; ns = 1; }
+    }
+    for (int i = hi - 1; i >= lo; --i) {
         const float *sources[4];
         int n = 0;
         for (int a = 0; a < ns; ++a) sources[n++] = srcs[a];
@@ -553,9 +605,11 @@ int tef_net_pass_backward_part2(const tef_net_plan *p, int part, const float *x,
             else *dx_valid = 1;
         }
     }
+    if (lo > 0) *dx_valid = ns == 1;      // (the gradient w.r.t. state lo - 1 waits at gtape + dxin[lo] for the levels below)
     if (ran_out) *ran_out = ran;
     return 0;
 }
+}  // namespace
 
 // The window's deferred weight gradients: per layer ONE reduction over the pixels of all passes (tef_conv_wgrad_parts, up to
 // TEF_CONV_MAX_PARTS passes per launch) instead of one short, atomics-heavy reduction per pass.  x / states_in / tape /

@@ -53,7 +53,7 @@ class _Tape:
     """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
     __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape", "gtape", "ran", "targets_set", "queued",
-                 "stream", "hn", "new_states", "dec_dstates")
+                 "stream", "hn", "new_states", "dec_dstates", "dec_event", "high_event", "above_valid", "hub")
 
 
 class PassEngine:
@@ -66,6 +66,10 @@ class PassEngine:
         self.side_stream = None       # set: passes that record a graph run as two nodes on two streams (module docstring)
         self.defer_join = False       # with side_stream: leave the flows on the side stream (the caller joins)
         self.lazy_flows = False       # with side_stream, without defer_join: hand the flows out as LazyFlow tensors (models/lazy.py)
+        # window mode: (low stream, high stream) — the encoder levels [0, n/2) of pass t + 1 run beside the levels [n/2, n) of
+        # pass t (encode_pass); None: the encoder half of a pass is one call on the caller's stream
+        self.enc_streams = None
+        self.debug_delay_levels = None   # tests: cycles of spinning in front of the (lower, upper) level ranges, forward and backward
         self.debug_delay = None       # tests: cycles of spinning put in front of the (encoder halves, decoder halves[, weight-gradient groups])
         # two-stream windows: the deferred weight gradients of every `wgrad_group` finished backward passes are reduced on
         # `wgrad_stream` while BPTT goes on (the encoder chain leaves the side stream idle about half of the time and
@@ -90,7 +94,7 @@ class PassEngine:
         """Wait for the engine's streams and drop its device buffers (workspaces, cached zero states, unreduced weight
         gradients).  Idempotent; the engine can be used again afterwards."""
         if torch.cuda.is_available() and torch.cuda.is_initialized():
-            for st in (self.side_stream, self.wgrad_stream):
+            for st in (self.side_stream, self.wgrad_stream) + tuple(self.enc_streams or ()):
                 if st is not None:
                     st.synchronize()
             torch.cuda.current_stream().synchronize()
@@ -113,6 +117,19 @@ class PassEngine:
         """Make the current stream wait for the side stream (the decoder halves issued so far)."""
         if self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
+        self.join_encoders()
+
+    def join_encoders(self):
+        """Make the current stream wait for the pipelined encoder halves issued so far (enc_streams)."""
+        if self.enc_streams is not None:
+            cur = torch.cuda.current_stream()
+            if cur in self.enc_streams:
+                # called from a level stream (a group of weight gradients flushed from the lower range's backward): what the
+                # other one did for these passes is already ordered before this point (_EncLowFn.backward), and a direct
+                # wait between the two in this direction is what hipStreamEndCapture does not survive
+                return
+            for s_ in self.enc_streams:
+                cur.wait_stream(s_)
 
     def zero_state(self, shape, device):
         key = (tuple(shape), device)
@@ -223,12 +240,29 @@ class PassEngine:
             tgt(pl.pred[k], (head.conv2d.weight,), (head.conv2d.bias,))
 
     # ---- the pass ----------------------------------------------------------------------------------------------
-    def forward(self, x, states, keep, part=3, rec=None):
+    def forward(self, x, states, keep, part=3, rec=None, levels=None):
         """x [B, bins, H, W] -> (flows: 4 x [B, 2, H, W], new states: 4 x [B, C_i, h_i, w_i], tape | None).
         part 1 (encoders only): flows is None, the record is always returned; part 2 (the rest of the pass `rec` began,
-        on the current stream): new states is None."""
+        on the current stream): new states is None.
+        levels (lo, hi), part 1 only: the encoder levels [lo, hi) alone, on the current stream (tef_net_pass_forward_levels:
+        the levels of consecutive passes pipelined over streams) — lo = 0 begins the pass's record (`states`: ALL incoming
+        states), lo > 0 continues `rec`; new states: those of the range (None elsewhere)."""
         plan = self.plan
         n = plan.levels
+        if levels is not None and levels[0] > 0:
+            cur = torch.cuda.current_stream()
+            if cur != rec.stream and not torch.cuda.is_current_stream_capturing():
+                rec.tape.record_stream(cur)
+            pl = rec.plan
+            _, _, wsb, _, so, _, _ = self.layout(pl)
+            ws = self.workspace(wsb, rec.tape.device)
+            if self.debug_delay_levels and self.debug_delay_levels[1]:
+                torch.cuda._sleep(int(self.debug_delay_levels[1]))
+            rc = _lib.lib().tef_net_pass_forward_levels(ctypes.byref(pl), levels[0], levels[1], _p(rec.xp), rec.states_arr,
+                                                        rec.tape.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+            _lib.check(rc, "tef_net_pass_forward_levels")
+            return None, [rec.tape[so[i]:so[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape)
+                          if levels[0] <= i < levels[1] else None for i in range(n)], rec
         if part & 1:
             _lib.require_device_tensor(x, "network input")
             x = x.contiguous()
@@ -261,14 +295,20 @@ class PassEngine:
             rec.states_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
             rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-            rec.hn = rec.new_states = rec.dec_dstates = None
+            rec.hn = rec.new_states = rec.dec_dstates = rec.dec_event = rec.high_event = rec.hub = None
+            rec.above_valid = 0
         pl = rec.plan
         if part == 2:
             self.make_plan(pl.B, pl.H, pl.W, pl.crop_top, pl.crop_left, 2, pl)
         _, _, wsb, fo, so, _, _ = self.layout(pl)
         B, H, W = rec.x_shape[0], rec.x_shape[2], rec.x_shape[3]
         ws = self.workspace(wsb, rec.tape.device)
-        if part == 3:
+        if levels is not None:
+            if self.debug_delay_levels and self.debug_delay_levels[0]:
+                torch.cuda._sleep(int(self.debug_delay_levels[0]))
+            rc = _lib.lib().tef_net_pass_forward_levels(ctypes.byref(pl), 0, levels[1], rec.xp.data_ptr(), rec.states_arr,
+                                                        rec.tape.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        elif part == 3:
             rc = _lib.lib().tef_net_pass_forward(ctypes.byref(pl), rec.xp.data_ptr(), rec.states_arr, rec.tape.data_ptr(),
                                                  ws.data_ptr(), ws.numel(), _lib.stream_ptr())
         else:
@@ -280,7 +320,8 @@ class PassEngine:
             fshape = (B, plan.nout, H, W)
             flows = [rec.tape[fo[k]:fo[k] + B * plan.nout * H * W].view(fshape) for k in range(n)]
         if part & 1:
-            new_states = [rec.tape[so[i]:so[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape) for i in range(n)]
+            new_states = [rec.tape[so[i]:so[i] + rec.states_in[i].numel()].view(rec.states_in[i].shape)
+                          if (levels is None or i < levels[1]) else None for i in range(n)]
         return flows, new_states, (rec if (keep or part != 3) else None)
 
     # ---- the decoder half of a whole loss window as ONE batch (round 6) --------------------------------------------------
@@ -294,6 +335,12 @@ class PassEngine:
         p0 = recs[0].plan
         B = p0.B
         dev = recs[0].tape.device
+        if self.enc_streams is not None:       # the states were written on the level streams
+            self.join_encoders()
+            cur = torch.cuda.current_stream()
+            for r in recs:
+                if r.stream != cur and not torch.cuda.is_current_stream_capturing():
+                    r.tape.record_stream(cur)
         # the passes' states stacked along the batch: [P * B, C_i, h_i, w_i] (4 copies per window, 16 MB per pass)
         hn = [torch.cat([states[t][i].detach() for t in range(P)], 0) for i in range(n)]
         pl = self.make_plan(P * B, p0.H, p0.W, p0.crop_top, p0.crop_left, 2, None, dec_only=True)
@@ -305,7 +352,7 @@ class PassEngine:
         rec.tape = torch.empty((ntape,), dtype=torch.float32, device=dev)
         rec.geom, rec.x_shape = recs[0].geom, (P * B,) + tuple(recs[0].x_shape[1:])
         rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-        rec.hn, rec.new_states, rec.dec_dstates = hn, None, None
+        rec.hn, rec.new_states, rec.dec_dstates, rec.dec_event, rec.high_event, rec.above_valid, rec.hub = hn, None, None, None, None, 0, None
         ws = self.workspace(wsb, dev)
         rc = _lib.lib().tef_net_pass_forward_part(ctypes.byref(pl), 2, None, None, rec.tape.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   _lib.stream_ptr())
@@ -315,7 +362,7 @@ class PassEngine:
         flows = [[rec.tape[fo[k] + t * per:fo[k] + (t + 1) * per].view(B, plan.nout, H, W) for k in range(n)] for t in range(P)]
         return flows, rec
 
-    def backward(self, rec, dflows, dstates, params, want_dx, part=3, dstates2=None):
+    def backward(self, rec, dflows, dstates, params, want_dx, part=3, dstates2=None, levels=None):
         """-> (gradients w.r.t. the incoming states, gradient w.r.t. the network input or None, parameter gradients for
         autograd).  Parameter gradients are added into the parameters' own .grad buffers when the training loop owns them
         (`direct_grads`: nothing is handed to autograd), otherwise into one fresh zero buffer whose views are returned.
@@ -366,7 +413,21 @@ class PassEngine:
         off = (ctypes.c_longlong * n)()
         dxv = ctypes.c_int(0)
         ws = self.workspace(wsb, dev)
-        if dstates2 is not None and any(g is not None for g in dstates2):
+        if levels is not None:
+            # the encoder levels [lo, hi) alone (part 1), on the current stream; the range above left rec.above_valid
+            lo, hi = levels
+            k_ = 0 if lo == 0 else 1
+            if self.debug_delay_levels and self.debug_delay_levels[k_]:
+                torch.cuda._sleep(int(self.debug_delay_levels[k_]))
+            dst2 = [None if g is None else g.to(torch.float32).contiguous() for g in (dstates2 or [None] * n)]
+            a_dst2 = (ctypes.c_void_p * n)(*[_p(g) for g in dst2])
+            rc = _lib.lib().tef_net_pass_backward_levels(ctypes.byref(pl), lo, hi, int(rec.above_valid) if hi < n else 0, _p(rec.xp),
+                                                         rec.states_arr, rec.tape.data_ptr(), a_dst, a_dst2, 1 if want_dx else 0,
+                                                         gtape.data_ptr(), ctypes.byref(ran), off, ctypes.byref(dxv), ws.data_ptr(),
+                                                         ws.numel(), _lib.stream_ptr())
+            if lo > 0:
+                rec.above_valid = int(dxv.value)
+        elif dstates2 is not None and any(g is not None for g in dstates2):
             # a second addend per new state (window mode: the batched decoders' share, handed over beside autograd)
             dst2 = [None if g is None else g.to(torch.float32).contiguous() for g in dstates2]
             a_dst2 = (ctypes.c_void_p * n)(*[_p(g) for g in dst2])
@@ -383,7 +444,7 @@ class PassEngine:
         shapes = [t_.shape for t_ in (rec.hn if rec.hn is not None else rec.states_in)]      # (a window's decoders: the stacked states)
         dh = [gtape[off[i]:off[i] + shapes[i].numel()].view(shapes[i]) if off[i] >= 0 else None for i in range(n)]
         dx = None
-        if want_dx and (part & 1):
+        if want_dx and (part & 1) and (levels is None or levels[0] == 0):
             ph, pw = rec.geom
             if dxv.value:
                 dx = gtape[dxo:dxo + rec.xp.numel()].view(rec.xp.shape)[:, :, ph:, pw:]
@@ -408,7 +469,7 @@ class PassEngine:
             # ONLY this record: this backward runs on the decoders' stream, and the reduction stream waits for the stream the
             # flush is issued from — encoder records still queued belong to the caller's stream
             self.flush_window(self.wgrad_stream, only=[rec])
-        if rec.queued and part == 1 and self.wgrad_stream is not None and self.wgrad_group:
+        if rec.queued and part == 1 and (levels is None or levels[0] == 0) and self.wgrad_stream is not None and self.wgrad_group:
             # (backward walks the passes last to first and a pass's encoder half is its last piece: when this record is
             # the newest one queued, every queued pass is complete)
             done = self._pending.index(rec) + 1
@@ -440,6 +501,8 @@ class PassEngine:
         the order to reduce them (2 = residual blocks / decoders / heads, 1 = encoders, 3 = all); `between()` runs after
         every half but the last — a data-parallel caller starts the all-reduce of the finished half's gradients there.
         keep: leave the backward calls queued (the caller reduces the other half with a second call)."""
+        if only is None:
+            self.join_encoders()           # (the encoder halves' backward may still be running on the level streams)
         pend = self._pending
         if only is not None:               # these records alone; whatever else is queued stays queued
             pend = [r for r in pend if any(r is o_ for o_ in only)]
@@ -458,6 +521,13 @@ class PassEngine:
                 for _ in parts[:-1]:
                     between()
             return
+        if self.enc_streams is not None and not torch.cuda.is_current_stream_capturing():
+            # arenas made on the level streams, read by the reductions on this one
+            cur = torch.cuda.current_stream()
+            for r in pend:
+                for t in (r.tape, r.gtape, r.xp):
+                    if t is not None:
+                        t.record_stream(cur)
         if stream is not None:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
@@ -564,6 +634,93 @@ class _EncFn(torch.autograd.Function):
         return (None, None, None, dx) + tuple(dh) + tuple(pg)
 
 
+class _EncLowFn(torch.autograd.Function):
+    """Pipelined encoder half, levels [0, split) of a pass, on the engine's low stream: (input, the incoming states of these
+    levels, parameters...) -> their new states.  `all_states`: the incoming states of ALL levels (the pass's record holds
+    them for both ranges); `holder` receives the record for `_EncHighFn`."""
+
+    @staticmethod
+    def forward(ctx, engine, split, all_states, holder, x, *rest):
+        _, new_states, rec = engine.forward(x, list(all_states), keep=True, part=1, levels=(0, split))
+        holder.append(rec)
+        ctx.engine, ctx.rec, ctx.split = engine, rec, split
+        ctx.params = rest[split:]
+        ctx.state_given = [s is not None for s in rest[:split]]
+        ctx.want_dx = bool(x.requires_grad)
+        ctx.set_materialize_grads(False)
+        return tuple(new_states[:split])
+
+    @staticmethod
+    def backward(ctx, *dstates):
+        rec, n = ctx.rec, ctx.engine.plan.levels
+        dec = None
+        if rec is not None:
+            cur = torch.cuda.current_stream()
+            # the upper levels' backward (other stream: the last thing issued there — autograd walks the nodes newest first, the
+            # upper range of pass t - 1 comes after this node) left a gradient for state split - 1 in the arena
+            # (through the caller's stream, which idles during BPTT: on this stack hipStreamEndCapture crashes on a capture in
+            # which the low stream waits for the high one after the high one has waited for the low one —
+            # tools/experiments/capture_topology_probe.py)
+            if rec.high_event is not None:
+                if rec.hub is not None and rec.hub != cur:
+                    rec.hub.wait_stream(rec.high_event)
+                    cur.wait_stream(rec.hub)
+                else:
+                    cur.wait_stream(rec.high_event)
+            if rec.dec_event is not None:
+                cur.wait_stream(rec.dec_event)
+            dec = rec.dec_dstates
+            if dec is not None and not torch.cuda.is_current_stream_capturing():
+                for g in dec:
+                    if g is not None:
+                        g.record_stream(cur)
+        dst = list(dstates) + [None] * (n - ctx.split)
+        dh, dx, pg = ctx.engine.backward(rec, None, dst, ctx.params, ctx.want_dx, part=1, dstates2=dec, levels=(0, ctx.split))
+        if rec is not None:
+            rec.dec_dstates = None
+        ctx.rec = None
+        dh = [g if given else None for g, given in zip(dh[:ctx.split], ctx.state_given)]
+        return (None, None, None, None, dx) + tuple(dh) + tuple(pg)
+
+
+class _EncHighFn(torch.autograd.Function):
+    """Pipelined encoder half, levels [split, n), on the engine's high stream: (the new state of level split - 1, the
+    incoming states of these levels, parameters...) -> their new states.  Its backward leaves the gradient w.r.t. the state
+    below in the pass's gradient arena (rec.above_valid) instead of handing it to autograd, where it would be summed with
+    the next pass's by a launch of its own."""
+
+    @staticmethod
+    def forward(ctx, engine, split, rec, below, *rest):
+        n = engine.plan.levels
+        _, new_states, _ = engine.forward(None, None, keep=True, part=1, rec=rec, levels=(split, n))
+        ctx.engine, ctx.rec, ctx.split = engine, rec, split
+        ctx.params = rest[n - split:]
+        ctx.state_given = [s is not None for s in rest[:n - split]]
+        ctx.set_materialize_grads(False)
+        return tuple(new_states[split:])
+
+    @staticmethod
+    def backward(ctx, *dstates):
+        rec, n, split = ctx.rec, ctx.engine.plan.levels, ctx.split
+        dec = None
+        if rec is not None:
+            cur = torch.cuda.current_stream()
+            if rec.dec_event is not None:
+                cur.wait_stream(rec.dec_event)
+            dec = rec.dec_dstates
+            if dec is not None and not torch.cuda.is_current_stream_capturing():
+                for g in dec:
+                    if g is not None:
+                        g.record_stream(cur)
+        dst = [None] * split + list(dstates)
+        dh, _, pg = ctx.engine.backward(rec, None, dst, ctx.params, False, part=1, dstates2=dec, levels=(split, n))
+        if rec is not None:
+            rec.high_event = torch.cuda.current_stream()      # (the stream to wait for; see _EncLowFn.backward)
+        ctx.rec = None
+        dh = [g if given else None for g, given in zip(dh[split:], ctx.state_given)]
+        return (None, None, None, None) + tuple(dh) + tuple(pg)
+
+
 class _DecFn(torch.autograd.Function):
     """Two-stream pass, second node, on the side stream: (4 new states, parameters...) -> 4 flows."""
 
@@ -616,18 +773,42 @@ class _DecWinFn(torch.autograd.Function):
         # autograd: there it would be added to the next pass's gradient by a launch per state and pass (36 per window);
         # the encoder half's first kernel sums its addends anyway.  The encoder nodes still run — each is reached through
         # the states it produced, with None where nothing else arrives.
+        # (the encoder halves' backward runs on other streams: they wait for this one — the decoders' backward is the last
+        # thing issued on it when they are)
+        done = torch.cuda.current_stream() if engine.enc_streams is not None else None
         for t, r in enumerate(ctx.recs):
             r.dec_dstates = [None if ds[i] is None else ds[i][t * B:(t + 1) * B] for i in range(n)]
+            r.dec_event = done
         ctx.recs = None
         return (None, None, None) + (None,) * (P * n) + tuple(pg)
 
 
 def encode_pass(engine, x, states):
-    """The encoder half of one pass as an autograd node of its own -> (new states, the pass's record for decode_passes)."""
+    """The encoder half of one pass as an autograd node of its own -> (new states, the pass's record for decode_passes).
+    With engine.enc_streams: as two nodes on two streams, levels [0, n/2) and [n/2, n) — the lower levels of this pass run
+    beside the upper levels of the previous one (the caller joins the streams: PassEngine.join_encoders)."""
     params = [p for p in engine.arch.parameters()]
     holder = []
-    new_states = _EncFn.apply(engine, len(states), holder, x, *states, *params)
-    return list(new_states), holder[0]
+    n = len(states)
+    if engine.enc_streams is None or n < 2 or any(s is None for s in states):
+        # (a fresh sequence — None states — takes the single call: its zero states are made on the caller's stream)
+        new_states = _EncFn.apply(engine, n, holder, x, *states, *params)
+        return list(new_states), holder[0]
+    low_s, high_s = engine.enc_streams
+    split = n // 2
+    main = torch.cuda.current_stream()
+    low_s.wait_stream(main)          # the input (loader stage), the weights (optimiser step), a window's first states
+    with torch.cuda.stream(low_s):
+        low = _EncLowFn.apply(engine, split, tuple(states), holder, x, *states[:split], *params)
+    rec = holder[0]
+    rec.hub = main
+    if isinstance(x, torch.Tensor) and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        x.record_stream(low_s)
+    high_s.wait_stream(main)
+    high_s.wait_stream(low_s)        # (everything issued on the low stream so far: this pass's lower levels are its last piece)
+    with torch.cuda.stream(high_s):
+        high = _EncHighFn.apply(engine, split, rec, low[split - 1], *states[split:], *params)
+    return list(low) + list(high), rec
 
 
 def decode_passes(engine, recs, states):

@@ -305,6 +305,11 @@ class Trainer:
             if self.deferred_wgrad and group > 0:
                 self.wgrad_stream = torch.cuda.Stream(device=device)
                 eng.wgrad_stream, eng.wgrad_group = self.wgrad_stream, group
+            # Window mode: the encoder levels of consecutive passes pipelined over two streams (models/engine.py encode_pass:
+            # the lower two levels of pass t + 1 beside the upper two of pass t, forward and backward; TEF_ENC_PIPELINE=0:
+            # the encoder half of a pass as one call on the caller's stream)
+            if self.window_decode and os.environ.get("TEF_ENC_PIPELINE", "1") != "0":
+                eng.enc_streams = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
 
     def close(self):
         """Wait for every stream the trainer launched on and release the engine's device buffers in a fixed order.
@@ -393,7 +398,8 @@ class Trainer:
         work = [{k: (torch.empty_like(v) if k in inplace else inputs[t][k]) for k, v in b.items()} for t, b in enumerate(batches)]
         # In window mode a CAPTURED window keeps its weight-gradient reductions on the capture stream (round 6, measured: the
         # window is bound by the sum of its kernels, and a replayed graph gains nothing from the third stream — 31.9 ms
-        # against 32.4 with groups of three passes on it; the eager window, whose launches the host feeds, keeps the stream)
+        # against 32.4 with groups of three passes on it, 30.7 against 31.4 with the pipelined encoder levels; the eager
+        # window, whose launches the host feeds, keeps the stream)
         eng_ = getattr(getattr(self.model, "arch", None), "_engine", None)
         saved_wgrad = None
         if self.window_decode and eng_ is not None and eng_.wgrad_stream is not None:
@@ -600,6 +606,9 @@ class Trainer:
         reductions that ran beside BPTT.  Under DP the last reduction is split: the decoder half first, then `between`
         (eager: start that half's all-reduce on the communication stream), then the encoder half.  A captured window
         records the two halves in two graphs (stage 1, stage 2) with the collective between them."""
+        eng_ = getattr(getattr(self.model, "arch", None), "_engine", None)
+        if eng_ is not None:
+            eng_.join_encoders()      # (window mode: the encoder halves' backward ran on the level streams)
         if not self.deferred_wgrad:
             return
         def tail_done():       # every reduction has been issued: wait for the ones that ran beside BPTT on the side stream

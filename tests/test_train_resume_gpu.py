@@ -200,8 +200,17 @@ def test_checkpoint_resume_continues_the_run(dev, tmp_path):
     if noise == 0.0 and lnoise == 0.0:
         assert c[1] == a[1] and torch.equal(c[2], a[2]), "the resumed run differs from the uninterrupted one"
     else:
-        assert abs(c[1] - a[1]) <= max(10 * lnoise, 1e-6 * abs(a[1]))
-        assert (c[2] - a[2]).abs().max().item() <= max(10 * noise, 1e-6 * a[2].abs().max().item())
+        # The noise of this run is heavy-tailed: Adam divides by sqrt(v), so a gradient element near zero whose last bits
+        # differ moves its parameter by up to 2 lr in one run and not at all in the next — the LARGEST difference of a few
+        # pairs of runs says little about the next pair (this assertion failed one run in four on it, then one in ten).
+        # What a broken restore looks like is different in kind: moments, weights or recurrent state not restored move
+        # (nearly) EVERY parameter by about lr, and the loss in its leading digits.  So: the share of parameters that moved.
+        def moved(x, y):
+            return ((x - y).abs() > 1e-7 + 1e-5 * y.abs()).double().mean().item()
+
+        share = max(moved(a[2], b[2]), moved(a[2], b2[2]), moved(b[2], b2[2]))
+        assert abs(c[1] - a[1]) <= max(10 * lnoise, 1e-5 * abs(a[1]))
+        assert moved(c[2], a[2]) <= max(5 * share, 1e-3), (moved(c[2], a[2]), share, noise)
 
 
 def test_reference_format_state_dict_loads_through_load_model(dev, tmp_path):
