@@ -3,7 +3,7 @@
 a second, independent chain of launches hide?  Two networks' encoder halves (10 passes each, forward only), first one after
 the other on one stream, then side by side on two streams — the shape a level-pipelined encoder walker would have.
 
-    python tools/encoder_overlap_probe.py
+    python tools/encoder_overlap_probe.py [CHAINS]
 """
 import os
 import sys
@@ -26,14 +26,15 @@ def main():
 
     dev = torch.device("cuda:0")
     cfg = copy.deepcopy(train.DEFAULT_CONFIG)
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     nets = []
-    for k in range(2):
+    for k in range(N):
         torch.manual_seed(k)
         m = RecEVFlowNet(cfg["model"].copy() if isinstance(cfg["model"], dict) else cfg["model"]).to(dev)
         nets.append(m)
     P, B = 10, 8
     xs = [torch.rand(B, 2, 128, 128, device=dev) for _ in range(P)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream() for _ in range(N)]
 
     def chain(m, n=P):
         eng = m.arch.engine
@@ -52,8 +53,8 @@ def main():
 
     def one_after_the_other():
         with torch.no_grad():
-            chain(nets[0])
-            chain(nets[1])
+            for m in nets:
+                chain(m)
 
     def side_by_side():
         with torch.no_grad():
@@ -64,7 +65,7 @@ def main():
             engs = [m.arch.engine for m in nets]
             states = [[None] * engs[0].plan.levels for _ in nets]
             for t in range(P):
-                for k in range(2):
+                for k in range(N):
                     with torch.cuda.stream(streams[k]):
                         _, states[k], _ = engs[k].forward(xs[t], states[k], keep=False, part=1)
             for s in streams:
@@ -85,7 +86,7 @@ def main():
 
     a = timed(one_after_the_other)
     b = timed(side_by_side)
-    print(f"eager: two encoder chains of {P} passes one after the other {a:.3f} ms, side by side on two streams {b:.3f} ms ({b / a:.3f})")
+    print(f"eager: {N} encoder chains of {P} passes one after the other {a:.3f} ms, side by side on {N} streams {b:.3f} ms ({b / a:.3f})")
     ga, gb = graph_of(one_after_the_other), graph_of(side_by_side)
     a = timed(ga.replay)
     b = timed(gb.replay)
