@@ -840,7 +840,8 @@ def bench_train(a, torch, dist, dev, rank, world, lib):
                                    f"B={a.batch}/GPU, N={a.events}+{a.detached} (BASELINE.json configs[2]/[3])",
                        "global_batch": a.batch * world, "parallelism": f"dp{world} (RCCL all-reduce SUM of 125.5 MB grads)",
                        "launch": "hipGraph replay of the whole window" if a.graph else "eager",
-                       "streams": 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)},
+                       "streams": 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)
+                                  + 2 * (getattr(tr.model.arch.engine, "enc_streams", None) is not None)},
             "loss": round(float(tr.last_loss.item()), 6),
             "host_enqueue_ms_per_step": round(1e3 * t_enqueue / a.steps, 3),
             "conv_gflop_per_pass_fwd": round(fl_pass / 1e9, 2),
@@ -954,16 +955,18 @@ def one_stream(tr):
     @contextlib.contextmanager
     def ctx():
         eng = getattr(getattr(tr.model, "arch", None), "engine", None)
-        saved = (tr.dec_stream, eng.side_stream if eng is not None else None, eng.wgrad_stream if eng is not None else None)
+        saved = (tr.dec_stream, eng.side_stream if eng is not None else None, eng.wgrad_stream if eng is not None else None,
+                 getattr(eng, "enc_streams", None))
         tr.dec_stream = None
         if eng is not None:
-            eng.side_stream = eng.wgrad_stream = None
+            eng.join()
+            eng.side_stream = eng.wgrad_stream = eng.enc_streams = None      # (enc_streams: the pipelined encoder levels, round 6)
         try:
             yield
         finally:
             tr.dec_stream = saved[0]
             if eng is not None:
-                eng.side_stream, eng.wgrad_stream = saved[1], saved[2]
+                eng.side_stream, eng.wgrad_stream, eng.enc_streams = saved[1], saved[2], saved[3]
 
     return ctx()
 
@@ -1020,7 +1023,8 @@ def train_extra(a, torch, dev):
         lib.tef_profile_enable(0)
         flops = 3 * conv_flops_per_pass(a.batch, a.res[0], a.res[1]) * a.passes
         ev = a.batch * a.passes * (a.events + a.detached)
-        tr_streams = 1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)
+        tr_streams = (1 + (tr.dec_stream is not None) + (tr.wgrad_stream is not None)
+                      + 2 * (getattr(tr.model.arch.engine, "enc_streams", None) is not None))
         win_mode = bool(getattr(tr, "window_decode", False))
         del tr, window
         release_now(torch)
@@ -1035,8 +1039,9 @@ def train_extra(a, torch, dev):
                 "window_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                 "window_frac_of_fp32_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                 "streams": tr_streams,
-                # (round 6) encoder halves pass by pass, the decoder halves of the window as one batch (train.Trainer.window_decode);
-                # the captured window keeps its weight-gradient reductions on the capture stream, the eager one on a second stream
+                # (round 6) encoder halves pass by pass — their levels pipelined over two streams —, the decoder halves of the window
+                # as one batch (train.Trainer.window_decode); the captured window keeps its weight-gradient reductions on the
+                # capture stream, the eager one on a stream of their own
                 "window_decode": win_mode}
     except Exception as e:                                    # noqa: BLE001
         return {"error": repr(e)}
