@@ -49,6 +49,7 @@ torch.cuda.current_stream = lambda *a, **k: _Stream()
 torch.cuda.Stream = lambda *a, **k: _Stream()
 torch.cuda.stream = lambda s: contextlib.nullcontext()
 torch.Tensor.record_stream = lambda self, s: None
+torch.cuda.is_current_stream_capturing = lambda: False
 
 from taming_event_flow_amd import synth, train  # noqa: E402
 from taming_event_flow_amd.dataloader import base as dl_base  # noqa: E402
@@ -98,6 +99,8 @@ def window(cfg, passes, wgrad_group, streams, new_seq_at=None, events=600, windo
         if not window_decode:
             e.side_stream = _Stream()
             tr.dec_stream = e.side_stream
+        else:         # the encoder levels of consecutive passes by level range (tef_net_pass_forward_levels / _backward_levels)
+            e.enc_streams = (_Stream(), _Stream())
     src = train.SyntheticSequences(cfg, dev, events, seq_len=10 ** 9, seed=3, jitter=50)
     tr.reset()
     steps = 0
