@@ -53,7 +53,7 @@ class _Tape:
     """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
     __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape", "gtape", "ran", "targets_set", "queued",
-                 "stream", "hn", "new_states", "dec_dstates", "dec_event", "high_event", "above_valid", "hub")
+                 "stream", "hn", "new_states", "dec_dstates", "dec_event", "high_event", "above_valid", "hub", "dec_token")
 
 
 class PassEngine:
@@ -69,6 +69,7 @@ class PassEngine:
         # window mode: (low stream, high stream) — the encoder levels [0, n/2) of pass t + 1 run beside the levels [n/2, n) of
         # pass t (encode_pass); None: the encoder half of a pass is one call on the caller's stream
         self.enc_streams = None
+        self._dec_seen = {}              # stream -> the window (token) whose batched decoders' backward it has waited for
         self.debug_delay_levels = None   # tests: cycles of spinning in front of the (lower, upper) level ranges, forward and backward
         self.debug_delay = None       # tests: cycles of spinning put in front of the (encoder halves, decoder halves[, weight-gradient groups])
         # two-stream windows: the deferred weight gradients of every `wgrad_group` finished backward passes are reduced on
@@ -118,6 +119,15 @@ class PassEngine:
         if self.side_stream is not None:
             torch.cuda.current_stream().wait_stream(self.side_stream)
         self.join_encoders()
+
+    def dec_wait_needed(self, stream, rec):
+        """Whether `stream` still has to wait for the batched decoders' backward of rec's window: the first encoder node of
+        the window on that stream waits, the later ones are ordered behind it."""
+        key = stream.cuda_stream
+        if self._dec_seen.get(key) is rec.dec_token:
+            return False
+        self._dec_seen[key] = rec.dec_token
+        return True
 
     def join_encoders(self):
         """Make the current stream wait for the pipelined encoder halves issued so far (enc_streams)."""
@@ -295,7 +305,7 @@ class PassEngine:
             rec.states_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
             rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-            rec.hn = rec.new_states = rec.dec_dstates = rec.dec_event = rec.high_event = rec.hub = None
+            rec.hn = rec.new_states = rec.dec_dstates = rec.dec_event = rec.high_event = rec.hub = rec.dec_token = None
             rec.above_valid = 0
         pl = rec.plan
         if part == 2:
@@ -352,7 +362,7 @@ class PassEngine:
         rec.tape = torch.empty((ntape,), dtype=torch.float32, device=dev)
         rec.geom, rec.x_shape = recs[0].geom, (P * B,) + tuple(recs[0].x_shape[1:])
         rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-        rec.hn, rec.new_states, rec.dec_dstates, rec.dec_event, rec.high_event, rec.above_valid, rec.hub = hn, None, None, None, None, 0, None
+        rec.hn, rec.new_states, rec.dec_dstates, rec.dec_event, rec.high_event, rec.above_valid, rec.hub, rec.dec_token = hn, None, None, None, None, 0, None, None
         ws = self.workspace(wsb, dev)
         rc = _lib.lib().tef_net_pass_forward_part(ctypes.byref(pl), 2, None, None, rec.tape.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   _lib.stream_ptr())
@@ -667,7 +677,7 @@ class _EncLowFn(torch.autograd.Function):
                     cur.wait_stream(rec.hub)
                 else:
                     cur.wait_stream(rec.high_event)
-            if rec.dec_event is not None:
+            if rec.dec_event is not None and ctx.engine.dec_wait_needed(cur, rec):
                 cur.wait_stream(rec.dec_event)
             dec = rec.dec_dstates
             if dec is not None and not torch.cuda.is_current_stream_capturing():
@@ -705,7 +715,7 @@ class _EncHighFn(torch.autograd.Function):
         dec = None
         if rec is not None:
             cur = torch.cuda.current_stream()
-            if rec.dec_event is not None:
+            if rec.dec_event is not None and ctx.engine.dec_wait_needed(cur, rec):
                 cur.wait_stream(rec.dec_event)
             dec = rec.dec_dstates
             if dec is not None and not torch.cuda.is_current_stream_capturing():
@@ -776,17 +786,20 @@ class _DecWinFn(torch.autograd.Function):
         # (the encoder halves' backward runs on other streams: they wait for this one — the decoders' backward is the last
         # thing issued on it when they are)
         done = torch.cuda.current_stream() if engine.enc_streams is not None else None
+        token = object()
         for t, r in enumerate(ctx.recs):
             r.dec_dstates = [None if ds[i] is None else ds[i][t * B:(t + 1) * B] for i in range(n)]
-            r.dec_event = done
+            r.dec_event, r.dec_token = done, token
         ctx.recs = None
         return (None, None, None) + (None,) * (P * n) + tuple(pg)
 
 
-def encode_pass(engine, x, states):
+def encode_pass(engine, x, states, first=True):
     """The encoder half of one pass as an autograd node of its own -> (new states, the pass's record for decode_passes).
     With engine.enc_streams: as two nodes on two streams, levels [0, n/2) and [n/2, n) — the lower levels of this pass run
-    beside the upper levels of the previous one (the caller joins the streams: PassEngine.join_encoders)."""
+    beside the upper levels of the previous one (the caller joins the streams: PassEngine.join_encoders).
+    first: the first pass of its window (a captured window's later passes need no new dependency on the caller's stream:
+    their inputs are static buffers written before the first one)."""
     params = [p for p in engine.arch.parameters()]
     holder = []
     n = len(states)
@@ -797,15 +810,19 @@ def encode_pass(engine, x, states):
     low_s, high_s = engine.enc_streams
     split = n // 2
     main = torch.cuda.current_stream()
-    low_s.wait_stream(main)          # the input (loader stage), the weights (optimiser step), a window's first states
+    # the input (loader stage), the weights (optimiser step), a window's first states.  (Every cross-stream dependency is a
+    # node of a captured window: spelled out at every pass they cost the replay 0.3 ms)
+    if first or not torch.cuda.is_current_stream_capturing():
+        low_s.wait_stream(main)
     with torch.cuda.stream(low_s):
         low = _EncLowFn.apply(engine, split, tuple(states), holder, x, *states[:split], *params)
     rec = holder[0]
     rec.hub = main
     if isinstance(x, torch.Tensor) and x.is_cuda and not torch.cuda.is_current_stream_capturing():
         x.record_stream(low_s)
-    high_s.wait_stream(main)
-    high_s.wait_stream(low_s)        # (everything issued on the low stream so far: this pass's lower levels are its last piece)
+    # everything issued on the low stream so far — this pass's lower levels are its last piece, and what the low stream has
+    # waited for on the caller's stream comes with it
+    high_s.wait_stream(low_s)
     with torch.cuda.stream(high_s):
         high = _EncHighFn.apply(engine, split, rec, low[split - 1], *states[split:], *params)
     return list(low) + list(high), rec
