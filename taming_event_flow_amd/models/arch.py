@@ -204,7 +204,8 @@ class MultiResUNetRecurrent(nn.Module):
     def encode(self, x):
         """The encoder half of one pass: updates `states` and queues the pass for decode_window().  Needs the training
         loop's in-place gradient buffers (direct_grads) like every split pass."""
-        new_states, rec = encode_pass(self.engine, x, self.states, first=not self._window)
+        # (first: no pass of this window has gone onto the level streams yet — a fresh sequence's first pass does not)
+        new_states, rec = encode_pass(self.engine, x, self.states, first=not any(r.hub is not None for r, _ in self._window))
         self.states = new_states
         self._window.append((rec, new_states))
 
