@@ -214,6 +214,63 @@ def test_two_node_pass_matches_fused(dev, nres):
         assert float(b.abs().max()) > 0 and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
 
 
+@pytest.mark.parametrize("nres", [2, 0])
+def test_window_mode_and_level_pipeline_match_fused(dev, nres):
+    """Window mode at the level of the model (arch.encode per pass, arch.decode_window once: the decoder halves of all passes
+    as one batch, `_DecWinFn`) and its encoder halves pipelined by level over two streams (`_EncLowFn` / `_EncHighFn` on
+    tef_net_pass_forward_levels / _backward_levels; the first pass — no states yet — takes the single call) against the
+    one-node pass: four recurrent passes, a head of each pass without gradient, the input's gradient wanted.  States
+    bit-identical (the encoder halves are the same launches); flows to fp32 summation order against the one-node pass (a
+    batch of P x B samples is tiled and split over k differently) and bit-identical between the two window forms; gradients
+    to fp32 summation order."""
+    from taming_event_flow_amd import parallel
+    from taming_event_flow_amd.models import submodules
+    from taming_event_flow_amd.models.model import RecEVFlowNet
+
+    P = 4
+    rng = np.random.default_rng(41 + nres)
+    xs_np = [rng.poisson(0.4, (2, 2, 32, 48)).astype(np.float32) for _ in range(P)]
+    rs = [[torch.tensor(rng.standard_normal((2, 2, 32, 48)).astype(np.float32), device=dev) for _ in range(4)] for _ in range(P)]
+
+    def run(mode):
+        net = load_weights(RecEVFlowNet({"name": "RecEVFlowNet", "final_w_scale": 0.01, "num_residual_blocks": nres}, 2), 9, dev)
+        net.train()
+        bucket = parallel.FlatGradBucket(net.parameters())
+        submodules.enable_direct_grads(net)
+        eng = net.arch.engine
+        if mode == "pipeline":
+            eng.enc_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        xs = [torch.tensor(x, device=dev, requires_grad=True) for x in xs_np]
+        if mode == "fused":
+            flows_all = [net(xs[t])["flow"] for t in range(P)]
+        else:
+            for t in range(P):
+                net.arch.encode(xs[t])
+            flows_all = net.arch.decode_window()
+        loss = sum((f * r).sum() for t in range(P) for f, r in zip(flows_all[t][1:], rs[t][1:]))
+        loss.backward()
+        eng.join()
+        eng.flush_window()
+        torch.cuda.synchronize()
+        return ([[f.detach().clone() for f in fl] for fl in flows_all], [s.detach().clone() for s in net.arch.states],
+                bucket.flat.clone(), [x.grad.clone() for x in xs])
+
+    ref = run("fused")
+    first = None
+    for mode in ("window", "pipeline"):
+        got = run(mode)
+        for t in range(P):
+            for i in range(4):
+                assert rel_err(got[0][t][i].cpu().numpy(), ref[0][t][i].cpu().numpy()) <= 1e-5, (mode, t, i)
+                assert first is None or torch.equal(got[0][t][i], first[0][t][i]), (mode, t, i)
+        first = first or got
+        for a, b in zip(got[1], ref[1]):
+            assert torch.equal(a, b), mode
+        assert rel_err(got[2].cpu().numpy(), ref[2].cpu().numpy()) <= 2e-5, mode
+        for a, b in zip(got[3], ref[3]):
+            assert float(b.abs().max()) > 0 and rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5, mode
+
+
 @pytest.mark.parametrize("two", [False, True])
 def test_backward_twice_is_refused(dev, two):
     """The fused pass releases its activation arena after its backward (a BPTT window holds ten of them): a second
