@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--case", type=int, required=True)
     ap.add_argument("--ragged-windows", action="store_true")
     ap.add_argument("--no-smooth", action="store_true", help="drop the smoothing terms")
+    ap.add_argument("--frac", type=float, default=0.1, help="a subset is kept while it shows this share of the whole case's mismatch")
     ap.add_argument("--keep", default=None, help="events to keep instead of searching, e.g. pm:4:0:41,dpm:3:0:7")
     ap.add_argument("--set", default=None, help="overrides of the case's settings, e.g. S=1,mode=two")
     a = ap.parse_args()
@@ -125,12 +126,13 @@ def main():
         i = 0
         while i < len(keep) and len(keep) > 1:
             trial = keep[:i] + keep[i + chunk:]
-            if trial and err(masked(trial))[0] > 0.1 * base:
+            if trial and err(masked(trial))[0] > a.frac * base:
                 keep = trial
             else:
                 i += chunk
         chunk //= 2
-    print(len(keep), "events left:", keep, err(masked(keep)))
+    print(len(keep), "events left:", keep[:40], "..." if len(keep) > 40 else "")
+    print("their mismatch:", err(masked(keep), show=8))
     for k, t, b, j in keep:
         lst = win["ev" if k == "pm" else "dev"][t][b, j]
         print("  ", k, t, b, j, "event (ts, y, x, p) =", [repr(float(v)) for v in lst], "mask", win[k][t][b, j])
