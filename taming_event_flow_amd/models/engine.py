@@ -53,7 +53,7 @@ class _Tape:
     """What one forward pass leaves for its backward: the plan it ran with, its inputs and its activation arena."""
 
     __slots__ = ("plan", "xp", "states_in", "states_arr", "tape", "geom", "x_shape", "gtape", "ran", "targets_set", "queued",
-                 "stream", "hn", "new_states", "dec_dstates", "dec_event", "high_event", "above_valid", "hub", "dec_token")
+                 "stream", "hn", "new_states", "dec_dstates", "dec_stream", "high_stream", "above_valid", "hub", "dec_token")
 
 
 class PassEngine:
@@ -305,7 +305,7 @@ class PassEngine:
             rec.states_arr = (ctypes.c_void_p * n)(*[s.data_ptr() for s in st])
             rec.geom, rec.x_shape = (ph, pw), tuple(x.shape)
             rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-            rec.hn = rec.new_states = rec.dec_dstates = rec.dec_event = rec.high_event = rec.hub = rec.dec_token = None
+            rec.hn = rec.new_states = rec.dec_dstates = rec.dec_stream = rec.high_stream = rec.hub = rec.dec_token = None
             rec.above_valid = 0
         pl = rec.plan
         if part == 2:
@@ -362,7 +362,7 @@ class PassEngine:
         rec.tape = torch.empty((ntape,), dtype=torch.float32, device=dev)
         rec.geom, rec.x_shape = recs[0].geom, (P * B,) + tuple(recs[0].x_shape[1:])
         rec.gtape, rec.ran, rec.targets_set, rec.queued, rec.stream = None, 0, False, False, torch.cuda.current_stream()
-        rec.hn, rec.new_states, rec.dec_dstates, rec.dec_event, rec.high_event, rec.above_valid, rec.hub, rec.dec_token = hn, None, None, None, None, 0, None, None
+        rec.hn, rec.new_states, rec.dec_dstates, rec.dec_stream, rec.high_stream, rec.above_valid, rec.hub, rec.dec_token = hn, None, None, None, None, 0, None, None
         ws = self.workspace(wsb, dev)
         rc = _lib.lib().tef_net_pass_forward_part(ctypes.byref(pl), 2, None, None, rec.tape.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   _lib.stream_ptr())
@@ -671,14 +671,14 @@ class _EncLowFn(torch.autograd.Function):
             # (through the caller's stream, which idles during BPTT: on this stack hipStreamEndCapture crashes on a capture in
             # which the low stream waits for the high one after the high one has waited for the low one —
             # tools/experiments/capture_topology_probe.py)
-            if rec.high_event is not None:
+            if rec.high_stream is not None:
                 if rec.hub is not None and rec.hub != cur:
-                    rec.hub.wait_stream(rec.high_event)
+                    rec.hub.wait_stream(rec.high_stream)
                     cur.wait_stream(rec.hub)
                 else:
-                    cur.wait_stream(rec.high_event)
-            if rec.dec_event is not None and ctx.engine.dec_wait_needed(cur, rec):
-                cur.wait_stream(rec.dec_event)
+                    cur.wait_stream(rec.high_stream)
+            if rec.dec_stream is not None and ctx.engine.dec_wait_needed(cur, rec):
+                cur.wait_stream(rec.dec_stream)
             dec = rec.dec_dstates
             if dec is not None and not torch.cuda.is_current_stream_capturing():
                 for g in dec:
@@ -715,8 +715,8 @@ class _EncHighFn(torch.autograd.Function):
         dec = None
         if rec is not None:
             cur = torch.cuda.current_stream()
-            if rec.dec_event is not None and ctx.engine.dec_wait_needed(cur, rec):
-                cur.wait_stream(rec.dec_event)
+            if rec.dec_stream is not None and ctx.engine.dec_wait_needed(cur, rec):
+                cur.wait_stream(rec.dec_stream)
             dec = rec.dec_dstates
             if dec is not None and not torch.cuda.is_current_stream_capturing():
                 for g in dec:
@@ -725,7 +725,7 @@ class _EncHighFn(torch.autograd.Function):
         dst = [None] * split + list(dstates)
         dh, _, pg = ctx.engine.backward(rec, None, dst, ctx.params, False, part=1, dstates2=dec, levels=(split, n))
         if rec is not None:
-            rec.high_event = torch.cuda.current_stream()      # (the stream to wait for; see _EncLowFn.backward)
+            rec.high_stream = torch.cuda.current_stream()      # (the stream to wait for; see _EncLowFn.backward)
         ctx.rec = None
         dh = [g if given else None for g, given in zip(dh[split:], ctx.state_given)]
         return (None, None, None, None) + tuple(dh) + tuple(pg)
@@ -789,7 +789,7 @@ class _DecWinFn(torch.autograd.Function):
         token = object()
         for t, r in enumerate(ctx.recs):
             r.dec_dstates = [None if ds[i] is None else ds[i][t * B:(t + 1) * B] for i in range(n)]
-            r.dec_event, r.dec_token = done, token
+            r.dec_stream, r.dec_token = done, token
         ctx.recs = None
         return (None, None, None) + (None,) * (P * n) + tuple(pg)
 
